@@ -1,0 +1,87 @@
+"""ctypes binding of libgcanet_hip.so (the C ABI declared in include/gcanet_hip.h).
+
+The argument types of every entry point are derived from the header itself, so the
+header is the single source of truth for the boundary.  There is NO fallback: if the
+library is missing or a call fails, a RuntimeError is raised (the reference raises
+RuntimeError via AT_ASSERT, P2/_ext-src/include/utils.h:5-25; it never silently degrades).
+"""
+import ctypes as C
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "gcanet_hip.h")
+SO_PATH = os.path.join(_HERE, "lib", "libgcanet_hip.so")
+
+_PROTO = re.compile(r"^\s*(const\s+char\s*\*|int)\s*(gcn_\w+)\s*\(([^;]*?)\)\s*;", re.S | re.M)
+
+
+def parse_header(path=HEADER):
+    """-> {name: (restype, [argtypes])} for every prototype in the header."""
+    text = re.sub(r"/\*.*?\*/", "", open(path).read(), flags=re.S)
+    protos = {}
+    for ret, name, args in _PROTO.findall(text):
+        argtypes = []
+        for a in [x.strip() for x in args.replace("\n", " ").split(",")]:
+            if a in ("void", ""):
+                continue
+            if "*" in a:
+                argtypes.append(C.c_void_p)
+            elif re.match(r"(const\s+)?float\b", a):
+                argtypes.append(C.c_float)
+            elif re.match(r"(const\s+)?(long|int64_t)\b", a):
+                argtypes.append(C.c_int64)
+            elif re.match(r"(const\s+)?(int|int32_t)\b", a):
+                argtypes.append(C.c_int)
+            else:
+                raise ValueError("unhandled parameter %r in %s" % (a, name))
+        protos[name] = (C.c_char_p if "char" in ret else C.c_int, argtypes)
+    return protos
+
+
+_lib = None
+
+
+def lib():
+    """Load the library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise RuntimeError(
+                "gcanet_amd: %s not found -- build it with `python -m gcanet_amd.build` "
+                "(there is no CPU fallback)" % SO_PATH)
+        dll = C.CDLL(SO_PATH)
+        for name, (res, args) in parse_header().items():
+            fn = getattr(dll, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = dll
+    return _lib
+
+
+def call(name, *args):
+    """Invoke an entry point; non-zero status -> RuntimeError with gcn_last_error()."""
+    dll = lib()
+    rc = getattr(dll, name)(*args)
+    if rc != 0:
+        raise RuntimeError("%s failed (status %d): %s" % (name, rc, dll.gcn_last_error().decode()))
+
+
+def ptr(t):
+    """Device (or host) address of a torch tensor / None."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def stream_of(t):
+    """Raw hipStream_t of torch's current stream on the tensor's device."""
+    import torch
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("gcanet_amd: expected a GPU tensor (the reference asserts 'CPU not supported', "
+                               "P2/_ext-src/src/group_points.cpp:31-33); got device %s" % t.device)

@@ -1,0 +1,63 @@
+// common.h -- shared helpers for the gfx950 kernels of libgcanet_hip.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "gcanet_hip.h"
+
+#define GCN_EXPORT extern "C" __attribute__((visibility("default")))
+
+namespace gcn {
+
+void set_error(const char *fmt, ...);
+
+inline int check_launch(const char *what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return GCN_ELAUNCH;
+  }
+  return GCN_OK;
+}
+
+#define GCN_REQUIRE(cond, ...)        \
+  do {                                \
+    if (!(cond)) {                    \
+      gcn::set_error(__VA_ARGS__);    \
+      return GCN_EINVAL;              \
+    }                                 \
+  } while (0)
+
+#define GCN_HIP(call)                                                   \
+  do {                                                                  \
+    hipError_t e_ = (call);                                             \
+    if (e_ != hipSuccess) {                                             \
+      gcn::set_error("%s: %s", #call, hipGetErrorString(e_));           \
+      return GCN_ELAUNCH;                                               \
+    }                                                                   \
+  } while (0)
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+// wave id within the block as a scalar (SGPR) value
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
+__device__ __forceinline__ float readlane_f(float v, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+__device__ __forceinline__ int readlane_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+
+// lane i <- lane i-1 across the whole wave (DPP wave_shr:1); lane 0 <- lane0_val
+__device__ __forceinline__ int wave_shr1_i(int lane0_val, int v) {
+  return __builtin_amdgcn_update_dpp(lane0_val, v, 0x138, 0xf, 0xf, false);
+}
+__device__ __forceinline__ float wave_shr1_f(float lane0_val, float v) {
+  return __builtin_bit_cast(float, wave_shr1_i(__builtin_bit_cast(int, lane0_val), __builtin_bit_cast(int, v)));
+}
+
+inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace gcn

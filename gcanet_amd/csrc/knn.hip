@@ -1,0 +1,299 @@
+// knn.hip -- fused brute-force kNN for gfx950 (CDNA4, wave64).
+//
+// Replaces KNN_CUDA's three kernels (models/KNN_CUDA/knn_cuda/csrc/cuda/knn.cu:29-183:
+// materialised (nr,nq) distance matrix -> per-thread global-memory insertion sort ->
+// sqrt) and the pure-torch N x N `knn` / `knn_points_normals` + topk of
+// models/dgcnn-hais-concat-direct-4.py:30-90 with ONE kernel that never writes the
+// distance matrix.
+//
+// Design (wave64-first, not a warp tiling):
+//   * one wave owns QW queries; its 64 lanes each take one candidate of a 64-wide batch,
+//     so a batch's candidate coordinates are one coalesced 256-B load per dimension and
+//     are reused for all QW queries from registers;
+//   * query coordinates are wave-uniform -> scalar loads, SGPR operands of v_fma;
+//   * the running top-k of a query is a SORTED list held one entry per lane (k <= 64) or
+//     KPL entries per lane (k <= 64*KPL): insertion = ballot + popcount for the position,
+//     one DPP wave_shr:1 to open the slot.  The k-th key is a scalar threshold, so the
+//     steady state per (query, batch) is: distance, one v_cmp against an SGPR, one scalar
+//     branch.
+//   * candidates are visited in ascending index and inserted behind equal keys, so ties
+//     resolve to the LOWEST index exactly like the reference's stable insertion sort
+//     (knn.cu:125-131) -- bit-exact indices vs oracle/gcanet_oracle.c.
+// Arithmetic follows the oracle's contraction convention (explicit fmaf chains; the file
+// is compiled with -ffp-contract=off).
+#include "common.h"
+
+namespace gcn {
+
+#define KNN_INF __builtin_inff()
+
+template <int KPL>
+struct TopK {
+  float key[KPL];
+  int idx[KPL];
+
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int s = 0; s < KPL; ++s) {
+      key[s] = KNN_INF;
+      idx[s] = 0x7fffffff;
+    }
+  }
+  // key at sorted position kslot*64 + klane (wave-uniform result)
+  __device__ __forceinline__ float kth(int kslot, int klane) const {
+    float t = KNN_INF;
+#pragma unroll
+    for (int s = 0; s < KPL; ++s)
+      if (s == kslot) t = readlane_f(key[s], klane);
+    return t;
+  }
+  // insert (ckey, cidx) behind all entries with key <= ckey; the last entry falls off
+  __device__ __forceinline__ void insert(float ckey, int cidx, int lane) {
+    int pos = 0;
+#pragma unroll
+    for (int s = 0; s < KPL; ++s) pos += __popcll(__ballot(key[s] <= ckey));
+#pragma unroll
+    for (int s = KPL - 1; s >= 0; --s) {
+      const int lo = s * 64;
+      if (pos < lo + 64) {
+        float ck = 0.f;
+        int ci = 0;
+        if (s > 0) {
+          ck = readlane_f(key[s - 1], 63);
+          ci = readlane_i(idx[s - 1], 63);
+        }
+        const float sk = wave_shr1_f(ck, key[s]);
+        const int si = wave_shr1_i(ci, idx[s]);
+        const int lp = pos - lo;
+        key[s] = lane < lp ? key[s] : (lane == lp ? ckey : sk);
+        idx[s] = lane < lp ? idx[s] : (lane == lp ? cidx : si);
+      }
+    }
+  }
+};
+
+struct KnnArgs {
+  const float *ref;    // candidates
+  const float *query;
+  const float *xx;     // (B, nr) squared norms for the model metrics (ref == query there)
+  long ref_sb, ref_sd, ref_sn;  // element (b,d,j) at b*sb + d*sd + j*sn
+  long q_sb, q_sd, q_sn;
+  int dim, nr, nq, k, step;
+  float *dist;   // may be null
+  int64_t *ind;
+  long o_sb, o_sk, o_sq;  // output element (b,t,q) at b*sb + t*sk + q*sq
+};
+
+// METRIC 0: KNN_CUDA direct sum of squared differences (knn.cu:73-77), out dist = sqrt
+// METRIC 1: in-model expanded form (M4:36-38), key = -pairwise_distance
+// METRIC 2: knn_points_normals (M4:62-75), key = p_pd*(1+n_pd)
+template <int KPL, int QW, int METRIC, int DIMC>
+__global__ __launch_bounds__(256) void knn_select_kernel(KnnArgs a) {
+  const int lane = lane_id();
+  const int wave = wave_id();
+  const int b = blockIdx.y;
+  const int q0 = (blockIdx.x * 4 + wave) * QW;
+  if (q0 >= a.nq) return;  // wave-uniform
+  const int dim = DIMC > 0 ? DIMC : a.dim;
+
+  const float *__restrict__ ref = a.ref + (long)b * a.ref_sb;
+  const float *__restrict__ qry = a.query + (long)b * a.q_sb;
+  const float *__restrict__ xx = METRIC == 0 ? nullptr : a.xx + (long)b * a.nr;
+
+  int qi[QW];  // clamped query ids (uniform)
+#pragma unroll
+  for (int q = 0; q < QW; ++q) qi[q] = min(q0 + q, a.nq - 1);
+
+  TopK<KPL> top[QW];
+  float thr[QW];
+#pragma unroll
+  for (int q = 0; q < QW; ++q) {
+    top[q].init();
+    thr[q] = KNN_INF;
+  }
+  const int kslot = (a.k - 1) >> 6, klane = (a.k - 1) & 63;
+
+  float xxi[QW];
+  if (METRIC != 0) {
+#pragma unroll
+    for (int q = 0; q < QW; ++q) xxi[q] = xx[qi[q]];
+  }
+
+  for (int base = 0; base < a.nr; base += 64) {
+    const int j = base + lane;
+    const bool valid = j < a.nr;
+    const int jc = valid ? j : a.nr - 1;
+    float key[QW];
+    if (METRIC == 0) {
+      float acc[QW];
+#pragma unroll
+      for (int q = 0; q < QW; ++q) acc[q] = 0.f;
+#pragma unroll 4
+      for (int d = 0; d < dim; ++d) {
+        const float cv = ref[d * a.ref_sd + jc * a.ref_sn];
+#pragma unroll
+        for (int q = 0; q < QW; ++q) {
+          const float t = cv - qry[d * a.q_sd + qi[q] * a.q_sn];
+          acc[q] = fmaf(t, t, acc[q]);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < QW; ++q) key[q] = valid ? acc[q] : KNN_INF;
+    } else if (METRIC == 1) {
+      float acc[QW];
+#pragma unroll
+      for (int q = 0; q < QW; ++q) acc[q] = 0.f;
+#pragma unroll 4
+      for (int d = 0; d < dim; ++d) {
+        const float cv = ref[d * a.ref_sd + jc * a.ref_sn];
+#pragma unroll
+        for (int q = 0; q < QW; ++q) acc[q] = fmaf(qry[d * a.q_sd + qi[q] * a.q_sn], cv, acc[q]);
+      }
+      const float xxj = xx[jc];
+#pragma unroll
+      for (int q = 0; q < QW; ++q) {
+        const float t = 2.f * acc[q] - xxj;
+        const float pd = t - xxi[q];
+        key[q] = valid ? -pd : KNN_INF;
+      }
+    } else {
+      float cv[6];
+#pragma unroll
+      for (int d = 0; d < 6; ++d) cv[d] = ref[d * a.ref_sd + jc * a.ref_sn];
+      const float xxj = xx[jc];
+#pragma unroll
+      for (int q = 0; q < QW; ++q) {
+        float dp = 0.f, dn = 0.f;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) dp = fmaf(qry[d * a.q_sd + qi[q] * a.q_sn], cv[d], dp);
+#pragma unroll
+        for (int d = 3; d < 6; ++d) dn = fmaf(qry[d * a.q_sd + qi[q] * a.q_sn], cv[d], dn);
+        const float p_pd = (xxj - 2.f * dp) + xxi[q];
+        const float n_pd = 2.f - 2.f * dn;
+        const float pd = p_pd * (1.f + n_pd);
+        key[q] = valid ? pd : KNN_INF;
+      }
+    }
+
+#pragma unroll
+    for (int q = 0; q < QW; ++q) {
+      unsigned long long m = __ballot(key[q] < thr[q]);
+      while (m) {
+        const int l = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const float ck = readlane_f(key[q], l);
+        if (ck < thr[q]) {
+          top[q].insert(ck, base + l, lane);
+          thr[q] = top[q].kth(kslot, klane);
+        }
+      }
+    }
+  }
+
+  // epilogue: sorted ascending by (key, index); position t = s*64 + lane
+#pragma unroll
+  for (int q = 0; q < QW; ++q) {
+    if (q0 + q >= a.nq) break;
+#pragma unroll
+    for (int s = 0; s < KPL; ++s) {
+      const int t = s * 64 + lane;
+      if (t < a.k && (t % a.step) == 0) {
+        const long o = (long)b * a.o_sb + (long)(t / a.step) * a.o_sk + (long)(q0 + q) * a.o_sq;
+        a.ind[o] = (int64_t)top[q].idx[s];
+        if (a.dist) {
+          const float kv = top[q].key[s];
+          a.dist[o] = METRIC == 0 ? sqrtf(kv) : (METRIC == 1 ? -kv : -kv);
+        }
+      }
+    }
+  }
+}
+
+// squared norms in the oracle's order: squares rounded, added left to right (x**2 then sum)
+__global__ void sqnorm_kernel(const float *__restrict__ x, float *__restrict__ xx, int C, int N, int cx) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y;
+  if (j >= N) return;
+  const float *p = x + (long)b * C * N + j;
+  float s = 0.f;
+  for (int c = 0; c < cx; ++c) {
+    const float v = p[(long)c * N];
+    const float sq = v * v;
+    s = c == 0 ? sq : s + sq;
+  }
+  xx[(long)b * N + j] = s;
+}
+
+template <int METRIC, int DIMC>
+static int launch_knn(const KnnArgs &a, int B, hipStream_t st) {
+  const int k = a.k;
+  if (k <= 64) {
+    dim3 grid(cdiv(a.nq, 4 * 8), B);
+    knn_select_kernel<1, 8, METRIC, DIMC><<<grid, 256, 0, st>>>(a);
+  } else if (k <= 128) {
+    dim3 grid(cdiv(a.nq, 4 * 8), B);
+    knn_select_kernel<2, 8, METRIC, DIMC><<<grid, 256, 0, st>>>(a);
+  } else if (k <= 256) {
+    dim3 grid(cdiv(a.nq, 4 * 4), B);
+    knn_select_kernel<4, 4, METRIC, DIMC><<<grid, 256, 0, st>>>(a);
+  } else {
+    dim3 grid(cdiv(a.nq, 4 * 2), B);
+    knn_select_kernel<8, 2, METRIC, DIMC><<<grid, 256, 0, st>>>(a);
+  }
+  return check_launch("knn_select_kernel");
+}
+
+}  // namespace gcn
+
+using namespace gcn;
+
+GCN_EXPORT int gcn_knn_cuda(const float *ref, const float *query, int B, int dim, int nr, int nq, int k,
+                            int point_major, float *dist, int64_t *ind, void *stream) {
+  GCN_REQUIRE(ref && query && dist && ind, "gcn_knn_cuda: null pointer");
+  GCN_REQUIRE(B >= 0 && dim >= 1 && nr >= 1 && nq >= 0, "gcn_knn_cuda: bad shape B=%d dim=%d nr=%d nq=%d", B, dim, nr, nq);
+  GCN_REQUIRE(k >= 1 && k <= nr && k <= 512, "gcn_knn_cuda: need 1 <= k <= min(nr,512), got k=%d nr=%d", k, nr);
+  if (B == 0 || nq == 0) return GCN_OK;
+  KnnArgs a{};
+  a.ref = ref; a.query = query; a.xx = nullptr;
+  a.dim = dim; a.nr = nr; a.nq = nq; a.k = k; a.step = 1;
+  a.ref_sb = (long)dim * nr; a.q_sb = (long)dim * nq;
+  if (point_major) {
+    a.ref_sd = 1; a.ref_sn = dim; a.q_sd = 1; a.q_sn = dim;
+    a.o_sk = 1; a.o_sq = k;
+  } else {
+    a.ref_sd = nr; a.ref_sn = 1; a.q_sd = nq; a.q_sn = 1;
+    a.o_sk = nq; a.o_sq = 1;
+  }
+  a.o_sb = (long)k * nq;
+  a.dist = dist; a.ind = ind;
+  hipStream_t st = (hipStream_t)stream;
+  if (dim == 3) return launch_knn<0, 3>(a, B, st);
+  return launch_knn<0, 0>(a, B, st);
+}
+
+GCN_EXPORT int gcn_knn_model(const float *x, int B, int C, int N, int k1, int k2, int metric,
+                             int64_t *idx, float *val, float *xx_ws, void *stream) {
+  GCN_REQUIRE(x && idx && xx_ws, "gcn_knn_model: null pointer");
+  GCN_REQUIRE(metric == 0 || metric == 1, "gcn_knn_model: metric must be 0 (knn) or 1 (knn_points_normals)");
+  GCN_REQUIRE(B >= 0 && C >= 1 && N >= 1, "gcn_knn_model: bad shape B=%d C=%d N=%d", B, C, N);
+  GCN_REQUIRE(metric == 0 || C >= 6, "gcn_knn_model: knn_points_normals needs C >= 6, got %d", C);
+  GCN_REQUIRE(k1 >= 1 && k1 <= k2 && k2 <= N && k2 <= 512, "gcn_knn_model: need 1 <= k1 <= k2 <= min(N,512), got k1=%d k2=%d N=%d", k1, k2, N);
+  if (B == 0) return GCN_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int step = k2 / k1;
+  const int kout = (k2 + step - 1) / step;
+  dim3 g(cdiv(N, 256), B);
+  sqnorm_kernel<<<g, 256, 0, st>>>(x, xx_ws, C, N, metric == 0 ? C : 3);
+  int rc = check_launch("sqnorm_kernel");
+  if (rc) return rc;
+  KnnArgs a{};
+  a.ref = x; a.query = x; a.xx = xx_ws;
+  a.dim = C; a.nr = N; a.nq = N; a.k = k2; a.step = step;
+  a.ref_sb = a.q_sb = (long)C * N;
+  a.ref_sd = a.q_sd = N; a.ref_sn = a.q_sn = 1;
+  a.o_sb = (long)N * kout; a.o_sk = 1; a.o_sq = kout;
+  a.dist = val; a.ind = idx;
+  if (metric == 1) return launch_knn<2, 6>(a, B, st);
+  if (C == 3) return launch_knn<1, 3>(a, B, st);
+  return launch_knn<1, 0>(a, B, st);
+}

@@ -1,0 +1,420 @@
+// pointnet2.hip -- gfx950 kernels behind the pointnet2_ops boundary
+// (reference: models/Pointnet2_PyTorch-master/pointnet2_ops_lib/pointnet2_ops/_ext-src/src/*.cu).
+//
+// The reference launches grid = b (one block per batch element, 8 blocks on a 256-CU part)
+// with serial inner loops.  These kernels are re-designed for MI355X:
+//   ball_query       one wave per query, 64 candidates per step, ballot/popcount slots
+//   group/gather     element-parallel over (point, sample), 16-B coalesced stores, the
+//                    neighbour ids live in registers across a channel tile
+//   *_grad           scatter-add into an LDS-resident row (n floats) instead of fp32
+//                    global atomics on random addresses (~17x slower, MI355X_MICROARCH)
+//   fps              one 1024-thread workgroup per cloud, coordinates + running distance
+//                    in registers, one barrier per selected point
+//   three_nn         one lane per unknown point, known points as scalar (SGPR) loads
+// Arithmetic uses the oracle's contraction convention (explicit fmaf, -ffp-contract=off).
+#include <cmath>
+
+#include "common.h"
+
+namespace gcn {
+
+__device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx, float by, float bz) {
+  const float dx = ax - bx, dy = ay - by, dz = az - bz;
+  float t = dx * dx;
+  t = fmaf(dy, dy, t);
+  t = fmaf(dz, dz, t);
+  return t;
+}
+
+// ---------------------------------------------------------------- ball query
+// ball_query_gpu.cu:9-44: first nsample indices (ascending) with d2 < r2, remaining slots
+// filled with the first hit, all-zero row if no hit.
+__global__ __launch_bounds__(256) void ball_query_kernel(int n, int m, float radius2, int nsample,
+                                                         const float *__restrict__ new_xyz,
+                                                         const float *__restrict__ xyz,
+                                                         int32_t *__restrict__ idx) {
+  const int lane = lane_id();
+  const int b = blockIdx.y;
+  const int j = blockIdx.x * 4 + wave_id();
+  if (j >= m) return;
+  xyz += (long)b * n * 3;
+  const float *q = new_xyz + ((long)b * m + j) * 3;
+  int32_t *out = idx + ((long)b * m + j) * nsample;
+  const float qx = q[0], qy = q[1], qz = q[2];
+  int cnt = 0, first = 0;
+  for (int base = 0; base < n && cnt < nsample; base += 64) {
+    const int k = base + lane;
+    bool hit = false;
+    if (k < n) {
+      const float d2 = sqdist3(qx, qy, qz, xyz[k * 3], xyz[k * 3 + 1], xyz[k * 3 + 2]);
+      hit = d2 < radius2;
+    }
+    const unsigned long long mask = __ballot(hit);
+    if (mask) {
+      if (cnt == 0) first = base + __ffsll((long long)mask) - 1;
+      const int slot = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+      if (hit && slot < nsample) out[slot] = k;
+      cnt += __popcll(mask);
+    }
+  }
+  if (cnt > nsample) cnt = nsample;
+  for (int l = cnt + lane; l < nsample; l += 64) out[l] = first;  // cnt == 0 -> zeros
+}
+
+// ---------------------------------------------------------------- group / gather
+// group_points_gpu.cu:8-28.  E = npoints*nsample elements per (b,c) plane; each thread
+// owns 4 consecutive elements and CT channels.
+template <int CT>
+__global__ __launch_bounds__(256) void group_points_kernel(int c, int n, long E,
+                                                           const float *__restrict__ points,
+                                                           const int32_t *__restrict__ idx,
+                                                           float *__restrict__ out) {
+  const int b = blockIdx.z;
+  const int c0 = blockIdx.y * CT;
+  const long e = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (e >= E) return;
+  const int32_t *ip = idx + (long)b * E + e;
+  int ii[4];
+  const bool full = (e + 3 < E) && ((E & 3) == 0);
+  if (full) {
+    const int4 v = *reinterpret_cast<const int4 *>(ip);
+    ii[0] = v.x; ii[1] = v.y; ii[2] = v.z; ii[3] = v.w;
+  } else {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) ii[t] = (e + t < E) ? ip[t] : 0;
+  }
+#pragma unroll
+  for (int cc = 0; cc < CT; ++cc) {
+    const int ch = c0 + cc;
+    if (ch >= c) break;
+    const float *row = points + ((long)b * c + ch) * n;
+    float4 v;
+    v.x = row[ii[0]]; v.y = row[ii[1]]; v.z = row[ii[2]]; v.w = row[ii[3]];
+    float *op = out + ((long)b * c + ch) * E + e;
+    if (full) {
+      *reinterpret_cast<float4 *>(op) = v;
+    } else {
+      const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (e + t < E) op[t] = vv[t];
+    }
+  }
+}
+
+// group_points_gpu.cu:43-64 (atomicAdd scatter).  One workgroup owns CT (b,c) rows of n
+// floats in LDS, streams the row's E gradients (coalesced) and adds them with LDS float
+// atomics, then writes the rows out.  Also serves gather_points_grad (E = m).
+template <int CT>
+__global__ __launch_bounds__(512) void scatter_rows_lds_kernel(int c, int n, long E,
+                                                               const float *__restrict__ grad_out,
+                                                               const int32_t *__restrict__ idx,
+                                                               float *__restrict__ grad_points) {
+  extern __shared__ float acc[];  // CT * n
+  const int b = blockIdx.y;
+  const int c0 = blockIdx.x * CT;
+  for (int i = threadIdx.x; i < CT * n; i += blockDim.x) acc[i] = 0.f;
+  __syncthreads();
+  const int32_t *ip = idx + (long)b * E;
+  for (long e = threadIdx.x; e < E; e += blockDim.x) {
+    const int ii = ip[e];
+#pragma unroll
+    for (int cc = 0; cc < CT; ++cc) {
+      const int ch = c0 + cc;
+      if (ch < c) atomicAdd(&acc[cc * n + ii], grad_out[((long)b * c + ch) * E + e]);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int cc = 0; cc < CT; ++cc) {
+    const int ch = c0 + cc;
+    if (ch >= c) break;
+    float *gp = grad_points + ((long)b * c + ch) * n;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) gp[i] = acc[cc * n + i];
+  }
+}
+
+// fallback for rows that do not fit LDS: global fp32 atomics (grad_points pre-zeroed)
+__global__ void scatter_rows_atomic_kernel(int c, int n, long E, const float *__restrict__ grad_out,
+                                           const int32_t *__restrict__ idx, float *__restrict__ grad_points) {
+  const int b = blockIdx.z, ch = blockIdx.y;
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  atomicAdd(grad_points + ((long)b * c + ch) * n + idx[(long)b * E + e], grad_out[((long)b * c + ch) * E + e]);
+}
+
+// ---------------------------------------------------------------- FPS
+// sampling_gpu.cu:69-173.  The reference's winner on exact ties depends on its launch
+// geometry: thread tid = k mod BS keeps the first maximum of its strided points, and the
+// LDS tree (`v2 > v1 ? i2 : i1`, strides BS/2..1) prefers the lower position at each
+// level, i.e. the smaller BIT-REVERSED tid.  Encoded here as a total order so that any
+// thread layout reproduces it: max over (d2, ~bitrev(k mod BS), ~k).
+__device__ __forceinline__ unsigned long long fps_key(float d2, int k, int bs_log2, int bs_mask) {
+  const unsigned int r = bs_log2 ? (__brev((unsigned int)(k & bs_mask)) >> (32 - bs_log2)) : 0u;
+  const unsigned int tie = (r << 22) | (unsigned int)k;  // k < 2^22, bs <= 512
+  return ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned long long)(~tie);
+}
+
+template <int PT>
+__global__ __launch_bounds__(1024) void fps_kernel(int n, int m, int bs_log2,
+                                                   const float *__restrict__ dataset,
+                                                   int32_t *__restrict__ idxs) {
+  __shared__ unsigned long long red[2][16];
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  dataset += (long)b * n * 3;
+  idxs += (long)b * m;
+  const int bs_mask = (1 << bs_log2) - 1;
+
+  float px[PT], py[PT], pz[PT], td[PT];
+  bool ok[PT];
+#pragma unroll
+  for (int i = 0; i < PT; ++i) {
+    const int k = tid + i * 1024;
+    ok[i] = false;
+    px[i] = py[i] = pz[i] = 0.f;
+    td[i] = 1e10f;  // sampling.cpp:74-76
+    if (k < n) {
+      px[i] = dataset[k * 3]; py[i] = dataset[k * 3 + 1]; pz[i] = dataset[k * 3 + 2];
+      float mag = px[i] * px[i];
+      mag = fmaf(py[i], py[i], mag);
+      mag = fmaf(pz[i], pz[i], mag);
+      ok[i] = !((double)mag <= 1e-3);  // sampling_gpu.cu:100-101
+    }
+  }
+  int old = 0;
+  if (tid == 0) idxs[0] = 0;
+  for (int j = 1; j < m; ++j) {
+    const float x1 = dataset[old * 3], y1 = dataset[old * 3 + 1], z1 = dataset[old * 3 + 2];
+    unsigned long long best = 0ull;
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+      if (ok[i]) {
+        const float d = sqdist3(px[i], py[i], pz[i], x1, y1, z1);
+        const float d2 = fminf(d, td[i]);
+        td[i] = d2;
+        const unsigned long long key = fps_key(d2, tid + i * 1024, bs_log2, bs_mask);
+        best = key > best ? key : best;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      const unsigned long long other = __shfl_xor(best, o);
+      best = other > best ? other : best;
+    }
+    if (lane == 0) red[j & 1][wave] = best;
+    __syncthreads();
+    unsigned long long g = red[j & 1][0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) {
+      const unsigned long long v = red[j & 1][w];
+      g = v > g ? v : g;
+    }
+    old = g == 0ull ? 0 : (int)((~(unsigned int)g) & 0x3fffffu);
+    if (tid == 0) idxs[j] = old;
+  }
+}
+
+// ---------------------------------------------------------------- three_nn / interpolate
+// interpolate_gpu.cu:9-59: strict-< cascade == stable top-3 by (d, k).
+__global__ __launch_bounds__(256) void three_nn_kernel(int n, int m, const float *__restrict__ unknown,
+                                                       const float *__restrict__ known,
+                                                       float *__restrict__ dist2, int32_t *__restrict__ idx) {
+  const int b = blockIdx.y;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  const float *u = unknown + ((long)b * n + j) * 3;
+  known += (long)b * m * 3;
+  const float ux = u[0], uy = u[1], uz = u[2];
+  float b1 = __builtin_inff(), b2 = __builtin_inff(), b3 = __builtin_inff();
+  int i1 = 0, i2 = 0, i3 = 0;
+  for (int k = 0; k < m; ++k) {
+    const float d = sqdist3(ux, uy, uz, known[k * 3], known[k * 3 + 1], known[k * 3 + 2]);
+    if (d < b1) {
+      b3 = b2; i3 = i2; b2 = b1; i2 = i1; b1 = d; i1 = k;
+    } else if (d < b2) {
+      b3 = b2; i3 = i2; b2 = d; i2 = k;
+    } else if (d < b3) {
+      b3 = d; i3 = k;
+    }
+  }
+  const long o = ((long)b * n + j) * 3;
+  dist2[o] = b1; dist2[o + 1] = b2; dist2[o + 2] = b3;
+  idx[o] = i1; idx[o + 1] = i2; idx[o + 2] = i3;
+}
+
+// interpolate_gpu.cu:72-101
+template <int CT>
+__global__ __launch_bounds__(256) void three_interpolate_kernel(int c, int m, int n,
+                                                                const float *__restrict__ points,
+                                                                const int32_t *__restrict__ idx,
+                                                                const float *__restrict__ weight,
+                                                                float *__restrict__ out) {
+  const int b = blockIdx.z;
+  const int c0 = blockIdx.y * CT;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  const long o = ((long)b * n + j) * 3;
+  const int i1 = idx[o], i2 = idx[o + 1], i3 = idx[o + 2];
+  const float w1 = weight[o], w2 = weight[o + 1], w3 = weight[o + 2];
+#pragma unroll
+  for (int cc = 0; cc < CT; ++cc) {
+    const int ch = c0 + cc;
+    if (ch >= c) break;
+    const float *row = points + ((long)b * c + ch) * m;
+    float t = row[i1] * w1;
+    t = fmaf(row[i2], w2, t);
+    t = fmaf(row[i3], w3, t);
+    out[((long)b * c + ch) * n + j] = t;
+  }
+}
+
+// interpolate_gpu.cu:116-143 (global atomics; grad_points pre-zeroed)
+__global__ void three_interpolate_grad_kernel(int c, int n, int m, const float *__restrict__ grad_out,
+                                              const int32_t *__restrict__ idx, const float *__restrict__ weight,
+                                              float *__restrict__ grad_points) {
+  const int b = blockIdx.z, ch = blockIdx.y;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const long o = ((long)b * n + j) * 3;
+  const float g = grad_out[((long)b * c + ch) * n + j];
+  float *gp = grad_points + ((long)b * c + ch) * m;
+  atomicAdd(gp + idx[o], g * weight[o]);
+  atomicAdd(gp + idx[o + 1], g * weight[o + 1]);
+  atomicAdd(gp + idx[o + 2], g * weight[o + 2]);
+}
+
+// gather: sampling_gpu.cu:8-20
+template <int CT>
+__global__ __launch_bounds__(256) void gather_points_kernel(int c, int n, int m, const float *__restrict__ points,
+                                                            const int32_t *__restrict__ idx, float *__restrict__ out) {
+  const int b = blockIdx.z;
+  const int c0 = blockIdx.y * CT;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= m) return;
+  const int a = idx[(long)b * m + j];
+#pragma unroll
+  for (int cc = 0; cc < CT; ++cc) {
+    const int ch = c0 + cc;
+    if (ch >= c) break;
+    out[((long)b * c + ch) * m + j] = points[((long)b * c + ch) * n + a];
+  }
+}
+
+static int scatter_rows(int b, int c, int n, long E, const float *grad_out, const int32_t *idx,
+                        float *grad_points, hipStream_t st, const char *what) {
+  if (b == 0 || c == 0 || n == 0) return GCN_OK;
+  const size_t row_bytes = (size_t)n * sizeof(float);
+  if (row_bytes <= 64 * 1024) {
+    if (row_bytes * 2 <= 64 * 1024) {
+      scatter_rows_lds_kernel<2><<<dim3(cdiv(c, 2), b), 512, row_bytes * 2, st>>>(c, n, E, grad_out, idx, grad_points);
+    } else {
+      scatter_rows_lds_kernel<1><<<dim3(c, b), 512, row_bytes, st>>>(c, n, E, grad_out, idx, grad_points);
+    }
+  } else {
+    GCN_HIP(hipMemsetAsync(grad_points, 0, (size_t)b * c * n * sizeof(float), st));
+    if (E > 0) scatter_rows_atomic_kernel<<<dim3(cdiv(E, 256), c, b), 256, 0, st>>>(c, n, E, grad_out, idx, grad_points);
+  }
+  return check_launch(what);
+}
+
+}  // namespace gcn
+
+using namespace gcn;
+
+GCN_EXPORT int gcn_ball_query(int b, int n, int m, float radius, int nsample, const float *new_xyz,
+                              const float *xyz, int32_t *idx, void *stream) {
+  GCN_REQUIRE(new_xyz && xyz && idx, "gcn_ball_query: null pointer");
+  GCN_REQUIRE(b >= 0 && n >= 0 && m >= 0 && nsample >= 0, "gcn_ball_query: bad shape");
+  if (b == 0 || m == 0 || nsample == 0) return GCN_OK;
+  ball_query_kernel<<<dim3(cdiv(m, 4), b), 256, 0, (hipStream_t)stream>>>(n, m, radius * radius, nsample, new_xyz, xyz, idx);
+  return check_launch("ball_query_kernel");
+}
+
+GCN_EXPORT int gcn_group_points(int b, int c, int n, int npoints, int nsample, const float *points,
+                                const int32_t *idx, float *out, void *stream) {
+  GCN_REQUIRE(points && idx && out, "gcn_group_points: null pointer");
+  GCN_REQUIRE(b >= 0 && c >= 0 && n >= 1 && npoints >= 0 && nsample >= 0, "gcn_group_points: bad shape");
+  const long E = (long)npoints * nsample;
+  if (b == 0 || c == 0 || E == 0) return GCN_OK;
+  constexpr int CT = 8;
+  group_points_kernel<CT><<<dim3(cdiv(E, 1024), cdiv(c, CT), b), 256, 0, (hipStream_t)stream>>>(c, n, E, points, idx, out);
+  return check_launch("group_points_kernel");
+}
+
+GCN_EXPORT int gcn_group_points_grad(int b, int c, int n, int npoints, int nsample, const float *grad_out,
+                                     const int32_t *idx, float *grad_points, void *stream) {
+  GCN_REQUIRE(grad_out && idx && grad_points, "gcn_group_points_grad: null pointer");
+  GCN_REQUIRE(b >= 0 && c >= 0 && n >= 1 && npoints >= 0 && nsample >= 0, "gcn_group_points_grad: bad shape");
+  return scatter_rows(b, c, n, (long)npoints * nsample, grad_out, idx, grad_points, (hipStream_t)stream, "group_points_grad");
+}
+
+GCN_EXPORT int gcn_gather_points(int b, int c, int n, int m, const float *points, const int32_t *idx,
+                                 float *out, void *stream) {
+  GCN_REQUIRE(points && idx && out, "gcn_gather_points: null pointer");
+  GCN_REQUIRE(b >= 0 && c >= 0 && n >= 1 && m >= 0, "gcn_gather_points: bad shape");
+  if (b == 0 || c == 0 || m == 0) return GCN_OK;
+  constexpr int CT = 8;
+  gather_points_kernel<CT><<<dim3(cdiv(m, 256), cdiv(c, CT), b), 256, 0, (hipStream_t)stream>>>(c, n, m, points, idx, out);
+  return check_launch("gather_points_kernel");
+}
+
+GCN_EXPORT int gcn_gather_points_grad(int b, int c, int n, int m, const float *grad_out, const int32_t *idx,
+                                      float *grad_points, void *stream) {
+  GCN_REQUIRE(grad_out && idx && grad_points, "gcn_gather_points_grad: null pointer");
+  GCN_REQUIRE(b >= 0 && c >= 0 && n >= 1 && m >= 0, "gcn_gather_points_grad: bad shape");
+  return scatter_rows(b, c, n, (long)m, grad_out, idx, grad_points, (hipStream_t)stream, "gather_points_grad");
+}
+
+GCN_EXPORT int gcn_furthest_point_sampling(int b, int n, int m, const float *dataset, float *temp,
+                                           int32_t *idxs, void *stream) {
+  GCN_REQUIRE(dataset && idxs, "gcn_furthest_point_sampling: null pointer");
+  GCN_REQUIRE(b >= 0 && n >= 1 && m >= 0, "gcn_furthest_point_sampling: bad shape");
+  GCN_REQUIRE(n <= 16384, "gcn_furthest_point_sampling: n=%d > 16384 unsupported", n);
+  (void)temp;  // running distances are register-resident; kept in the ABI for the reference's shape
+  if (b == 0 || m == 0) return GCN_OK;
+  // block_size the reference would launch with (cuda_utils.h:13-19), for its tie order
+  int bs_log2 = (int)(std::log((double)n) / std::log(2.0));
+  if (bs_log2 > 9) bs_log2 = 9;
+  if (bs_log2 < 0) bs_log2 = 0;
+  hipStream_t st = (hipStream_t)stream;
+  const int pt = cdiv(n, 1024);
+  if (pt <= 1) fps_kernel<1><<<b, 1024, 0, st>>>(n, m, bs_log2, dataset, idxs);
+  else if (pt <= 2) fps_kernel<2><<<b, 1024, 0, st>>>(n, m, bs_log2, dataset, idxs);
+  else if (pt <= 4) fps_kernel<4><<<b, 1024, 0, st>>>(n, m, bs_log2, dataset, idxs);
+  else if (pt <= 8) fps_kernel<8><<<b, 1024, 0, st>>>(n, m, bs_log2, dataset, idxs);
+  else fps_kernel<16><<<b, 1024, 0, st>>>(n, m, bs_log2, dataset, idxs);
+  return check_launch("fps_kernel");
+}
+
+GCN_EXPORT int gcn_three_nn(int b, int n, int m, const float *unknown, const float *known, float *dist2,
+                            int32_t *idx, void *stream) {
+  GCN_REQUIRE(unknown && known && dist2 && idx, "gcn_three_nn: null pointer");
+  GCN_REQUIRE(b >= 0 && n >= 0 && m >= 0, "gcn_three_nn: bad shape");
+  if (b == 0 || n == 0) return GCN_OK;
+  three_nn_kernel<<<dim3(cdiv(n, 256), b), 256, 0, (hipStream_t)stream>>>(n, m, unknown, known, dist2, idx);
+  return check_launch("three_nn_kernel");
+}
+
+GCN_EXPORT int gcn_three_interpolate(int b, int c, int m, int n, const float *points, const int32_t *idx,
+                                     const float *weight, float *out, void *stream) {
+  GCN_REQUIRE(points && idx && weight && out, "gcn_three_interpolate: null pointer");
+  GCN_REQUIRE(b >= 0 && c >= 0 && m >= 1 && n >= 0, "gcn_three_interpolate: bad shape");
+  if (b == 0 || c == 0 || n == 0) return GCN_OK;
+  constexpr int CT = 8;
+  three_interpolate_kernel<CT><<<dim3(cdiv(n, 256), cdiv(c, CT), b), 256, 0, (hipStream_t)stream>>>(c, m, n, points, idx, weight, out);
+  return check_launch("three_interpolate_kernel");
+}
+
+GCN_EXPORT int gcn_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out, const int32_t *idx,
+                                          const float *weight, float *grad_points, void *stream) {
+  GCN_REQUIRE(grad_out && idx && weight && grad_points, "gcn_three_interpolate_grad: null pointer");
+  GCN_REQUIRE(b >= 0 && c >= 0 && m >= 1 && n >= 0, "gcn_three_interpolate_grad: bad shape");
+  if (b == 0 || c == 0) return GCN_OK;
+  hipStream_t st = (hipStream_t)stream;
+  GCN_HIP(hipMemsetAsync(grad_points, 0, (size_t)b * c * m * sizeof(float), st));
+  if (n == 0) return GCN_OK;
+  three_interpolate_grad_kernel<<<dim3(cdiv(n, 256), c, b), 256, 0, st>>>(c, n, m, grad_out, idx, weight, grad_points);
+  return check_launch("three_interpolate_grad_kernel");
+}

@@ -1,0 +1,351 @@
+// softgroup.hip -- gfx950 kernels behind the softgroup.ops boundary
+// (reference: softgroup/ops/src/{voxelize,bfs_cluster,bfs_cluster_easy,sec_mean,roipool,
+// cal_iou_and_masklabel}/*.cu).  All of these are HBM-bound integer/byte work: the design
+// rules that matter are coalescing, enough waves in flight and no host round trips.
+//
+//   voxelize fp/bp     one wave per voxel row, lanes across planes (256-B coalesced rows),
+//                      rule-book entries are wave-uniform scalar loads
+//   ballquery_batch_p  count -> exclusive scan -> fill (deterministic CSR in point order;
+//                      no 3000-int per-thread scratch array as in bfs_cluster.cu:30)
+//   sec_* / avg pool   one wave per (segment, 64-plane chunk)
+//   mask IoU           one workgroup per proposal: LDS histogram of instance labels instead
+//                      of the reference's O(P*I*len) serial intersection loops
+#include "common.h"
+
+namespace gcn {
+
+__device__ __forceinline__ float sqdist3s(float ax, float ay, float az, float bx, float by, float bz) {
+  const float dx = ax - bx, dy = ay - by, dz = az - bz;
+  float t = dx * dx;
+  t = fmaf(dy, dy, t);
+  t = fmaf(dz, dz, t);
+  return t;
+}
+
+// ---------------------------------------------------------------- voxelize
+// voxelize.cu:9-25: sequential sum over the rule list (single thread per (row,plane) in the
+// reference, so its atomicAdd order is fixed) -> bit-exact restatement.
+__global__ __launch_bounds__(256) void voxelize_fp_kernel(int M, int maxActive, int C,
+                                                          const float *__restrict__ feats,
+                                                          float *__restrict__ out,
+                                                          const int32_t *__restrict__ rules, int average) {
+  const int lane = lane_id();
+  const int row = blockIdx.x * 4 + wave_id();
+  if (row >= M) return;
+  const int32_t *r = rules + (long)row * (maxActive + 1);
+  const int nActive = r[0];
+  const float mult = (average && nActive > 0) ? 1.f / (float)nActive : 1.f;
+  for (int p0 = 0; p0 < C; p0 += 64) {
+    const int p = p0 + lane;
+    float acc = 0.f;
+    if (p < C) {
+      for (int i = 1; i <= nActive; ++i) acc += mult * feats[(long)r[i] * C + p];
+      out[(long)row * C + p] = acc;
+    }
+  }
+}
+
+// voxelize.cu:38-54 (accumulates into d_feats like the reference; 256-B contiguous atomics)
+__global__ __launch_bounds__(256) void voxelize_bp_kernel(int M, int maxActive, int C,
+                                                          const float *__restrict__ d_out,
+                                                          float *__restrict__ d_feats,
+                                                          const int32_t *__restrict__ rules, int average) {
+  const int lane = lane_id();
+  const int row = blockIdx.x * 4 + wave_id();
+  if (row >= M) return;
+  const int32_t *r = rules + (long)row * (maxActive + 1);
+  const int nActive = r[0];
+  const float mult = (average && nActive > 0) ? 1.f / (float)nActive : 1.f;
+  for (int p0 = 0; p0 < C; p0 += 64) {
+    const int p = p0 + lane;
+    if (p < C) {
+      const float g = mult * d_out[(long)row * C + p];
+      for (int i = 1; i <= nActive; ++i) atomicAdd(&d_feats[(long)r[i] * C + p], g);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- ball query (batched, CSR)
+// bfs_cluster.cu:18-77 / bfs_cluster_easy.cu:15-66.  FILL == false: count pass;
+// FILL == true: write neighbour ids at start_len[p][0] (truncated at thre).
+template <bool FILL>
+__global__ __launch_bounds__(256) void ballquery_kernel(int n, long thre, float radius2, int cap,
+                                                        const float *__restrict__ xyz,
+                                                        const int32_t *__restrict__ batch_idxs,
+                                                        const int32_t *__restrict__ batch_offsets,
+                                                        const float *__restrict__ adj_inst, float thr_inst,
+                                                        const float *__restrict__ adj_para, float thr_para,
+                                                        int32_t *__restrict__ idx, int32_t *__restrict__ start_len,
+                                                        int32_t *__restrict__ counts) {
+  const int lane = lane_id();
+  const int p = blockIdx.x * 4 + wave_id();
+  if (p >= n) return;
+  const float ox = xyz[p * 3], oy = xyz[p * 3 + 1], oz = xyz[p * 3 + 2];
+  const int bi = batch_idxs[p];
+  const int start = batch_offsets[bi], end = batch_offsets[bi + 1];
+  long s0 = 0;
+  int limit = cap;  // entries this point may write
+  if (FILL) {
+    s0 = start_len[p * 2];
+    if (s0 >= thre) return;
+    const int cnt = start_len[p * 2 + 1];
+    limit = (s0 + cnt >= thre) ? (int)(thre - s0) : cnt;
+  }
+  int cnt = 0;
+  for (int base = start; base < end && cnt < limit; base += 64) {
+    const int k = base + lane;
+    bool hit = false;
+    if (k < end) {
+      const float d2 = sqdist3s(ox, oy, oz, xyz[k * 3], xyz[k * 3 + 1], xyz[k * 3 + 2]);
+      hit = d2 < radius2;
+      if (hit && adj_inst) hit = (adj_inst[(long)p * n + k] > thr_inst) && (adj_para[(long)p * n + k] > thr_para);
+    }
+    const unsigned long long mask = __ballot(hit);
+    if (FILL) {
+      const int slot = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+      if (hit && slot < limit) idx[s0 + slot] = k;
+    }
+    cnt += __popcll(mask);
+  }
+  if (!FILL) counts[p] = cnt < cap ? cnt : cap;
+}
+
+// single-workgroup exclusive scan of counts[0..n) -> start_len[:,0], start_len[:,1]=count,
+// counts[n] = total
+__global__ __launch_bounds__(1024) void scan_counts_kernel(int n, int32_t *__restrict__ counts,
+                                                           int32_t *__restrict__ start_len) {
+  __shared__ int part[1024];
+  const int tid = threadIdx.x;
+  const int chunk = (n + 1023) / 1024;
+  const int lo = tid * chunk, hi = min(lo + chunk, n);
+  int s = 0;
+  for (int i = lo; i < hi; ++i) s += counts[i];
+  part[tid] = s;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    int v = tid >= off ? part[tid - off] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int run = part[tid] - s;
+  for (int i = lo; i < hi; ++i) {
+    const int c = counts[i];
+    start_len[i * 2] = run;
+    start_len[i * 2 + 1] = c;
+    run += c;
+  }
+  if (tid == 1023) counts[n] = part[1023];
+}
+
+// ---------------------------------------------------------------- segment ops
+// sec_mean.cu:13-85, roipool.cu:12-32.  OP 0 sec_mean (sum of v/count), 1 min, 2 max,
+// 3 global_avg_pool (sum then divide).  Row order is kept sequential per plane -> bit-exact.
+template <int OP>
+__global__ __launch_bounds__(256) void segment_kernel(int P, int C, const float *__restrict__ inp,
+                                                      const int32_t *__restrict__ offsets,
+                                                      float *__restrict__ out) {
+  const int lane = lane_id();
+  const int chunks = (C + 63) / 64;
+  const int w = blockIdx.x * 4 + wave_id();
+  if (w >= P * chunks) return;
+  const int pid = w / chunks, p = (w % chunks) * 64 + lane;
+  const int start = offsets[pid], end = offsets[pid + 1];
+  if (p >= C) return;
+  const float count = (float)(end - start);
+  float acc = OP == 1 ? __builtin_inff() : (OP == 2 ? -__builtin_inff() : 0.f);
+  for (int i = start; i < end; ++i) {
+    const float v = inp[(long)i * C + p];
+    if (OP == 0) acc += v / count;
+    else if (OP == 1) acc = v < acc ? v : acc;
+    else if (OP == 2) acc = v > acc ? v : acc;
+    else acc += v;
+  }
+  if (OP == 3) acc = acc / count;
+  out[(long)pid * C + p] = acc;
+}
+
+// roipool.cu:46-60: every row of a segment receives d_out / n_points (plain stores: a row
+// belongs to one segment)
+__global__ __launch_bounds__(256) void avg_pool_bp_kernel(int P, int C, float *__restrict__ d_feats,
+                                                          const int32_t *__restrict__ offsets,
+                                                          const float *__restrict__ d_out) {
+  const int pid = blockIdx.y;
+  const int start = offsets[pid], end = offsets[pid + 1];
+  const float n_points = (float)(end - start);
+  const long total = (long)(end - start) * C;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int p = (int)(e % C);
+    d_feats[(long)start * C + e] = d_out[(long)pid * C + p] / n_points;
+  }
+}
+
+// ---------------------------------------------------------------- IoU / mask labels
+// cal_iou_and_masklabel.cu:9-68: intersection counts via an LDS histogram of the labels of
+// the proposal's points (integer counts -> exact).
+__global__ __launch_bounds__(256) void mask_iou_kernel(int nInstance, const int32_t *__restrict__ proposals_idx,
+                                                       const int32_t *__restrict__ proposals_offset,
+                                                       const int64_t *__restrict__ instance_labels,
+                                                       const int32_t *__restrict__ instance_pointnum,
+                                                       const float *__restrict__ mask, float *__restrict__ iou) {
+  extern __shared__ int hist[];  // nInstance + 1
+  const int pid = blockIdx.x;
+  const int start = proposals_offset[pid], end = proposals_offset[pid + 1];
+  for (int i = threadIdx.x; i <= nInstance; i += 256) hist[i] = 0;
+  __syncthreads();
+  for (int i = start + threadIdx.x; i < end; i += 256) {
+    if (mask && !(mask[i] > 0.5f)) continue;
+    atomicAdd(&hist[nInstance], 1);  // proposal_total
+    const int lab = (int)instance_labels[proposals_idx[i]];
+    if (lab >= 0 && lab < nInstance) atomicAdd(&hist[lab], 1);
+  }
+  __syncthreads();
+  const int proposal_total = hist[nInstance];
+  for (int inst = threadIdx.x; inst < nInstance; inst += 256) {
+    const int inter = hist[inst];
+    const double den = (double)(float)(proposal_total + instance_pointnum[inst] - inter) + 1e-5;
+    iou[(long)pid * nInstance + inst] = (float)((double)(float)inter / den);
+  }
+}
+
+// cal_iou_and_masklabel.cu:70-104
+__global__ __launch_bounds__(256) void mask_label_kernel(int nInstance, float iou_thr,
+                                                         const int32_t *__restrict__ proposals_idx,
+                                                         const int32_t *__restrict__ proposals_offset,
+                                                         const int64_t *__restrict__ instance_labels,
+                                                         const int64_t *__restrict__ instance_cls,
+                                                         const float *__restrict__ proposals_iou,
+                                                         float *__restrict__ mask_label) {
+  __shared__ float s_iou[256];
+  __shared__ int s_ind[256];
+  const int pid = blockIdx.x, tid = threadIdx.x;
+  // first maximum with strict '>' starting from 0 == max value, lowest index among equals
+  float best = 0.f;
+  int bind = 0x7fffffff;
+  for (int inst = tid; inst < nInstance; inst += 256) {
+    const float v = proposals_iou[(long)pid * nInstance + inst];
+    if (v > best && instance_cls[inst] != -100) { best = v; bind = inst; }
+  }
+  s_iou[tid] = best; s_ind[tid] = bind;
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if (tid < off) {
+      const float v = s_iou[tid + off];
+      const int i2 = s_ind[tid + off];
+      if (v > s_iou[tid] || (v == s_iou[tid] && i2 < s_ind[tid])) { s_iou[tid] = v; s_ind[tid] = i2; }
+    }
+    __syncthreads();
+  }
+  const float max_iou = s_iou[0];
+  const int max_ind = s_ind[0] == 0x7fffffff ? 0 : s_ind[0];
+  if (!(max_iou >= iou_thr)) return;
+  const int start = proposals_offset[pid], end = proposals_offset[pid + 1];
+  for (int i = start + tid; i < end; i += 256)
+    mask_label[i] = ((int)instance_labels[proposals_idx[i]] == max_ind) ? 1.f : 0.f;
+}
+
+}  // namespace gcn
+
+using namespace gcn;
+
+GCN_EXPORT int gcn_voxelize_fp(int M, int maxActive, int C, const float *feats, float *output_feats,
+                               const int32_t *rules, int average, void *stream) {
+  GCN_REQUIRE(M >= 0 && maxActive >= 0 && C >= 0, "gcn_voxelize_fp: bad shape");
+  if (M == 0 || C == 0) return GCN_OK;
+  GCN_REQUIRE(feats && output_feats && rules, "gcn_voxelize_fp: null pointer");
+  voxelize_fp_kernel<<<cdiv(M, 4), 256, 0, (hipStream_t)stream>>>(M, maxActive, C, feats, output_feats, rules, average);
+  return check_launch("voxelize_fp_kernel");
+}
+
+GCN_EXPORT int gcn_voxelize_bp(int M, int maxActive, int C, const float *d_output_feats, float *d_feats,
+                               const int32_t *rules, int average, void *stream) {
+  GCN_REQUIRE(M >= 0 && maxActive >= 0 && C >= 0, "gcn_voxelize_bp: bad shape");
+  if (M == 0 || C == 0) return GCN_OK;
+  GCN_REQUIRE(d_output_feats && d_feats && rules, "gcn_voxelize_bp: null pointer");
+  voxelize_bp_kernel<<<cdiv(M, 4), 256, 0, (hipStream_t)stream>>>(M, maxActive, C, d_output_feats, d_feats, rules, average);
+  return check_launch("voxelize_bp_kernel");
+}
+
+GCN_EXPORT int gcn_ballquery_batch_p(int n, int meanActive, float radius, const float *xyz,
+                                     const int32_t *batch_idxs, const int32_t *batch_offsets,
+                                     const float *adj_inst, float thr_inst, const float *adj_para,
+                                     float thr_para, int32_t *idx, int32_t *start_len, int32_t *count_ws,
+                                     int *total_host, void *stream) {
+  GCN_REQUIRE(n >= 0 && meanActive >= 0, "gcn_ballquery_batch_p: bad shape");
+  GCN_REQUIRE(total_host, "gcn_ballquery_batch_p: total_host is null");
+  GCN_REQUIRE((adj_inst == nullptr) == (adj_para == nullptr), "gcn_ballquery_batch_p: adj_inst and adj_para must both be given or both be NULL");
+  *total_host = 0;
+  if (n == 0) return GCN_OK;
+  GCN_REQUIRE(xyz && batch_idxs && batch_offsets && start_len && count_ws, "gcn_ballquery_batch_p: null pointer");
+  GCN_REQUIRE(idx || meanActive == 0, "gcn_ballquery_batch_p: idx is null");
+  hipStream_t st = (hipStream_t)stream;
+  const int cap = adj_inst ? 3000 : 1000;  // bfs_cluster.cu:54 / bfs_cluster_easy.cu:43
+  const float r2 = radius * radius;
+  const long thre = (long)n * meanActive;
+  ballquery_kernel<false><<<cdiv(n, 4), 256, 0, st>>>(n, thre, r2, cap, xyz, batch_idxs, batch_offsets, adj_inst, thr_inst,
+                                                       adj_para, thr_para, idx, start_len, count_ws);
+  scan_counts_kernel<<<1, 1024, 0, st>>>(n, count_ws, start_len);
+  if (thre > 0)
+    ballquery_kernel<true><<<cdiv(n, 4), 256, 0, st>>>(n, thre, r2, cap, xyz, batch_idxs, batch_offsets, adj_inst, thr_inst,
+                                                        adj_para, thr_para, idx, start_len, count_ws);
+  int rc = check_launch("ballquery_kernel");
+  if (rc) return rc;
+  GCN_HIP(hipMemcpyAsync(total_host, count_ws + n, sizeof(int), hipMemcpyDeviceToHost, st));
+  GCN_HIP(hipStreamSynchronize(st));
+  return GCN_OK;
+}
+
+GCN_EXPORT int gcn_sec_op(int op, int P, int C, const float *inp, const int32_t *offsets, float *out, void *stream) {
+  GCN_REQUIRE(op >= 0 && op <= 2, "gcn_sec_op: op must be 0 (mean), 1 (min) or 2 (max)");
+  GCN_REQUIRE(P >= 0 && C >= 0, "gcn_sec_op: bad shape");
+  if (P == 0 || C == 0) return GCN_OK;
+  GCN_REQUIRE(inp && offsets && out, "gcn_sec_op: null pointer");
+  const int waves = P * ((C + 63) / 64);
+  hipStream_t st = (hipStream_t)stream;
+  if (op == 0) segment_kernel<0><<<cdiv(waves, 4), 256, 0, st>>>(P, C, inp, offsets, out);
+  else if (op == 1) segment_kernel<1><<<cdiv(waves, 4), 256, 0, st>>>(P, C, inp, offsets, out);
+  else segment_kernel<2><<<cdiv(waves, 4), 256, 0, st>>>(P, C, inp, offsets, out);
+  return check_launch("segment_kernel");
+}
+
+GCN_EXPORT int gcn_global_avg_pool_fp(int P, int C, const float *feats, const int32_t *offsets, float *out, void *stream) {
+  GCN_REQUIRE(P >= 0 && C >= 0, "gcn_global_avg_pool_fp: bad shape");
+  if (P == 0 || C == 0) return GCN_OK;
+  GCN_REQUIRE(feats && offsets && out, "gcn_global_avg_pool_fp: null pointer");
+  const int waves = P * ((C + 63) / 64);
+  segment_kernel<3><<<cdiv(waves, 4), 256, 0, (hipStream_t)stream>>>(P, C, feats, offsets, out);
+  return check_launch("segment_kernel<avg>");
+}
+
+GCN_EXPORT int gcn_global_avg_pool_bp(int P, int C, float *d_feats, const int32_t *offsets, const float *d_out, void *stream) {
+  GCN_REQUIRE(P >= 0 && C >= 0, "gcn_global_avg_pool_bp: bad shape");
+  if (P == 0 || C == 0) return GCN_OK;
+  GCN_REQUIRE(d_feats && offsets && d_out, "gcn_global_avg_pool_bp: null pointer");
+  avg_pool_bp_kernel<<<dim3(64, P), 256, 0, (hipStream_t)stream>>>(P, C, d_feats, offsets, d_out);
+  return check_launch("avg_pool_bp_kernel");
+}
+
+GCN_EXPORT int gcn_get_mask_iou(int nInstance, int nProposal, const int32_t *proposals_idx,
+                                const int32_t *proposals_offset, const int64_t *instance_labels,
+                                const int32_t *instance_pointnum, const float *mask_scores_sigmoid,
+                                float *proposals_iou, void *stream) {
+  GCN_REQUIRE(nInstance >= 0 && nProposal >= 0, "gcn_get_mask_iou: bad shape");
+  GCN_REQUIRE(nInstance <= 16000, "gcn_get_mask_iou: nInstance=%d > 16000 unsupported", nInstance);
+  if (nInstance == 0 || nProposal == 0) return GCN_OK;
+  GCN_REQUIRE(proposals_idx && proposals_offset && instance_labels && instance_pointnum && proposals_iou, "gcn_get_mask_iou: null pointer");
+  mask_iou_kernel<<<nProposal, 256, (nInstance + 1) * sizeof(int), (hipStream_t)stream>>>(
+      nInstance, proposals_idx, proposals_offset, instance_labels, instance_pointnum, mask_scores_sigmoid, proposals_iou);
+  return check_launch("mask_iou_kernel");
+}
+
+GCN_EXPORT int gcn_get_mask_label(int nInstance, int nProposal, float iou_thr, const int32_t *proposals_idx,
+                                  const int32_t *proposals_offset, const int64_t *instance_labels,
+                                  const int64_t *instance_cls, const float *proposals_iou, float *mask_label,
+                                  void *stream) {
+  GCN_REQUIRE(nInstance >= 0 && nProposal >= 0, "gcn_get_mask_label: bad shape");
+  if (nProposal == 0) return GCN_OK;
+  GCN_REQUIRE(proposals_idx && proposals_offset && instance_labels && instance_cls && proposals_iou && mask_label, "gcn_get_mask_label: null pointer");
+  mask_label_kernel<<<nProposal, 256, 0, (hipStream_t)stream>>>(nInstance, iou_thr, proposals_idx, proposals_offset,
+                                                                instance_labels, instance_cls, proposals_iou, mask_label);
+  return check_launch("mask_label_kernel");
+}

@@ -1,0 +1,194 @@
+/*
+ * gcanet_hip.h -- C ABI of libgcanet_hip.so: hand-written HIP (gfx950) kernels for
+ * GCANet's per-point feature-aggregation hot path.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no torch / C++ types cross the boundary.
+ *   - every pointer is a DEVICE pointer unless the parameter name ends in _host.
+ *   - the caller owns all buffers (the reference's callee-allocates convention,
+ *     e.g. group_points.cpp:22-24 / knn.cpp:36-37, is reproduced by the Python shims).
+ *   - `stream` is a hipStream_t (pass torch.cuda.current_stream().cuda_stream); all
+ *     work is enqueued on it and nothing synchronises unless stated.
+ *   - return value: GCN_OK (0) or an error code; gcn_last_error() gives a
+ *     thread-local message.  Never exit()s (the reference does: cuda_utils.h:30-39).
+ *   - re-entrant, no global mutable state.
+ *
+ * Each entry point cites the reference interface it replaces (paths relative to the
+ * reference repo root; P2 = models/Pointnet2_PyTorch-master/pointnet2_ops_lib/pointnet2_ops,
+ * KNN = models/KNN_CUDA/knn_cuda, SG = softgroup/ops, M4 = models/dgcnn-hais-concat-direct-4.py).
+ */
+#ifndef GCANET_HIP_H
+#define GCANET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GCN_OK 0
+#define GCN_EINVAL 1   /* bad argument (shape / null pointer / unsupported size) */
+#define GCN_ELAUNCH 2  /* HIP launch or runtime error */
+
+const char *gcn_last_error(void);
+int gcn_version(void);
+
+/* ------------------------------------------------------------------ kNN ------- */
+
+/* Replaces KNN/csrc/cuda/knn.cpp:23-56 `knn(ref, query, k)` + kernels knn.cu:29-183
+ * (distance matrix, insertion sort, sqrt) + the `i -= 1` of KNN/__init__.py:41-44,
+ * batched (KNN.forward loops over the batch in Python, KNN/__init__.py:61-74).
+ * One fused kernel; the (nr,nq) distance matrix is never materialised.
+ *   ref   (B, dim, nr) if point_major == 0 else (B, nr, dim)   f32
+ *   query (B, dim, nq) if point_major == 0 else (B, nq, dim)   f32
+ *   dist  (B, k, nq) if point_major == 0 else (B, nq, k)       f32, L2 distance (sqrt applied)
+ *   ind   same shape as dist, int64, 0-based; ties -> lowest ref index (knn.cu:125-131)
+ * 1 <= k <= min(nr, 512). */
+int gcn_knn_cuda(const float *ref, const float *query, int B, int dim, int nr, int nq, int k,
+                 int point_major, float *dist, int64_t *ind, void *stream);
+
+/* Replaces the pure-torch `knn(x,k1,k2)` (M4:30-47, metric 0) and
+ * `knn_points_normals(x,k1,k2)` (M4:50-90, metric 1): per-cloud N x N negative squared
+ * distance + topk(k2) + dilated pick `[:, :, arange(0,k2,k2//k1)]`.
+ *   x    (B, C, N) f32 channel-major (metric 1 needs C >= 6: xyz + normal)
+ *   idx  (B, N, kout) int64, kout = ceil(k2 / (k2/k1)); order: value desc, index asc
+ *   val  optional (B, N, kout) f32: the selected pairwise_distance values (may be NULL)
+ *   xx_ws workspace (B, N) f32 (squared norms; written by the call)
+ * 1 <= k1 <= k2 <= min(N, 512). */
+int gcn_knn_model(const float *x, int B, int C, int N, int k1, int k2, int metric,
+                  int64_t *idx, float *val, float *xx_ws, void *stream);
+
+/* ------------------------------------------------------------ pointnet2_ops ---- */
+
+/* P2/_ext-src/src/ball_query.cpp:10-33 `ball_query(new_xyz, xyz, radius, nsample)`.
+ * new_xyz (b,m,3), xyz (b,n,3) -> idx (b,m,nsample) int32 (fully written: rows with no
+ * hit are zero, ball_query.cpp:19-21). */
+int gcn_ball_query(int b, int n, int m, float radius, int nsample, const float *new_xyz,
+                   const float *xyz, int32_t *idx, void *stream);
+
+/* P2/_ext-src/src/group_points.cpp:14-37 `group_points(points, idx)`:
+ * points (b,c,n), idx (b,npoints,nsample) i32 -> out (b,c,npoints,nsample). */
+int gcn_group_points(int b, int c, int n, int npoints, int nsample, const float *points,
+                     const int32_t *idx, float *out, void *stream);
+
+/* P2/_ext-src/src/group_points.cpp:39-63 `group_points_grad(grad_out, idx, n)`:
+ * grad_points (b,c,n) is fully written by the call (zero-init included). */
+int gcn_group_points_grad(int b, int c, int n, int npoints, int nsample, const float *grad_out,
+                          const int32_t *idx, float *grad_points, void *stream);
+
+/* P2/_ext-src/src/sampling.cpp:18-40 `gather_points(points, idx)`: (b,c,n),(b,m) -> (b,c,m). */
+int gcn_gather_points(int b, int c, int n, int m, const float *points, const int32_t *idx,
+                      float *out, void *stream);
+
+/* P2/_ext-src/src/sampling.cpp:42-66 `gather_points_grad(grad_out, idx, n)`. */
+int gcn_gather_points_grad(int b, int c, int n, int m, const float *grad_out, const int32_t *idx,
+                           float *grad_points, void *stream);
+
+/* P2/_ext-src/src/sampling.cpp:68-88 `furthest_point_sampling(points, nsamples)`:
+ * dataset (b,n,3) -> idxs (b,m) i32; temp (b,n) f32 workspace (initialised by the call). */
+int gcn_furthest_point_sampling(int b, int n, int m, const float *dataset, float *temp,
+                                int32_t *idxs, void *stream);
+
+/* P2/_ext-src/src/interpolate.cpp:22-44 `three_nn(unknowns, knows)`:
+ * unknown (b,n,3), known (b,m,3) -> dist2 (b,n,3) f32 (SQUARED; the Python wrapper takes
+ * sqrt, pointnet2_utils.py:124-125), idx (b,n,3) i32. */
+int gcn_three_nn(int b, int n, int m, const float *unknown, const float *known, float *dist2,
+                 int32_t *idx, void *stream);
+
+/* P2/_ext-src/src/interpolate.cpp:46-72 `three_interpolate(points, idx, weight)`:
+ * points (b,c,m), idx/weight (b,n,3) -> out (b,c,n). */
+int gcn_three_interpolate(int b, int c, int m, int n, const float *points, const int32_t *idx,
+                          const float *weight, float *out, void *stream);
+
+/* P2/_ext-src/src/interpolate.cpp:74-101 `three_interpolate_grad(grad_out, idx, weight, m)`:
+ * grad_points (b,c,m) fully written. */
+int gcn_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out,
+                               const int32_t *idx, const float *weight, float *grad_points,
+                               void *stream);
+
+/* ------------------------------------------------------------- softgroup.ops --- */
+
+/* SG/src/voxelize/voxelize.cpp:168-183 `voxelize_fp` (kernel voxelize.cu:9-25):
+ * feats (N,C), rules (M, maxActive+1) i32 [count, idx...] -> output_feats (M,C) fully written. */
+int gcn_voxelize_fp(int M, int maxActive, int C, const float *feats, float *output_feats,
+                    const int32_t *rules, int average, void *stream);
+
+/* SG/src/voxelize/voxelize.cpp:185-198 `voxelize_bp` (kernel voxelize.cu:38-54):
+ * d_feats (N,C) must be zero-initialised by the caller (functions.py:340). */
+int gcn_voxelize_bp(int M, int maxActive, int C, const float *d_output_feats, float *d_feats,
+                    const int32_t *rules, int average, void *stream);
+
+/* SG/src/bfs_cluster/bfs_cluster.cpp:20-46 `ballquery_batch_p` (kernel bfs_cluster.cu:18-77)
+ * and SG/src/bfs_cluster_easy (adj_* == NULL; per-point cap 1000 instead of 3000).
+ * Two-pass count -> scan -> fill: CSR segments are in POINT ORDER (the reference's
+ * atomicAdd slot allocation makes its segment order non-deterministic).
+ *   xyz (n,3), batch_idxs (n) i32, batch_offsets (B+1) i32, adj_* (n,n) f32 or NULL
+ *   idx (n*meanActive) i32 (entries past the truncation point untouched),
+ *   start_len (n,2) i32, count_ws (n+1) i32 workspace, total_host: pinned or pageable
+ *   HOST int receiving the untruncated total (the call synchronises the stream for it,
+ *   as the reference's blocking cudaMemcpy does, bfs_cluster.cu:118). */
+int gcn_ballquery_batch_p(int n, int meanActive, float radius, const float *xyz,
+                          const int32_t *batch_idxs, const int32_t *batch_offsets,
+                          const float *adj_inst, float thr_inst, const float *adj_para,
+                          float thr_para, int32_t *idx, int32_t *start_len, int32_t *count_ws,
+                          int *total_host, void *stream);
+
+/* SG/src/sec_mean/sec_mean.cpp `sec_mean/sec_min/sec_max` (kernels sec_mean.cu:13-85).
+ * op 0 mean, 1 min, 2 max.  inp (N,C), offsets (P+1) i32 -> out (P,C). */
+int gcn_sec_op(int op, int P, int C, const float *inp, const int32_t *offsets, float *out,
+               void *stream);
+
+/* SG/src/roipool/roipool.cpp `global_avg_pool_fp` (roipool.cu:12-32). */
+int gcn_global_avg_pool_fp(int P, int C, const float *feats, const int32_t *offsets, float *out,
+                           void *stream);
+
+/* SG/src/roipool/roipool.cpp `global_avg_pool_bp` (roipool.cu:46-60); d_feats (S,C) rows
+ * inside [offsets[0], offsets[P]) are fully written (no zero-init needed there). */
+int gcn_global_avg_pool_bp(int P, int C, float *d_feats, const int32_t *offsets,
+                           const float *d_out, void *stream);
+
+/* SG/src/cal_iou_and_masklabel `get_mask_iou_on_cluster` (mask == NULL, .cu:9-34) and
+ * `get_mask_iou_on_pred` (.cu:36-68).  proposals_iou (P, I) f32. */
+int gcn_get_mask_iou(int nInstance, int nProposal, const int32_t *proposals_idx,
+                     const int32_t *proposals_offset, const int64_t *instance_labels,
+                     const int32_t *instance_pointnum, const float *mask_scores_sigmoid,
+                     float *proposals_iou, void *stream);
+
+/* SG/src/cal_iou_and_masklabel `get_mask_label` (.cu:70-104); mask_label (S) pre-filled
+ * with -1 by the caller (functions.py:252). */
+int gcn_get_mask_label(int nInstance, int nProposal, float iou_thr, const int32_t *proposals_idx,
+                       const int32_t *proposals_offset, const int64_t *instance_labels,
+                       const int64_t *instance_cls, const float *proposals_iou, float *mask_label,
+                       void *stream);
+
+/* ---- host-side SoftGroup routines (the reference runs these on CPU tensors) ---- */
+
+/* SG/src/voxelize/voxelize.cpp:11-39 `voxelize_idx` (host C++ hash dedup).  HOST pointers.
+ * Two-call protocol: call with output_coords_host == NULL to obtain *M and *maxActive
+ * (input_map_host is filled), then again with buffers of (M,ncol) / (M,maxActive+1). */
+int gcn_voxelize_idx_host(const int64_t *coords_host, int N, int ncol, int mode,
+                          int32_t *input_map_host, int *M, int *maxActive,
+                          int64_t *output_coords_host, int32_t *output_map_host);
+
+/* SG/src/bfs_cluster/bfs_cluster.cpp:122-143 `bfs_cluster` (host BFS).  HOST pointers.
+ * Two-call: cluster_idxs_host == NULL -> sizes only. */
+int gcn_bfs_cluster_host(const float *class_numpoint_mean_host, const int32_t *ball_query_idxs_host,
+                         const int32_t *start_len_host, int N, float threshold, int class_id,
+                         int *sumNPoint, int *nCluster, int32_t *cluster_idxs_host,
+                         int32_t *cluster_offsets_host);
+
+/* SG/src/hierarchical_aggregation/hierarchical_aggregation.cpp:102-183 (host BFS + split;
+ * using_set_aggr additionally runs the fragment->primary absorption of
+ * hierarchical_aggregation.cu:22-196 on the host).  HOST pointers; buffers sized for the
+ * worst case: idxs (2N,2) i32, offsets (N+1) i32.  Outputs are the MERGED result of
+ * HierarchicalAggregation.forward (functions.py:52-72): *sumNPoint rows, *nCluster clusters. */
+int gcn_hierarchical_aggregation_host(const int32_t *semantic_label_host, const float *coord_shift_host,
+                                      const int32_t *batch_idxs_host, const int32_t *ball_query_idxs_host,
+                                      const int32_t *start_len_host, int N, int using_set_aggr,
+                                      int32_t *cluster_idxs_host, int32_t *cluster_offsets_host,
+                                      int *sumNPoint, int *nCluster);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GCANET_HIP_H */

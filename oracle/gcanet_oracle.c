@@ -1,0 +1,784 @@
+/*
+ * gcanet_oracle.c -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * Plain-C restatement of the native ops on GCANet's per-point feature-aggregation
+ * hot path.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+ * may load this library; the product path (gcanet_amd/) never does.
+ *
+ * Every function cites the reference file:line it follows (paths relative to
+ * /root/reference).  The reference kernels are CUDA; nvcc contracts a*b+c into
+ * FMA by default, so wherever the reference writes `s += t*t` or `a*a + b*b + c*c`
+ * this file uses an explicit left-to-right fmaf chain and is compiled with
+ * -ffp-contract=off.  No reference-held vector pins that choice at the ulp level
+ * (the reference's native extensions cannot be built here: CUDA only) -- see
+ * DESIGN.md "contraction convention".
+ *
+ * Pinning: the kNN + group path is pinned by the known-answer table of
+ * models/search_knn.py:183-243 (tests/golden/search_knn_known_answer.json); the
+ * in-model kNN/graph-feature/EdgeConv functions by fixtures generated from the
+ * importable reference module models/sppnet.py (tests/golden/make_golden.py).
+ * SoftGroup ops: the reference holds no tests or vectors -> "parity unpinned".
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------- */
+/* KNN_CUDA: models/KNN_CUDA/knn_cuda/csrc/cuda/knn.cu                          */
+/* ------------------------------------------------------------------------- */
+
+/* knn.cu:29-93 cuComputeDistanceGlobal: AB[r][q] = sum_d (A[d][r]-B[d][q])^2,
+ * accumulated in d order (zero padding of the 16-wide tiles adds exact zeros). */
+static float knn_cuda_ssd(const float *ref, int nr, const float *query, int nq,
+                          int dim, int r, int q) {
+  float ssd = 0.f;
+  for (int d = 0; d < dim; ++d) {
+    float tmp = ref[(size_t)d * nr + r] - query[(size_t)d * nq + q];
+    ssd = fmaf(tmp, tmp, ssd);
+  }
+  return ssd;
+}
+
+/* knn.cu:105-167 cuInsertionSort (literal, per query column) + knn.cu:178-183
+ * cuParallelSqrt + KNN/__init__.py:41-44 (i -= 1).
+ * ref (dim,nr), query (dim,nq) row-major; dist (k,nq) L2 (sqrt applied);
+ * ind (k,nq) int64 0-based.  Requires 1 <= k <= nr. */
+ORC_API void orc_knn_cuda(const float *ref, int nr, const float *query, int nq,
+                          int dim, int k, float *dist, int64_t *ind) {
+  float *col = (float *)malloc(sizeof(float) * (size_t)nr);
+  int64_t *pind = (int64_t *)malloc(sizeof(int64_t) * (size_t)k);
+  for (int q = 0; q < nq; ++q) {
+    for (int r = 0; r < nr; ++r) col[r] = knn_cuda_ssd(ref, nr, query, nq, dim, r, q);
+    float *p_dist = col;
+    float curr_dist, max_dist;
+    int l, i, j;
+    max_dist = p_dist[0];
+    pind[0] = 1;
+    /* Part 1: sort the k first elements (knn.cu:121-143) */
+    for (l = 1; l < k; l++) {
+      curr_dist = p_dist[l];
+      if (curr_dist < max_dist) {
+        i = l - 1;
+        for (int a = 0; a < l - 1; a++) {
+          if (p_dist[a] > curr_dist) { i = a; break; }
+        }
+        for (j = l; j > i; j--) {
+          p_dist[j] = p_dist[j - 1];
+          pind[j] = pind[j - 1];
+        }
+        p_dist[i] = curr_dist;
+        pind[i] = l + 1;
+      } else {
+        pind[l] = l + 1;
+      }
+      max_dist = p_dist[l];
+    }
+    /* Part 2: insert remaining elements into the k first lines (knn.cu:145-165) */
+    for (l = k; l < nr; l++) {
+      curr_dist = p_dist[l];
+      if (curr_dist < max_dist) {
+        i = k - 1;
+        for (int a = 0; a < k - 1; a++) {
+          if (p_dist[a] > curr_dist) { i = a; break; }
+        }
+        for (j = k - 1; j > i; j--) {
+          p_dist[j] = p_dist[j - 1];
+          pind[j] = pind[j - 1];
+        }
+        p_dist[i] = curr_dist;
+        pind[i] = l + 1;
+        max_dist = p_dist[k - 1];
+      }
+    }
+    for (l = 0; l < k; ++l) {
+      dist[(size_t)l * nq + q] = sqrtf(p_dist[l]);
+      ind[(size_t)l * nq + q] = pind[l] - 1;
+    }
+  }
+  free(col);
+  free(pind);
+}
+
+/* ------------------------------------------------------------------------- */
+/* In-model kNN: models/dgcnn-hais-concat-direct-4.py:30-90 (twin sppnet.py:14-76) */
+/* ------------------------------------------------------------------------- */
+
+/* Oracle arithmetic for the expanded form (M4:36-38):
+ *   xx_j  = sum_c x[c][j]^2         squares rounded, added in c order (x**2 then sum)
+ *   dot   = fma chain over c        (matmul; k-ordered accumulation from 0)
+ *   inner = -2*dot                  (exact scaling)
+ *   pd    = (-xx_j - inner) - xx_i  -> fl(fl(2*dot - xx_j) - xx_i)
+ * metric 1 (knn_points_normals, M4:62-75):
+ *   p_pd = (xx_j - 2*dot_p) + xx_i ; n_pd = 2 - 2*dot_n ; pd = -(p_pd * (1 + n_pd))
+ * topk(k2) largest pd; torch.topk leaves tie order unspecified -- the oracle
+ * (and the HIP kernel) break ties by LOWEST index and return (value desc, index asc). */
+static float model_pd(const float *x, int C, int N, int i, int j, int metric,
+                      const float *xx) {
+  if (metric == 0) {
+    float dot = 0.f;
+    for (int c = 0; c < C; ++c) dot = fmaf(x[(size_t)c * N + i], x[(size_t)c * N + j], dot);
+    float t = 2.f * dot - xx[j];
+    return t - xx[i];
+  } else {
+    float dp = 0.f, dn = 0.f;
+    for (int c = 0; c < 3; ++c) dp = fmaf(x[(size_t)c * N + i], x[(size_t)c * N + j], dp);
+    for (int c = 3; c < 6; ++c) dn = fmaf(x[(size_t)c * N + i], x[(size_t)c * N + j], dn);
+    float p_pd = (xx[j] - 2.f * dp) + xx[i];
+    float n_pd = 2.f - 2.f * dn;
+    float pd = p_pd * (1.f + n_pd);
+    return -pd;
+  }
+}
+
+/* x (C,N) channel-major for ONE cloud; idx (N,k2) int64, val (N,k2) or NULL. */
+ORC_API void orc_knn_model(const float *x, int C, int N, int k2, int metric,
+                           int64_t *idx, float *val) {
+  float *xx = (float *)malloc(sizeof(float) * (size_t)N);
+  int cx = metric == 0 ? C : 3;
+  for (int j = 0; j < N; ++j) {
+    float s = 0.f;
+    for (int c = 0; c < cx; ++c) {
+      float v = x[(size_t)c * N + j];
+      float sq = v * v;
+      s = (c == 0) ? sq : s + sq;
+    }
+    xx[j] = s;
+  }
+  float *bv = (float *)malloc(sizeof(float) * (size_t)k2);
+  int64_t *bi = (int64_t *)malloc(sizeof(int64_t) * (size_t)k2);
+  for (int i = 0; i < N; ++i) {
+    int cnt = 0;
+    for (int j = 0; j < N; ++j) {
+      float v = model_pd(x, C, N, i, j, metric, xx);
+      /* keep list sorted by (v desc, j asc); j ascends so ties go after equals */
+      if (cnt == k2 && !(v > bv[k2 - 1])) continue;
+      int pos = cnt < k2 ? cnt : k2 - 1;
+      while (pos > 0 && bv[pos - 1] < v) {
+        bv[pos] = bv[pos - 1];
+        bi[pos] = bi[pos - 1];
+        --pos;
+      }
+      bv[pos] = v;
+      bi[pos] = j;
+      if (cnt < k2) ++cnt;
+    }
+    for (int t = 0; t < k2; ++t) {
+      idx[(size_t)i * k2 + t] = bi[t];
+      if (val) val[(size_t)i * k2 + t] = bv[t];
+    }
+  }
+  free(xx); free(bv); free(bi);
+}
+
+/* ------------------------------------------------------------------------- */
+/* pointnet2_ops: models/Pointnet2_PyTorch-master/pointnet2_ops_lib/pointnet2_ops/_ext-src/src */
+/* ------------------------------------------------------------------------- */
+
+static inline float sqdist3(float ax, float ay, float az, float bx, float by, float bz) {
+  float dx = ax - bx, dy = ay - by, dz = az - bz;
+  float t = dx * dx;
+  t = fmaf(dy, dy, t);
+  t = fmaf(dz, dz, t);
+  return t;
+}
+
+/* ball_query_gpu.cu:9-44; idx is zero-initialised by the caller (ball_query.cpp:19-21). */
+ORC_API void orc_ball_query(int b, int n, int m, float radius, int nsample,
+                            const float *new_xyz, const float *xyz, int32_t *idx) {
+  float radius2 = radius * radius;
+  for (int bi = 0; bi < b; ++bi) {
+    const float *X = xyz + (size_t)bi * n * 3;
+    const float *Q = new_xyz + (size_t)bi * m * 3;
+    int32_t *I = idx + (size_t)bi * m * nsample;
+    for (int j = 0; j < m; ++j) {
+      int cnt = 0;
+      for (int k = 0; k < n && cnt < nsample; ++k) {
+        float d2 = sqdist3(Q[j * 3], Q[j * 3 + 1], Q[j * 3 + 2], X[k * 3], X[k * 3 + 1], X[k * 3 + 2]);
+        if (d2 < radius2) {
+          if (cnt == 0)
+            for (int l = 0; l < nsample; ++l) I[(size_t)j * nsample + l] = k;
+          I[(size_t)j * nsample + cnt] = k;
+          ++cnt;
+        }
+      }
+    }
+  }
+}
+
+/* group_points_gpu.cu:8-28 */
+ORC_API void orc_group_points(int b, int c, int n, int npoints, int nsample,
+                              const float *points, const int32_t *idx, float *out) {
+  for (int bi = 0; bi < b; ++bi)
+    for (int l = 0; l < c; ++l)
+      for (int j = 0; j < npoints; ++j)
+        for (int k = 0; k < nsample; ++k) {
+          int ii = idx[((size_t)bi * npoints + j) * nsample + k];
+          out[(((size_t)bi * c + l) * npoints + j) * nsample + k] = points[((size_t)bi * c + l) * n + ii];
+        }
+}
+
+/* group_points_gpu.cu:43-64 (atomicAdd order is unspecified in the reference; the
+ * oracle accumulates in (j,k) order -- compare with a tolerance). grad_points zeroed by caller. */
+ORC_API void orc_group_points_grad(int b, int c, int n, int npoints, int nsample,
+                                   const float *grad_out, const int32_t *idx, float *grad_points) {
+  for (int bi = 0; bi < b; ++bi)
+    for (int l = 0; l < c; ++l)
+      for (int j = 0; j < npoints; ++j)
+        for (int k = 0; k < nsample; ++k) {
+          int ii = idx[((size_t)bi * npoints + j) * nsample + k];
+          grad_points[((size_t)bi * c + l) * n + ii] += grad_out[(((size_t)bi * c + l) * npoints + j) * nsample + k];
+        }
+}
+
+/* sampling_gpu.cu:8-20 */
+ORC_API void orc_gather_points(int b, int c, int n, int m, const float *points,
+                               const int32_t *idx, float *out) {
+  for (int i = 0; i < b; ++i)
+    for (int l = 0; l < c; ++l)
+      for (int j = 0; j < m; ++j)
+        out[((size_t)i * c + l) * m + j] = points[((size_t)i * c + l) * n + idx[(size_t)i * m + j]];
+}
+
+/* sampling_gpu.cu:34-47 */
+ORC_API void orc_gather_points_grad(int b, int c, int n, int m, const float *grad_out,
+                                    const int32_t *idx, float *grad_points) {
+  for (int i = 0; i < b; ++i)
+    for (int l = 0; l < c; ++l)
+      for (int j = 0; j < m; ++j)
+        grad_points[((size_t)i * c + l) * n + idx[(size_t)i * m + j]] += grad_out[((size_t)i * c + l) * m + j];
+}
+
+/* cuda_utils.h:13-19 */
+ORC_API int orc_opt_n_threads(int work_size) {
+  int pow_2 = (int)(log((double)work_size) / log(2.0));
+  int v = 1 << pow_2;
+  if (v > 512) v = 512;
+  if (v < 1) v = 1;
+  return v;
+}
+
+/* sampling_gpu.cu:69-173: literal restatement including the per-thread strided
+ * partial arg-max and the LDS tree reduction (tie -> lower thread id), because
+ * tie-breaking depends on block_size = opt_n_threads(n) (sampling_gpu.cu:178).
+ * temp (b,n) must be initialised to 1e10 by the caller (sampling.cpp:74-76). */
+ORC_API void orc_furthest_point_sampling(int b, int n, int m, const float *dataset,
+                                         float *temp, int32_t *idxs) {
+  if (m <= 0) return;
+  int bs = orc_opt_n_threads(n);
+  float *dists = (float *)malloc(sizeof(float) * (size_t)bs);
+  int *dists_i = (int *)malloc(sizeof(int) * (size_t)bs);
+  for (int bi = 0; bi < b; ++bi) {
+    const float *D = dataset + (size_t)bi * n * 3;
+    float *T = temp + (size_t)bi * n;
+    int32_t *I = idxs + (size_t)bi * m;
+    int old = 0;
+    I[0] = old;
+    for (int j = 1; j < m; ++j) {
+      float x1 = D[old * 3], y1 = D[old * 3 + 1], z1 = D[old * 3 + 2];
+      for (int tid = 0; tid < bs; ++tid) {
+        int besti = 0;
+        float best = -1.f;
+        for (int k = tid; k < n; k += bs) {
+          float x2 = D[k * 3], y2 = D[k * 3 + 1], z2 = D[k * 3 + 2];
+          float mag = x2 * x2;
+          mag = fmaf(y2, y2, mag);
+          mag = fmaf(z2, z2, mag);
+          if ((double)mag <= 1e-3) continue;
+          float d = sqdist3(x2, y2, z2, x1, y1, z1);
+          float d2 = fminf(d, T[k]);
+          T[k] = d2;
+          besti = d2 > best ? k : besti;
+          best = d2 > best ? d2 : best;
+        }
+        dists[tid] = best;
+        dists_i[tid] = besti;
+      }
+      for (int s = bs / 2; s >= 1; s >>= 1)
+        for (int tid = 0; tid < s; ++tid) {
+          float v1 = dists[tid], v2 = dists[tid + s];
+          int i1 = dists_i[tid], i2 = dists_i[tid + s];
+          dists[tid] = fmaxf(v1, v2);
+          dists_i[tid] = v2 > v1 ? i2 : i1;
+        }
+      old = dists_i[0];
+      I[j] = old;
+    }
+  }
+  free(dists); free(dists_i);
+}
+
+/* interpolate_gpu.cu:9-59 (double running bests, strict <) */
+ORC_API void orc_three_nn(int b, int n, int m, const float *unknown, const float *known,
+                          float *dist2, int32_t *idx) {
+  for (int bi = 0; bi < b; ++bi) {
+    const float *U = unknown + (size_t)bi * n * 3;
+    const float *K = known + (size_t)bi * m * 3;
+    for (int j = 0; j < n; ++j) {
+      double best1 = 1e40, best2 = 1e40, best3 = 1e40;
+      int besti1 = 0, besti2 = 0, besti3 = 0;
+      for (int k = 0; k < m; ++k) {
+        float d = sqdist3(U[j * 3], U[j * 3 + 1], U[j * 3 + 2], K[k * 3], K[k * 3 + 1], K[k * 3 + 2]);
+        if (d < best1) {
+          best3 = best2; besti3 = besti2; best2 = best1; besti2 = besti1; best1 = d; besti1 = k;
+        } else if (d < best2) {
+          best3 = best2; besti3 = besti2; best2 = d; besti2 = k;
+        } else if (d < best3) {
+          best3 = d; besti3 = k;
+        }
+      }
+      size_t o = ((size_t)bi * n + j) * 3;
+      dist2[o] = (float)best1; dist2[o + 1] = (float)best2; dist2[o + 2] = (float)best3;
+      idx[o] = besti1; idx[o + 1] = besti2; idx[o + 2] = besti3;
+    }
+  }
+}
+
+/* interpolate_gpu.cu:72-101 */
+ORC_API void orc_three_interpolate(int b, int c, int m, int n, const float *points,
+                                   const int32_t *idx, const float *weight, float *out) {
+  for (int bi = 0; bi < b; ++bi)
+    for (int l = 0; l < c; ++l)
+      for (int j = 0; j < n; ++j) {
+        const float *w = weight + ((size_t)bi * n + j) * 3;
+        const int32_t *ii = idx + ((size_t)bi * n + j) * 3;
+        const float *P = points + ((size_t)bi * c + l) * m;
+        float t = P[ii[0]] * w[0];
+        t = fmaf(P[ii[1]], w[1], t);
+        t = fmaf(P[ii[2]], w[2], t);
+        out[((size_t)bi * c + l) * n + j] = t;
+      }
+}
+
+/* interpolate_gpu.cu:116-143 (atomic order unspecified; tolerance compare) */
+ORC_API void orc_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out,
+                                        const int32_t *idx, const float *weight, float *grad_points) {
+  for (int bi = 0; bi < b; ++bi)
+    for (int l = 0; l < c; ++l)
+      for (int j = 0; j < n; ++j) {
+        const float *w = weight + ((size_t)bi * n + j) * 3;
+        const int32_t *ii = idx + ((size_t)bi * n + j) * 3;
+        float g = grad_out[((size_t)bi * c + l) * n + j];
+        float *G = grad_points + ((size_t)bi * c + l) * m;
+        G[ii[0]] += g * w[0];
+        G[ii[1]] += g * w[1];
+        G[ii[2]] += g * w[2];
+      }
+}
+
+/* ------------------------------------------------------------------------- */
+/* softgroup/ops/src                                                          */
+/* ------------------------------------------------------------------------- */
+
+/* voxelize/voxelize.cpp:68-165 voxelize_inputmap + :41-57 voxelize_outputmap.
+ * The reference dedups with google::dense_hash_map keyed on (batch, x, y, z) in
+ * input order; voxel ids are assigned globally in first-occurrence order.  This
+ * restatement uses an open-addressing table with the same key equality -- the
+ * result does not depend on the hash function (datatype.h:13-22).
+ * Two-call protocol: pass output_coords/output_map == NULL to get (M, maxActive).
+ * coords (N, ncol) int64 with ncol == 3 or 4 ([batch,x,y,z]). */
+typedef struct { int64_t k[4]; int32_t v; int used; } vox_ent;
+
+ORC_API void orc_voxelize_idx(const int64_t *coords, int N, int ncol, int mode,
+                              int32_t *input_map, int *M_out, int *maxActive_out,
+                              int64_t *output_coords, int32_t *output_map) {
+  size_t cap = 16;
+  while (cap < (size_t)N * 2 + 2) cap <<= 1;
+  vox_ent *tab = (vox_ent *)calloc(cap, sizeof(vox_ent));
+  int32_t *first = (int32_t *)malloc(sizeof(int32_t) * (size_t)(N > 0 ? N : 1));
+  int32_t *last = (int32_t *)malloc(sizeof(int32_t) * (size_t)(N > 0 ? N : 1));
+  int32_t *count = (int32_t *)calloc((size_t)(N > 0 ? N : 1), sizeof(int32_t));
+  int nActive = 0;
+  for (int i = 0; i < N; ++i) {
+    int64_t key[4] = {0, 0, 0, 0};
+    if (ncol == 3) {
+      for (int j = 0; j < 3; ++j) key[j + 1] = (int32_t)coords[(size_t)i * 3 + j];
+    } else {
+      key[0] = (int32_t)coords[(size_t)i * 4];
+      for (int j = 0; j < 3; ++j) key[j + 1] = (int32_t)coords[(size_t)i * 4 + 1 + j];
+    }
+    uint64_t h = 1469598103934665603ULL;
+    for (int j = 0; j < 4; ++j) { h ^= (uint64_t)key[j]; h *= 1099511628211ULL; }
+    size_t p = (size_t)h & (cap - 1);
+    while (tab[p].used && memcmp(tab[p].k, key, sizeof(key)) != 0) p = (p + 1) & (cap - 1);
+    if (!tab[p].used) {
+      tab[p].used = 1;
+      memcpy(tab[p].k, key, sizeof(key));
+      tab[p].v = nActive;
+      first[nActive] = i;
+      ++nActive;
+    }
+    int v = tab[p].v;
+    input_map[i] = v;
+    last[v] = i;
+    count[v]++;
+  }
+  int maxActive = 1;
+  if (mode == 3 || mode == 4)
+    for (int v = 0; v < nActive; ++v) if (count[v] > maxActive) maxActive = count[v];
+  *M_out = nActive;
+  *maxActive_out = maxActive;
+  if (output_coords && output_map) {
+    int W = maxActive + 1;
+    memset(output_map, 0, sizeof(int32_t) * (size_t)nActive * W);
+    if (mode == 3 || mode == 4) {
+      int32_t *fill = (int32_t *)calloc((size_t)(nActive > 0 ? nActive : 1), sizeof(int32_t));
+      for (int i = 0; i < N; ++i) {
+        int v = input_map[i];
+        output_map[(size_t)v * W + 1 + fill[v]] = i;
+        fill[v]++;
+      }
+      for (int v = 0; v < nActive; ++v) output_map[(size_t)v * W] = count[v];
+      free(fill);
+    } else {
+      /* mode 0: unique; mode 1: front(); mode 2: back()  (voxelize.cpp:131-151) */
+      for (int v = 0; v < nActive; ++v) {
+        output_map[(size_t)v * W] = 1;
+        output_map[(size_t)v * W + 1] = (mode == 2) ? last[v] : first[v];
+      }
+    }
+    /* voxelize.cpp:47-55: coords of rule[1] (first listed input row) */
+    for (int v = 0; v < nActive; ++v) {
+      int src = output_map[(size_t)v * W + 1];
+      for (int j = 0; j < ncol; ++j)
+        output_coords[(size_t)v * ncol + j] = coords[(size_t)src * ncol + j];
+    }
+  }
+  free(tab); free(first); free(last); free(count);
+}
+
+/* voxelize/voxelize.cu:9-25: one block per output row, one thread per plane; the
+ * atomicAdd sequence per (row,plane) is issued by a single thread in rule order,
+ * so the sum is sequential.  output_feats zero-initialised by caller. */
+ORC_API void orc_voxelize_fp(int nOutputRows, int maxActive, int nPlanes, const float *feats,
+                             float *output_feats, const int32_t *rules, int average) {
+  for (int row = 0; row < nOutputRows; ++row) {
+    const int32_t *r = rules + (size_t)row * (maxActive + 1);
+    int nActive = r[0];
+    float multiplier = (average && nActive > 0) ? 1.f / (float)nActive : 1.f;
+    for (int i = 1; i <= nActive; ++i)
+      for (int p = 0; p < nPlanes; ++p)
+        output_feats[(size_t)row * nPlanes + p] += multiplier * feats[(size_t)r[i] * nPlanes + p];
+  }
+}
+
+/* voxelize/voxelize.cu:38-54 */
+ORC_API void orc_voxelize_bp(int nOutputRows, int maxActive, int nPlanes, const float *d_output_feats,
+                             float *d_feats, const int32_t *rules, int average) {
+  for (int row = 0; row < nOutputRows; ++row) {
+    const int32_t *r = rules + (size_t)row * (maxActive + 1);
+    int nActive = r[0];
+    float multiplier = (average && nActive > 0) ? 1.f / (float)nActive : 1.f;
+    for (int i = 1; i <= nActive; ++i)
+      for (int p = 0; p < nPlanes; ++p)
+        d_feats[(size_t)r[i] * nPlanes + p] += multiplier * d_output_feats[(size_t)row * nPlanes + p];
+  }
+}
+
+/* bfs_cluster/bfs_cluster.cu:18-77 (with adjacency, cap 3000) and
+ * bfs_cluster_easy/bfs_cluster_easy.cu:15-66 (adj == NULL, cap 1000).
+ * The reference allocates CSR segments with atomicAdd(cumsum,cnt) => segment
+ * ORDER is run-to-run non-deterministic; the oracle assigns segments in point
+ * order (exclusive prefix sum of counts).  Neighbour lists themselves are in
+ * ascending k.  Returns the untruncated total (the reference's cumsum). */
+ORC_API int orc_ballquery_batch_p(int n, int meanActive, float radius, const float *xyz,
+                                  const int32_t *batch_idxs, const int32_t *batch_offsets,
+                                  const float *adj_inst, float thr_inst,
+                                  const float *adj_para, float thr_para,
+                                  int32_t *idx, int32_t *start_len) {
+  const int cap = adj_inst ? 3000 : 1000;
+  float radius2 = radius * radius;
+  long cumsum = 0;
+  long thre = (long)n * meanActive;
+  int *tmp = (int *)malloc(sizeof(int) * 3000);
+  for (int p = 0; p < n; ++p) {
+    int bidx = batch_idxs[p];
+    int start = batch_offsets[bidx], end = batch_offsets[bidx + 1];
+    int cnt = 0;
+    for (int k = start; k < end; ++k) {
+      float d2 = sqdist3(xyz[p * 3], xyz[p * 3 + 1], xyz[p * 3 + 2], xyz[k * 3], xyz[k * 3 + 1], xyz[k * 3 + 2]);
+      int ok = d2 < radius2;
+      if (ok && adj_inst)
+        ok = (adj_inst[(size_t)p * n + k] > thr_inst) && (adj_para[(size_t)p * n + k] > thr_para);
+      if (ok) {
+        if (cnt < cap) tmp[cnt] = k; else break;
+        ++cnt;
+      }
+    }
+    start_len[p * 2] = (int32_t)cumsum;
+    start_len[p * 2 + 1] = cnt;
+    long s = cumsum;
+    cumsum += cnt;
+    if (s >= thre) continue;
+    int w = cnt;
+    if (s + cnt >= thre) w = (int)(thre - s);
+    for (int k = 0; k < w; ++k) idx[s + k] = tmp[k];
+  }
+  free(tmp);
+  return (int)cumsum;
+}
+
+/* bfs_cluster/bfs_cluster.cpp:48-143.  Two-call: cluster_idxs == NULL -> sizes only. */
+ORC_API void orc_bfs_cluster(const float *class_numpoint_mean, const int32_t *ball_query_idxs,
+                             const int32_t *start_len, int nPoint, float threshold, int class_id,
+                             int *sumNPoint_out, int *nCluster_out,
+                             int32_t *cluster_idxs, int32_t *cluster_offsets) {
+  int *visited = (int *)calloc((size_t)(nPoint > 0 ? nPoint : 1), sizeof(int));
+  int *queue = (int *)malloc(sizeof(int) * (size_t)(nPoint > 0 ? nPoint : 1));
+  int sumNPoint = 0, nCluster = 0;
+  if (cluster_offsets) cluster_offsets[0] = 0;
+  for (int i = 0; i < nPoint; ++i) {
+    if (visited[i]) continue;
+    int head = 0, tail = 0;
+    queue[tail++] = i;
+    visited[i] = 1;
+    while (head < tail) {
+      int cur = queue[head++];
+      int start = start_len[cur * 2], len = start_len[cur * 2 + 1];
+      for (int t = start; t < start + len; ++t) {
+        int j = ball_query_idxs[t];
+        if (visited[j] == 1) continue;
+        visited[j] = 1;
+        queue[tail++] = j;
+      }
+    }
+    float mean = class_numpoint_mean[class_id];
+    float thr = (mean == -1) ? threshold : threshold * mean;
+    if (tail >= thr) {
+      if (cluster_idxs) {
+        for (int t = 0; t < tail; ++t) {
+          cluster_idxs[(size_t)(sumNPoint + t) * 2] = nCluster;
+          cluster_idxs[(size_t)(sumNPoint + t) * 2 + 1] = queue[t];
+        }
+        cluster_offsets[nCluster + 1] = sumNPoint + tail;
+      }
+      sumNPoint += tail;
+      ++nCluster;
+    }
+  }
+  *sumNPoint_out = sumNPoint;
+  *nCluster_out = nCluster;
+  free(visited); free(queue);
+}
+
+/* hierarchical_aggregation/hierarchical_aggregation.cpp:7-8 */
+static const float class_numpoint_mean_dict[10] = {-1.f, -1.f, 3917.f, 12056.f, 2303.f,
+                                                   8331.f, 3948.f, 3166.f, 5629.f, 11719.f};
+
+/* hierarchical_aggregation.cpp:11-183 (BFS restricted to same label, centroid
+ * accumulation, split into fragment / kept / primary).  Output protocol: the
+ * caller passes buffers sized for the worst case (N points, N clusters each).
+ * kind 0 = fragment, 1 = kept, 2 = primary.
+ *   idxs[kind]    (<=N, 2) int32, offsets[kind] (<=N+1) int32, centers[kind] (<=N,5) f32
+ *   counts[kind*2+0] = sumNPoint, counts[kind*2+1] = nCluster */
+ORC_API void orc_hier_split(const int32_t *semantic_label, const float *coord_shift,
+                            const int32_t *batch_idxs, const int32_t *ball_query_idxs,
+                            const int32_t *start_len, int nPoint,
+                            int32_t *idxs0, int32_t *offs0, float *cent0,
+                            int32_t *idxs1, int32_t *offs1, float *cent1,
+                            int32_t *idxs2, int32_t *offs2, float *cent2, int *counts) {
+  int32_t *IDX[3] = {idxs0, idxs1, idxs2};
+  int32_t *OFF[3] = {offs0, offs1, offs2};
+  float *CEN[3] = {cent0, cent1, cent2};
+  int sum[3] = {0, 0, 0}, ncl[3] = {0, 0, 0};
+  for (int t = 0; t < 3; ++t) OFF[t][0] = 0;
+  int *visited = (int *)calloc((size_t)(nPoint > 0 ? nPoint : 1), sizeof(int));
+  int *queue = (int *)malloc(sizeof(int) * (size_t)(nPoint > 0 ? nPoint : 1));
+  for (int i = 0; i < nPoint; ++i) {
+    if (visited[i]) continue;
+    int head = 0, tail = 0;
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    queue[tail++] = i;
+    ax += coord_shift[i * 3]; ay += coord_shift[i * 3 + 1]; az += coord_shift[i * 3 + 2];
+    int cls = semantic_label[i], bidx = batch_idxs[i];
+    visited[i] = 1;
+    while (head < tail) {
+      int cur = queue[head++];
+      int start = start_len[cur * 2], len = start_len[cur * 2 + 1];
+      int label_cur = semantic_label[cur];
+      for (int t = start; t < start + len; ++t) {
+        int j = ball_query_idxs[t];
+        if (semantic_label[j] != label_cur) continue;
+        if (visited[j] == 1) continue;
+        queue[tail++] = j;
+        ax += coord_shift[j * 3]; ay += coord_shift[j * 3 + 1]; az += coord_shift[j * 3 + 2];
+        visited[j] = 1;
+      }
+    }
+    float mean = class_numpoint_mean_dict[cls];
+    float low_thre = (float)(0.05 * mean), high_thre = (float)(0.3 * mean);
+    int kinds[2], nk = 0;
+    if (tail < high_thre) {
+      kinds[nk++] = 0;
+      if (tail >= low_thre && tail < high_thre) kinds[nk++] = 1;
+    } else {
+      kinds[nk++] = 2;
+    }
+    for (int q = 0; q < nk; ++q) {
+      int t = kinds[q], c = ncl[t];
+      for (int u = 0; u < tail; ++u) {
+        IDX[t][(size_t)(sum[t] + u) * 2] = c;
+        IDX[t][(size_t)(sum[t] + u) * 2 + 1] = queue[u];
+      }
+      sum[t] += tail;
+      OFF[t][c + 1] = sum[t];
+      CEN[t][c * 5 + 0] = ax / (float)tail;
+      CEN[t][c * 5 + 1] = ay / (float)tail;
+      CEN[t][c * 5 + 2] = az / (float)tail;
+      CEN[t][c * 5 + 3] = (float)cls;
+      CEN[t][c * 5 + 4] = (float)bidx;
+      ncl[t]++;
+    }
+  }
+  for (int t = 0; t < 3; ++t) { counts[t * 2] = sum[t]; counts[t * 2 + 1] = ncl[t]; }
+  free(visited); free(queue);
+}
+
+/* hierarchical_aggregation.cu:22-196 set aggregation (using_set_aggr=True).  The
+ * reference's absorbed-fragment order comes from atomicAdd (unspecified); the
+ * oracle absorbs in fragment-index order.  pow(x,2) is restated as x*x summed
+ * left to right without contraction.  primary_idxs_post sized (sumFrag+sumPrim, 2). */
+ORC_API void orc_hier_set_aggr(int fragment_num, const int32_t *fragment_idxs,
+                               const int32_t *fragment_offsets, const float *fragment_centers,
+                               int primary_num, const int32_t *primary_idxs,
+                               const int32_t *primary_offsets, const float *primary_centers,
+                               int32_t *primary_idxs_post, int32_t *primary_offsets_post) {
+  const int MAX_FRAG = 1000, MAX_PTS = 3000;
+  primary_offsets_post[0] = 0;
+  if (primary_num == 0) return;
+  int *owner = (int *)malloc(sizeof(int) * (size_t)(fragment_num > 0 ? fragment_num : 1));
+  for (int f = 0; f < fragment_num; ++f) {
+    float nearest = 10000.f;
+    int ni = -1;
+    for (int i = 0; i < primary_num; ++i) {
+      if (fabsf(primary_centers[i * 5 + 3] - fragment_centers[f * 5 + 3]) > 0.1) continue;
+      if (fabsf(primary_centers[i * 5 + 4] - fragment_centers[f * 5 + 4]) > 0.1) continue;
+      float dx = primary_centers[i * 5 + 0] - fragment_centers[f * 5 + 0];
+      float dy = primary_centers[i * 5 + 1] - fragment_centers[f * 5 + 1];
+      float dz = primary_centers[i * 5 + 2] - fragment_centers[f * 5 + 2];
+      float d = (dx * dx + dy * dy) + dz * dz;
+      if (d < nearest) { nearest = d; ni = i; }
+    }
+    owner[f] = -1;
+    if (ni == -1) continue;
+    int pn = primary_offsets[ni + 1] - primary_offsets[ni];
+    float r_size = (float)(0.01 * sqrtf((float)pn));
+    if (nearest < r_size * r_size) owner[f] = ni;
+  }
+  int acc = 0;
+  for (int i = 0; i < primary_num; ++i) {
+    int np = primary_offsets[i + 1] - primary_offsets[i];
+    memcpy(primary_idxs_post + (size_t)acc * 2, primary_idxs + (size_t)primary_offsets[i] * 2,
+           sizeof(int32_t) * 2 * (size_t)np);
+    acc += np;
+    int nfrag = 0, npts = 0;
+    for (int f = 0; f < fragment_num; ++f) {
+      if (owner[f] != i) continue;
+      if (nfrag >= MAX_FRAG) break;
+      ++nfrag;
+      for (int j = fragment_offsets[f]; j < fragment_offsets[f + 1]; ++j) {
+        if (npts < MAX_PTS) {
+          primary_idxs_post[(size_t)(acc + npts) * 2] = i;
+          primary_idxs_post[(size_t)(acc + npts) * 2 + 1] = fragment_idxs[(size_t)j * 2 + 1];
+          ++npts;
+        }
+      }
+    }
+    acc += npts;
+    primary_offsets_post[i + 1] = acc;
+  }
+  free(owner);
+}
+
+/* sec_mean/sec_mean.cu:13-29,41-57,69-85 ; op 0 = mean, 1 = min, 2 = max */
+ORC_API void orc_sec_op(int op, int nProposal, int C, const float *inp, const int32_t *offsets, float *out) {
+  for (int p = 0; p < nProposal; ++p) {
+    int start = offsets[p], end = offsets[p + 1];
+    float count = (float)(end - start);
+    for (int c = 0; c < C; ++c) {
+      float acc = op == 0 ? 0.f : (op == 1 ? (float)1e50 : (float)-1e50);
+      for (int i = start; i < end; ++i) {
+        float v = inp[(size_t)i * C + c];
+        if (op == 0) acc += v / count;
+        else if (op == 1) { if (v < acc) acc = v; }
+        else { if (v > acc) acc = v; }
+      }
+      out[(size_t)p * C + c] = acc;
+    }
+  }
+}
+
+/* roipool/roipool.cu:12-32 */
+ORC_API void orc_global_avg_pool_fp(int nProposal, int C, const float *feats, const int32_t *offsets, float *out) {
+  for (int p = 0; p < nProposal; ++p) {
+    int start = offsets[p], end = offsets[p + 1];
+    int n_points = end - start;
+    for (int c = 0; c < C; ++c) {
+      float val = 0.f;
+      for (int i = start; i < end; ++i) val += feats[(size_t)i * C + c];
+      out[(size_t)p * C + c] = val / (float)n_points;
+    }
+  }
+}
+
+/* roipool/roipool.cu:46-60 ; d_feats zero-initialised by caller */
+ORC_API void orc_global_avg_pool_bp(int nProposal, int C, float *d_feats, const int32_t *offsets, const float *d_out) {
+  for (int p = 0; p < nProposal; ++p) {
+    int start = offsets[p], end = offsets[p + 1];
+    int n_points = end - start;
+    for (int c = 0; c < C; ++c)
+      for (int i = start; i < end; ++i)
+        d_feats[(size_t)i * C + c] += d_out[(size_t)p * C + c] / (float)n_points;
+  }
+}
+
+/* cal_iou_and_masklabel.cu:9-34 (mask == NULL) and :36-68 (mask_scores_sigmoid given) */
+ORC_API void orc_get_mask_iou(int nInstance, int nProposal, const int32_t *proposals_idx,
+                              const int32_t *proposals_offset, const int64_t *instance_labels,
+                              const int32_t *instance_pointnum, const float *mask_scores_sigmoid,
+                              float *proposals_iou) {
+  for (int p = 0; p < nProposal; ++p) {
+    int start = proposals_offset[p], end = proposals_offset[p + 1];
+    int proposal_total = 0;
+    if (mask_scores_sigmoid) {
+      for (int i = start; i < end; ++i) if (mask_scores_sigmoid[i] > 0.5) proposal_total += 1;
+    } else {
+      proposal_total = end - start;
+    }
+    for (int inst = 0; inst < nInstance; ++inst) {
+      int instance_total = instance_pointnum[inst];
+      int intersection = 0;
+      for (int i = start; i < end; ++i) {
+        if (mask_scores_sigmoid && !(mask_scores_sigmoid[i] > 0.5)) continue;
+        if ((int)instance_labels[proposals_idx[i]] == inst) intersection += 1;
+      }
+      proposals_iou[(size_t)p * nInstance + inst] =
+          (float)((float)intersection / ((float)(proposal_total + instance_total - intersection) + 1e-5));
+    }
+  }
+}
+
+/* cal_iou_and_masklabel.cu:70-104 ; mask_label pre-filled with -1 by caller (functions.py:252) */
+ORC_API void orc_get_mask_label(int nInstance, int nProposal, float iou_thr, const int32_t *proposals_idx,
+                                const int32_t *proposals_offset, const int64_t *instance_labels,
+                                const int64_t *instance_cls, const float *proposals_iou, float *mask_label) {
+  for (int p = 0; p < nProposal; ++p) {
+    int start = proposals_offset[p], end = proposals_offset[p + 1];
+    float max_iou = 0.f;
+    int max_ind = 0;
+    for (int inst = 0; inst < nInstance; ++inst) {
+      if (proposals_iou[(size_t)p * nInstance + inst] > max_iou) {
+        if (instance_cls[inst] != -100) {
+          max_iou = proposals_iou[(size_t)p * nInstance + inst];
+          max_ind = inst;
+        }
+      }
+    }
+    if (max_iou >= iou_thr) {
+      for (int i = start; i < end; ++i)
+        mask_label[i] = ((int)instance_labels[proposals_idx[i]] == max_ind) ? 1.f : 0.f;
+    }
+  }
+}

@@ -1,0 +1,265 @@
+"""CPU ORACLE (test infrastructure) -- plain PyTorch fp32 restatement of the pure-torch part
+of the hot path: graph features, EdgeConv block, DGCNN encoder, offset module, attention
+stacks.  Functional style (weights passed as dicts of tensors); every function cites the
+reference lines it follows (M4 = models/dgcnn-hais-concat-direct-4.py).  Pinned against
+tests/golden/*.npz, which were produced by running the reference's own code
+(tests/golden/make_golden.py).  Never imported by gcanet_amd/.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import knn_model
+
+
+# ----------------------------------------------------------------------------- kNN
+def knn(x, k1, k2):
+    """M4:30-47 (twin sppnet.py:14-31); ties -> lowest index (oracle convention)."""
+    return torch.from_numpy(knn_model(x.detach().cpu().numpy(), k1, k2, 0))
+
+
+def knn_points_normals(x, k1, k2):
+    """M4:50-90."""
+    return torch.from_numpy(knn_model(x.detach().cpu().numpy(), k1, k2, 1))
+
+
+# ----------------------------------------------------------------------------- graph features
+def _gather_neighbours(x, idx):
+    """x (B,C,N), idx (B,N,k) -> neighbours (B,N,k,C), centre (B,N,1,C)  (M4:103-122)."""
+    B, C, N = x.shape
+    xt = x.transpose(2, 1).contiguous()                      # (B,N,C)
+    flat = (idx + torch.arange(B).view(-1, 1, 1) * N).reshape(-1)
+    nb = xt.reshape(B * N, C)[flat].view(B, N, idx.shape[2], C)
+    return nb, xt.view(B, N, 1, C)
+
+
+def get_graph_feature(x, k1=20, k2=20, idx=None):
+    """M4:93-124: cat(x_j - x_i, x_i) -> (B,2C,N,k)."""
+    if idx is None:
+        idx = knn(x, k1, k2)
+    nb, ctr = _gather_neighbours(x, idx)
+    ctr = ctr.expand_as(nb)
+    return torch.cat((nb - ctr, ctr), dim=3).permute(0, 3, 1, 2)
+
+
+def get_graph_feature_with_normals(x, k1=20, k2=20, idx=None):
+    """M4:127-161: same construction, neighbours from knn_points_normals."""
+    if idx is None:
+        idx = knn_points_normals(x, k1, k2)
+    return get_graph_feature(x, k1, k2, idx)
+
+
+def get_graph_feature_with_normals_g(x, k1=20, k2=20, idx=None):
+    """M4:164-205: [clamp(n_i.n_j, +-0.99), n_j - n_i, n_i] -> (B,7,N,k)."""
+    if idx is None:
+        idx = knn_points_normals(x, k1, k2)
+    nb, ctr = _gather_neighbours(x, idx)
+    n_j, n_i = nb[..., 3:6], ctr[..., 3:6].expand(-1, -1, idx.shape[2], -1)
+    angle = (n_i * n_j).sum(-1, keepdim=True).clamp(-0.99, 0.99)
+    return torch.cat((angle, n_j - n_i, n_i), dim=3).permute(0, 3, 1, 2)
+
+
+# ----------------------------------------------------------------------------- EdgeConv block
+def edgeconv_block(x, idx, w, gamma, beta, groups, slope=0.2, eps=1e-5):
+    """get_graph_feature -> Conv2d 1x1 (no bias) -> GroupNorm -> LeakyReLU -> max over k
+    (M4:463-505).  x (B,C,N), idx (B,N,k), w (Cout,2C) -> (B,Cout,N)."""
+    ef = get_graph_feature(x, idx=idx)
+    y = F.conv2d(ef, w[:, :, None, None])
+    y = F.leaky_relu(F.group_norm(y, groups, gamma, beta, eps), slope)
+    return y.max(dim=-1)[0]
+
+
+def grouped_block(ef, w, gamma, beta, groups, slope=0.2, eps=1e-5):
+    """Same tail on a materialised edge tensor ef (B,Cin,N,k) (conv_normal M4:575-577, offset conv1 M4:391-393)."""
+    y = F.conv2d(ef, w[:, :, None, None])
+    y = F.leaky_relu(F.group_norm(y, groups, gamma, beta, eps), slope)
+    return y.max(dim=-1)[0]
+
+
+def dgcnn_encoder(x, sd, k, mode=5, idxs=None, prefix=""):
+    """DGCNNEncoderGn.forward (M4:492-534; sppnet.py:180-225 returns (x4, x_features)).
+    sd: state dict (conv{1,2,3}.0.weight, bn{1,2,3}.*, mlp1.*, bnmlp1.*); idxs: optional
+    per-layer neighbour lists.  Returns (x4 (B,1024), x_features (B,256,N), [idx1,idx2,idx3])."""
+    g = lambda n: torch.as_tensor(sd[prefix + n])
+    used = []
+
+    def layer(inp, i, first):
+        if idxs is not None:
+            idx = torch.as_tensor(idxs[i])
+        elif first and mode == 5:
+            idx = knn_points_normals(inp, k, k)
+        else:
+            idx = knn(inp, k, k)
+        used.append(idx)
+        w = g("conv%d.0.weight" % (i + 1))[:, :, 0, 0]
+        return edgeconv_block(inp, idx, w, g("bn%d.weight" % (i + 1)), g("bn%d.bias" % (i + 1)), 2)
+
+    x1 = layer(x, 0, True)
+    x2 = layer(x1, 1, False)
+    x3 = layer(x2, 2, False)
+    xf = torch.cat((x1, x2, x3), dim=1)
+    h = F.conv1d(xf, g("mlp1.weight"), g("mlp1.bias"))
+    h = F.relu(F.group_norm(h, 8, g("bnmlp1.weight"), g("bnmlp1.bias")))
+    return h.max(dim=2)[0], xf, used
+
+
+# ----------------------------------------------------------------------------- offset module
+def compute_batch_adjacency_matrix(pts, sigma=1.0):
+    """M4:210-233 (dist_state=True): cdist, zero diagonal, GLOBAL min/max normalise, Gaussian, zero diagonal."""
+    d = torch.cdist(pts, pts)
+    d = d - torch.diag_embed(torch.diagonal(d, dim1=-2, dim2=-1))
+    d = (d - d.min()) / (d.max() - d.min())
+    a = torch.exp(-d ** 2 / (2 * sigma ** 2))
+    return a - torch.diag_embed(torch.diagonal(a, dim1=-2, dim2=-1))
+
+
+def cos_dist(a, b):
+    """M4:326-342: -(1 - cos) between (B,N,C) and (B,K,C) -> (B,N,K)."""
+    an = a / a.norm(dim=-1, keepdim=True)
+    bn = b / b.norm(dim=-1, keepdim=True)
+    return -(1 - torch.einsum("bnc,bkc->bnk", an, bn))
+
+
+def key_point_indices(num_points, n_keys=120):
+    """M4:403-406: legacy NumPy RNG, seed 1234, shuffle of arange(N), first n_keys."""
+    l = np.arange(num_points)
+    np.random.seed(1234)
+    np.random.shuffle(l)
+    return torch.from_numpy(l[:n_keys]).long()
+
+
+def kpam(x, att, w1, w2):
+    """KPAM.forward (M4:351-373).  att (B,N,k) is permuted to (B,k,N), run through
+    Conv1d(k->k)-ReLU-Conv1d(k->k) (channels = the k axis), permuted BACK to (B,N,k) and only then
+    soft-maxed with dim=2 -- i.e. over the k neighbours (the in-line comment 'b,c,n' at M4:363 is
+    stale).  The weights scale x (B,N,k,F)."""
+    a = att.permute(0, 2, 1)
+    a = F.conv1d(F.relu(F.conv1d(a, w1[:, :, None])), w2[:, :, None]).permute(0, 2, 1)
+    a = torch.softmax(a, dim=2).unsqueeze(-1)
+    return a * x
+
+
+def offset_pred_module(points, feature, emb, sd, nn_nb=30, n_keys=120, prefix=""):
+    """OFFSET_PRED_MODULE.forward (M4:398-452).  points (B,N,3), feature (B,N,128), emb (B,N,64)
+    -> offsets (B,3,N).  Layout quirk kept: the conv runs on (B,131,k,N) and the max is over dim -2."""
+    g = lambda n: torch.as_tensor(sd[prefix + n])
+    B, N, _ = points.shape
+    sub = key_point_indices(N, n_keys)
+    key_pts, key_feat, key_emb = points[:, sub], feature[:, sub], emb[:, sub]
+    dist = cos_dist(emb, key_emb)                                  # (B,N,120)
+    topk_dist, topk_idx = torch.topk(dist, nn_nb, dim=2, largest=True)
+    bi = torch.arange(B).view(B, 1, 1)
+    f = torch.cat([key_feat[bi, topk_idx], key_pts[bi, topk_idx] - points.unsqueeze(2)], 3)   # (B,N,k,131)
+    f = kpam(f, topk_dist, g("attention.conv1.0.weight")[:, :, 0], g("attention.conv1.2.weight")[:, :, 0])
+    y = F.conv2d(f.permute(0, 3, 2, 1), g("conv1.0.weight"))      # (B,128,k,N)
+    y = F.leaky_relu(F.group_norm(y, 2, g("bn1.weight"), g("bn1.bias")), 0.2)
+    y = y.max(dim=-2)[0]                                           # (B,128,N)
+    y = torch.cat([y, feature.permute(0, 2, 1)], dim=1)            # (B,256,N)
+    return F.conv1d(y, g("mlp_offset.weight"), g("mlp_offset.bias"))
+
+
+# ----------------------------------------------------------------------------- attention stacks
+def transformer(x, sd, depth, heads, prefix=""):
+    """models/transformer.py:36-91: pre-norm MHSA (scale = dim**-0.5, NOT dim_head) + GELU FFN, residuals."""
+    g = lambda n: torch.as_tensor(sd[prefix + n])
+    dim = x.shape[-1]
+    scale = dim ** -0.5
+    for l in range(depth):
+        p = "layers.%d." % l
+        h = F.layer_norm(x, (dim,), g(p + "0.fn.norm.weight"), g(p + "0.fn.norm.bias"))
+        qkv = F.linear(h, g(p + "0.fn.fn.to_qkv.weight"))
+        b, n, _ = qkv.shape
+        q, k, v = [t.view(b, n, heads, -1).transpose(1, 2) for t in qkv.chunk(3, dim=-1)]
+        att = torch.softmax(q @ k.transpose(-1, -2) * scale, dim=-1)
+        o = (att @ v).transpose(1, 2).reshape(b, n, -1)
+        x = F.linear(o, g(p + "0.fn.fn.to_out.0.weight"), g(p + "0.fn.fn.to_out.0.bias")) + x
+        h = F.layer_norm(x, (dim,), g(p + "1.fn.norm.weight"), g(p + "1.fn.norm.bias"))
+        h = F.linear(F.gelu(F.linear(h, g(p + "1.fn.fn.net.0.weight"), g(p + "1.fn.fn.net.0.bias"))),
+                     g(p + "1.fn.fn.net.3.weight"), g(p + "1.fn.fn.net.3.bias"))
+        x = h + x
+    return x
+
+
+def _mha(q_in, k_in, v_in, w, b, ow, ob, nhead, attn_mask=None):
+    """nn.MultiheadAttention(batch_first) forward, eval mode."""
+    d = q_in.shape[-1]
+    q = F.linear(q_in, w[:d], b[:d])
+    k = F.linear(k_in, w[d:2 * d], b[d:2 * d])
+    v = F.linear(v_in, w[2 * d:], b[2 * d:])
+    B, L, _ = q.shape
+    S = k.shape[1]
+    hd = d // nhead
+    q = q.view(B, L, nhead, hd).transpose(1, 2)
+    k = k.view(B, S, nhead, hd).transpose(1, 2)
+    v = v.view(B, S, nhead, hd).transpose(1, 2)
+    s = q @ k.transpose(-1, -2) / math.sqrt(hd)
+    if attn_mask is not None:
+        s = s.masked_fill(attn_mask.view(1, 1, L, S), float("-inf"))
+    o = (torch.softmax(s, dim=-1) @ v).transpose(1, 2).reshape(B, L, d)
+    return F.linear(o, ow, ob)
+
+
+def query_decoder(x, batch_offsets, sd, num_layer, nhead, iter_pred=False, attn_mask=False, prefix=""):
+    """models/query_decoder.py:104-239 (eval).  Quirks kept: in cross-attention the results of
+    self.dropout(output) / self.norm(output) are DISCARDED (:40-42); pe only if present."""
+    g = lambda n: torch.as_tensor(sd[prefix + n])
+    has = lambda n: (prefix + n) in sd
+    d = g("query.weight").shape[1]
+    ln = lambda t, p: F.layer_norm(t, (d,), g(p + ".weight"), g(p + ".bias"))
+    inst = F.relu(ln(F.linear(x, g("input_proj.0.weight"), g("input_proj.0.bias")), "input_proj.1"))
+    maskf = F.linear(F.relu(F.linear(x, g("x_mask.0.weight"), g("x_mask.0.bias"))), g("x_mask.2.weight"), g("x_mask.2.bias"))
+    B = len(batch_offsets) - 1
+    query = g("query.weight").unsqueeze(0).repeat(B, 1, 1)
+    pe = g("pe.weight").unsqueeze(0).repeat(B, 1, 1) if (iter_pred and has("pe.weight")) else None
+
+    def head(q):
+        qn = ln(q, "out_norm")
+        mlp = lambda p: F.linear(F.relu(F.linear(qn, g(p + ".0.weight"), g(p + ".0.bias"))), g(p + ".2.weight"), g(p + ".2.bias"))
+        masks, amasks = [], []
+        for i in range(B):
+            m = qn[i] @ maskf[batch_offsets[i]:batch_offsets[i + 1]].T
+            if attn_mask:
+                am = (m.sigmoid() < 0.5)
+                am[torch.where(am.sum(-1) == am.shape[-1])] = False
+                amasks.append(am)
+            masks.append(m)
+        return mlp("out_cls"), mlp("out_score"), masks, mlp("out_paras"), amasks
+
+    outs = []
+    amasks = []
+    if iter_pred:
+        o = head(query)
+        outs.append(o)
+        amasks = o[4]
+    for l in range(num_layer):
+        p = "cross_attn_layers.%d.attn." % l
+        qpe = query if pe is None else query + pe
+        new = []
+        for i in range(B):
+            kv = inst[batch_offsets[i]:batch_offsets[i + 1]].unsqueeze(0)
+            am = amasks[i] if (iter_pred and amasks) else None
+            o = _mha(qpe[i:i + 1], kv, kv, g(p + "in_proj_weight"), g(p + "in_proj_bias"),
+                     g(p + "out_proj.weight"), g(p + "out_proj.bias"), nhead, am)
+            new.append(o + qpe[i])
+        query = torch.cat(new, 0)
+        p = "self_attn_layers.%d." % l
+        qk = query if pe is None else query + pe
+        o = _mha(qk, qk, query, g(p + "attn.in_proj_weight"), g(p + "attn.in_proj_bias"),
+                 g(p + "attn.out_proj.weight"), g(p + "attn.out_proj.bias"), nhead)
+        query = ln(o + query, p + "norm")
+        p = "ffn_layers.%d." % l
+        o = F.linear(F.relu(F.linear(query, g(p + "net.0.weight"), g(p + "net.0.bias"))), g(p + "net.3.weight"), g(p + "net.3.bias"))
+        query = ln(o + query, p + "norm")
+        if iter_pred:
+            o = head(query)
+            outs.append(o)
+            amasks = o[4]
+    if not iter_pred:
+        outs.append(head(query))
+    labels, scores, masks, paras, _ = outs[-1]
+    res = {"labels": labels, "scores": scores, "masks": masks, "parameters": paras}
+    if iter_pred:
+        res["aux_outputs"] = [{"labels": a[0], "scores": a[1], "masks": a[2], "parameters": a[3]} for a in outs[:-1]]
+    return res

@@ -1,0 +1,34 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return np.load(os.path.join(ROOT, "tests", "golden", "dgcnn_golden.npz"))
+
+
+@pytest.fixture(scope="session")
+def att_golden():
+    return np.load(os.path.join(ROOT, "tests", "golden", "attention_golden.npz"))
+
+
+@pytest.fixture(scope="session")
+def dev():
+    """cuda:0; GPU tests FAIL (not skip) when the HIP library is missing on a GPU box."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU in this container")
+    from gcanet_amd import _lib
+    _lib.lib()  # raises if libgcanet_hip.so is absent -> loud failure, no silent fallback
+    return torch.device("cuda:0")
