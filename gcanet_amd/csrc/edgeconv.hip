@@ -1,0 +1,522 @@
+// edgeconv.hip -- fused DGCNN EdgeConv block for gfx950: neighbour gather -> grouped
+// (N*k, 2C) x (2C, Cout) contraction on MFMA -> per-point max/min over k + GroupNorm
+// statistics, without ever materialising the (B,2C,N,k) edge tensor or the (B,Cout,N,k)
+// activation (reference: get_graph_feature M4:93-124 + Conv2d 1x1 + GroupNorm + LeakyReLU +
+// max, models/dgcnn-hais-concat-direct-4.py:463-505; its edge tensor alone is 4.3 GB at
+// B=8, N=8192, k=64, C=128).
+//
+// Formulation.  The reference's row is e = [x_j - x_i ; x_i] with weight W = [W1 | W2].  The
+// kernel contracts the SAME (N*k, 2C) row count against the re-parameterised weight
+// W' = [W1 | W2 - W1] with rows a = [x_j ; x_i]:  W.e == W'.a in exact arithmetic.  That
+// keeps the full grouped contraction on the matrix cores while making the A operand a pure
+// row gather (no VALU work per element), so rows go HBM/L2 -> LDS by LDS-DMA.
+//
+// Monotonicity.  y -> LeakyReLU(gamma*(y-mu)*rstd+beta) is monotone in y, so
+// max_k f(y_k) = f(max_k y_k) for gamma >= 0 and f(min_k y_k) for gamma < 0: the kernel keeps
+// per-(point, channel) max and min of the RAW conv output plus per-(cloud, group) sum and
+// sum of squares; gcn_edgeconv_finish applies GroupNorm + LeakyReLU to the routed extreme.
+//
+// bf16 kernel geometry (wave64, MFMA 32x32x16 bf16):
+//   tile      = TP points x kp rows (kp = k rounded up to 32; padded slots repeat neighbour 0,
+//               which cannot change max/min and is masked out of the sums)
+//   wave tile = 64 rows x 64 cols (2x2 MFMA blocks); B fragments (W') live in REGISTERS for
+//               the whole kernel, so the LDS only streams A
+//   A in LDS  = [rows][Cp] bf16, 16-B chunks XOR-swizzled (on the DMA *source* side) so the
+//               ds_read_b128 fragment reads are bank-conflict-free; double buffered: tile
+//               t+1 is gathered by global_load_lds_dwordx4 while tile t is on the MFMAs
+//   centre rows x_i are staged once per point and read as LDS broadcasts.
+#include "common.h"
+
+namespace gcn {
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
+  // round-to-nearest-even; NaN stays NaN (plain cast lowers to v_cvt_pk_bf16_f32)
+  __bf16 h = (__bf16)f;
+  return __builtin_bit_cast(unsigned short, h);
+}
+
+// ------------------------------------------------------------------ operand packing
+// x (B,C,N) f32 channel-major -> x_bf (B,N,Cp) bf16 zero padded and/or x_f32 (B,N,C)
+__global__ __launch_bounds__(256) void pack_x_kernel(const float *__restrict__ x, int C, int N, int Cp,
+                                                     unsigned short *__restrict__ x_bf, float *__restrict__ x_f32) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z;
+  const int n0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, n = n0 + tx;
+    tile[i][tx] = (c < C && n < N) ? x[((long)b * C + c) * N + n] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int n = n0 + i, c = c0 + tx;
+    if (n < N) {
+      const float v = tile[tx][i];
+      if (x_bf && c < Cp) x_bf[((long)b * N + n) * Cp + c] = f32_to_bf16(v);
+      if (x_f32 && c < C) x_f32[((long)b * N + n) * C + c] = v;
+    }
+  }
+}
+
+// w (Cout, 2C) f32 -> wp (Cout, 2Cp) bf16 = [W1 | 0 | W2 - W1 | 0]
+__global__ void pack_w_kernel(const float *__restrict__ w, int Cout, int C, int Cp, unsigned short *__restrict__ wp) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Cout * 2 * Cp) return;
+  const int co = i / (2 * Cp), kk = i % (2 * Cp);
+  float v = 0.f;
+  if (kk < C) v = w[(long)co * 2 * C + kk];
+  else if (kk >= Cp && kk < Cp + C) v = w[(long)co * 2 * C + C + (kk - Cp)] - w[(long)co * 2 * C + (kk - Cp)];
+  wp[i] = f32_to_bf16(v);
+}
+
+// ------------------------------------------------------------------ fused forward (bf16 MFMA)
+struct EcArgs {
+  const unsigned short *x;  // (B,N,Cp) bf16
+  const unsigned short *wp; // (Cout, 2Cp) bf16
+  const int64_t *idx;       // (B,N,k)
+  int B, N, k, kp, Cout, G, TP;
+  int tiles_per_cloud, total_tiles;
+  float *ymax, *ymin;       // (B,N,Cout)
+  unsigned char *amax, *amin;
+  double *gsum;             // (B,G,2)
+};
+
+// KSTEPS = 2*Cp/16 (= Cp/8 = 16-B chunks per row), CW = Cout/32 column groups,
+// RWT = 128-row groups per tile; block = 64*RWT*CW threads.  A wave owns 128 rows x 32 cols
+// (4 MFMA blocks): 64 VGPRs of B fragments + 64 accumulators, so two waves fit per SIMD.
+template <int KSTEPS, int CW, int RWT, bool WITH_ARG>
+__global__ __launch_bounds__(64 * RWT * CW) void edgeconv_fwd_bf16_kernel(EcArgs a) {
+  constexpr int NC = KSTEPS;               // chunks per x row
+  constexpr int CP = KSTEPS * 8;           // padded channels
+  constexpr int K = 2 * CP;
+  constexpr int ROW_BYTES = CP * 2;
+  constexpr int TILE_ROWS = RWT * 128;
+  constexpr int NW = RWT * CW;
+  constexpr int COUT = CW * 32;
+  constexpr int RPP = 64 / NC;             // rows per 1-KiB DMA piece
+  constexpr int PIECES = TILE_ROWS / RPP;
+  constexpr int PPW = (PIECES + NW - 1) / NW;
+  constexpr int RPB = NC >= 16 ? 1 : 16 / NC;  // rows per 256-B bank row
+  constexpr int A_BYTES = TILE_ROWS * ROW_BYTES;
+  constexpr int MAXTP = TILE_ROWS / 32;
+  constexpr int C_BYTES = ((MAXTP * ROW_BYTES + 1023) / 1024) * 1024;
+  constexpr int CPIECES = C_BYTES / 1024;
+  constexpr int BUF_BYTES = A_BYTES + C_BYTES;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+
+  const int lane = lane_id();
+  const int wave = wave_id();
+  const int rg = wave / CW, cg = wave % CW;
+  const int lr = lane & 31, lh = lane >> 5;
+
+  // ---- B fragments (W') in registers for the whole kernel
+  bf16x8 breg[KSTEPS];
+#pragma unroll
+  for (int s = 0; s < KSTEPS; ++s)
+    breg[s] = *reinterpret_cast<const bf16x8 *>(a.wp + (long)(cg * 32 + lr) * K + s * 16 + lh * 8);
+
+  const int G = gridDim.x;
+  const int t_begin = (int)((long)blockIdx.x * a.total_tiles / G);
+  const int t_end = (int)((long)(blockIdx.x + 1) * a.total_tiles / G);
+  if (t_begin >= t_end) return;
+
+  const int kp = a.kp, k = a.k, TP = a.TP;
+  const int rows_used = TP * kp;
+
+  // issue the LDS-DMA gather of tile t into buffer `buf`
+  auto issue_gather = [&](int t, int buf) {
+    const int b = t / a.tiles_per_cloud;
+    const int n0 = (t % a.tiles_per_cloud) * TP;
+    unsigned char *abuf = lds + buf * BUF_BYTES;
+    const unsigned short *xb = a.x + (long)b * a.N * CP;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int p = wave + i * NW;
+      if (p < PIECES && p * RPP < rows_used) {
+        const int row = p * RPP + lane / NC;
+        const int cs = lane % NC;                       // physical chunk slot
+        const int c = cs ^ ((row / RPB) & (NC - 1));    // logical chunk (swizzle on the source side)
+        int pt = row / kp, j = row % kp;
+        if (j >= k) j = 0;
+        int n = n0 + pt;
+        if (n >= a.N) n = a.N - 1;
+        const long g = a.idx[((long)b * a.N + n) * k + j];
+        const unsigned short *src = xb + g * CP + c * 8;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)(abuf + p * 1024), 16, 0, 0);
+      }
+    }
+    // centre rows of the tile's points (linear, no swizzle)
+    for (int p = wave; p < CPIECES; p += NW) {
+      const int row = p * RPP + lane / NC;
+      int n = n0 + (row < TP ? row : 0);
+      if (n >= a.N) n = a.N - 1;
+      const unsigned short *src = xb + (long)n * CP + (lane % NC) * 8;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                       (__attribute__((address_space(3))) void *)(abuf + A_BYTES + p * 1024), 16, 0, 0);
+    }
+  };
+
+  float s1 = 0.f, s2 = 0.f;
+  int cur_b = t_begin / a.tiles_per_cloud;
+  const int cpg = a.Cout / a.G;  // channels per group (multiple of 32 -> a column block is in one group)
+
+  auto flush_stats = [&](int b) {
+    double d1 = (double)s1, d2 = (double)s2;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      d1 += __shfl_xor(d1, o);
+      d2 += __shfl_xor(d2, o);
+    }
+    if (lane == 0) {
+      const int g = (cg * 32) / cpg;
+      atomicAdd(a.gsum + ((long)b * a.G + g) * 2, d1);
+      atomicAdd(a.gsum + ((long)b * a.G + g) * 2 + 1, d2);
+    }
+    s1 = 0.f;
+    s2 = 0.f;
+  };
+
+  issue_gather(t_begin, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int t = t_begin; t < t_end; ++t) {
+    const int buf = (t - t_begin) & 1;
+    const int b = t / a.tiles_per_cloud;
+    const int n0 = (t % a.tiles_per_cloud) * TP;
+    if (b != cur_b) {
+      flush_stats(cur_b);
+      cur_b = b;
+    }
+    if (t + 1 < t_end) issue_gather(t + 1, buf ^ 1);
+
+    unsigned char *abuf = lds + buf * BUF_BYTES;
+    const unsigned char *cbuf = abuf + A_BYTES;
+    const bool active = rg * 128 < rows_used;  // wave-uniform
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[rb][i] = 0.f;
+
+    if (active) {
+      int arow[4], aswz[4], cpt[4];
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) {
+        const int row = rg * 128 + rb * 32 + lr;
+        arow[rb] = row * ROW_BYTES;
+        aswz[rb] = (row / RPB) & (NC - 1);
+        cpt[rb] = (row / kp) * ROW_BYTES;
+      }
+#pragma unroll
+      for (int s = 0; s < KSTEPS; ++s) {
+        const int gc = 2 * s + lh;  // global 16-B chunk of the [x_j ; x_i] row
+        bf16x8 af[4];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+          const unsigned char *p = gc < NC ? abuf + arow[rb] + ((gc ^ aswz[rb]) << 4)
+                                           : cbuf + cpt[rb] + ((gc - NC) << 4);
+          af[rb] = *reinterpret_cast<const bf16x8 *>(p);
+        }
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+          acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rb], breg[s], acc[rb], 0, 0, 0);
+      }
+    }
+    // ---- per 32-row block: max / min (/ arg) over rows per column, sums for GroupNorm
+    float *pmax = reinterpret_cast<float *>(lds + 2 * BUF_BYTES);  // [blocks][Cout], own LDS region
+    float *pmin = pmax + (TILE_ROWS / 32) * COUT;
+    int *pamax = reinterpret_cast<int *>(pmin + (TILE_ROWS / 32) * COUT);
+    int *pamin = pamax + (TILE_ROWS / 32) * COUT;
+    if (active) {
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) {
+        const int blk = rg * 4 + rb;
+        if (blk * 32 >= rows_used) break;            // wave-uniform: block beyond the tile's points
+        if (n0 + (blk * 32) / kp >= a.N) break;      // tail tile: point past the end of the cloud
+        const int rbase = (blk * 32) % kp + 4 * lh;  // point-row of register 0 (kp % 32 == 0)
+        {
+          float mx = acc[rb][0], mn = acc[rb][0];
+#pragma unroll
+          for (int i = 1; i < 16; ++i) {
+            mx = fmaxf(mx, acc[rb][i]);
+            mn = fminf(mn, acc[rb][i]);
+          }
+          float ps = 0.f, pq = 0.f;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int rr = rbase + (i & 3) + 8 * (i >> 2);
+            const float v = (kp == k || rr < k) ? acc[rb][i] : 0.f;
+            ps += v;
+            pq = fmaf(v, v, pq);
+          }
+          s1 += ps;
+          s2 += pq;
+          int ax = 0x7fffffff, an = 0x7fffffff;
+          if (WITH_ARG) {
+            // the point-row of register i grows with i, so the lowest row is the lowest i
+            int ix = 0, in_ = 0;
+#pragma unroll
+            for (int i = 15; i >= 0; --i) {
+              ix = acc[rb][i] == mx ? i : ix;
+              in_ = acc[rb][i] == mn ? i : in_;
+            }
+            ax = rbase + (ix & 3) + 8 * (ix >> 2);
+            an = rbase + (in_ & 3) + 8 * (in_ >> 2);
+          }
+          // combine the two half-waves (rows 4h..)
+          const float mx2 = __shfl_xor(mx, 32), mn2 = __shfl_xor(mn, 32);
+          if (WITH_ARG) {
+            const int ax2 = __shfl_xor(ax, 32), an2 = __shfl_xor(an, 32);
+            ax = mx2 > mx ? ax2 : (mx2 == mx ? min(ax, ax2) : ax);
+            an = mn2 < mn ? an2 : (mn2 == mn ? min(an, an2) : an);
+          }
+          mx = fmaxf(mx, mx2);
+          mn = fminf(mn, mn2);
+          if (lh == 0) {
+            const int o = blk * COUT + cg * 32 + lr;
+            pmax[o] = mx;
+            pmin[o] = mn;
+            if (WITH_ARG) {
+              pamax[o] = ax;
+              pamin[o] = an;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- combine the kp/32 blocks of each point, write (B,N,Cout)
+    {
+      const int nb = kp / 32;
+      const int Cout = COUT;
+      for (int e = threadIdx.x; e < TP * Cout; e += 64 * NW) {
+        const int pt = e / Cout, col = e % Cout;
+        const int n = n0 + pt;
+        if (n >= a.N) continue;
+        float mx = -__builtin_inff(), mn = __builtin_inff();
+        int ax = 0, an = 0;
+        for (int q = 0; q < nb; ++q) {
+          const int o = (pt * nb + q) * Cout + col;
+          const float v1 = pmax[o], v2 = pmin[o];
+          if (WITH_ARG) {
+            if (v1 > mx) ax = pamax[o];   // blocks ascend in point-row, strict > keeps the lowest row
+            if (v2 < mn) an = pamin[o];
+          }
+          mx = fmaxf(mx, v1);
+          mn = fminf(mn, v2);
+        }
+        const long o = ((long)b * a.N + n) * Cout + col;
+        a.ymax[o] = mx;
+        a.ymin[o] = mn;
+        if (WITH_ARG) {
+          a.amax[o] = (unsigned char)ax;
+          a.amin[o] = (unsigned char)an;
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // next tile's DMA has landed
+    __syncthreads();
+  }
+  flush_stats(cur_b);
+}
+
+// ------------------------------------------------------------------ fp32 exact path (VALU)
+// Literal reference arithmetic: y = sum_c W[co][c]*(x_j[c]-x_i[c]) + sum_c W[co][C+c]*x_i[c],
+// one k-ordered fmaf chain (bit-exact vs oracle).  One workgroup per point, one thread per
+// output channel; the k edge rows are staged in LDS.  Parity path, not the fast path.
+__global__ __launch_bounds__(256) void edgeconv_fwd_f32_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                               const int64_t *__restrict__ idx, int N, int C, int k,
+                                                               int Cout, int G, float *__restrict__ ymax,
+                                                               float *__restrict__ ymin, unsigned char *__restrict__ amax,
+                                                               unsigned char *__restrict__ amin, double *__restrict__ gsum) {
+  extern __shared__ float e[];  // [k][2C] edge rows, then [Cout] scratch for sums
+  const int n = blockIdx.x, b = blockIdx.y;
+  const float *xb = x + (long)b * N * C;
+  const float *xi = xb + (long)n * C;
+  for (int t = threadIdx.x; t < k * C; t += blockDim.x) {
+    const int j = t / C, c = t % C;
+    const long g = idx[((long)b * N + n) * k + j];
+    const float ctr = xi[c];
+    e[j * 2 * C + c] = xb[g * C + c] - ctr;
+    e[j * 2 * C + C + c] = ctr;
+  }
+  __syncthreads();
+  double *gs = reinterpret_cast<double *>(e + (size_t)k * 2 * C + ((k * 2 * C) & 1));
+  for (int co = threadIdx.x; co < Cout; co += blockDim.x) {
+    const float *wr = w + (long)co * 2 * C;
+    float mx = -__builtin_inff(), mn = __builtin_inff();
+    int ax = 0, an = 0;
+    double s1 = 0.0, s2 = 0.0;
+    for (int j = 0; j < k; ++j) {
+      float y = 0.f;
+      for (int c = 0; c < 2 * C; ++c) y = fmaf(wr[c], e[j * 2 * C + c], y);
+      if (y > mx) { mx = y; ax = j; }
+      if (y < mn) { mn = y; an = j; }
+      s1 += (double)y;
+      s2 += (double)y * (double)y;
+    }
+    const long o = ((long)b * N + n) * Cout + co;
+    ymax[o] = mx; ymin[o] = mn;
+    if (amax) { amax[o] = (unsigned char)ax; amin[o] = (unsigned char)an; }
+    gs[co * 2] = s1; gs[co * 2 + 1] = s2;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < G * 2) {
+    const int g = threadIdx.x >> 1, which = threadIdx.x & 1;
+    const int cpg = Cout / G;
+    double t = 0.0;
+    for (int co = g * cpg; co < (g + 1) * cpg; ++co) t += gs[co * 2 + which];
+    atomicAdd(gsum + ((long)b * G + g) * 2 + which, t);
+  }
+}
+
+// ------------------------------------------------------------------ GroupNorm + LeakyReLU on the routed extreme
+__global__ __launch_bounds__(256) void edgeconv_finish_kernel(const float *__restrict__ ymax, const float *__restrict__ ymin,
+                                                              const double *__restrict__ gsum, const float *__restrict__ gamma,
+                                                              const float *__restrict__ beta, int N, int k, int Cout, int G,
+                                                              float eps, float slope, float *__restrict__ out_cm,
+                                                              float *__restrict__ out_pm, float *__restrict__ mean_rstd) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z;
+  const int n0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int cpg = Cout / G;
+  const double cnt = (double)cpg * N * k;
+  for (int i = ty; i < 32; i += 8) {
+    const int n = n0 + i, c = c0 + tx;
+    float v = 0.f;
+    if (n < N && c < Cout) {
+      const int g = c / cpg;
+      const double m = gsum[((long)b * G + g) * 2] / cnt;
+      double var = gsum[((long)b * G + g) * 2 + 1] / cnt - m * m;
+      if (var < 0.0) var = 0.0;
+      const float mean = (float)m, rstd = (float)(1.0 / sqrt(var + (double)eps));
+      const float ga = gamma[c];
+      const long o = ((long)b * N + n) * Cout + c;
+      const float y = ga >= 0.f ? ymax[o] : ymin[o];
+      const float z = (y - mean) * rstd * ga + beta[c];
+      v = z > 0.f ? z : z * slope;
+      if (out_pm) out_pm[o] = v;
+      if (mean_rstd && n == 0 && (c % cpg) == 0) {
+        mean_rstd[((long)b * G + g) * 2] = mean;
+        mean_rstd[((long)b * G + g) * 2 + 1] = rstd;
+      }
+    }
+    tile[i][tx] = v;
+  }
+  __syncthreads();
+  if (out_cm) {
+    for (int i = ty; i < 32; i += 8) {
+      const int c = c0 + i, n = n0 + tx;
+      if (c < Cout && n < N) out_cm[((long)b * Cout + c) * N + n] = tile[tx][i];
+    }
+  }
+}
+
+template <int KSTEPS, int CW, int RWT>
+static int launch_fwd_bf16(EcArgs &a, bool with_arg, hipStream_t st) {
+  constexpr int CP = KSTEPS * 8;
+  constexpr int TILE_ROWS = RWT * 128;
+  constexpr int A_BYTES = TILE_ROWS * CP * 2;
+  constexpr int C_BYTES = (((TILE_ROWS / 32) * CP * 2 + 1023) / 1024) * 1024;
+  constexpr int PART_BYTES = (TILE_ROWS / 32) * CW * 32 * 16;
+  constexpr int BUF_BYTES = A_BYTES + C_BYTES;
+  const int lds_bytes = 2 * BUF_BYTES + PART_BYTES;
+  static_assert(2 * BUF_BYTES + PART_BYTES <= 160 * 1024, "LDS budget");
+  a.TP = TILE_ROWS / a.kp;
+  if (a.TP < 1) {
+    set_error("gcn_edgeconv_fwd: k=%d needs %d rows per point > tile of %d rows", a.k, a.kp, TILE_ROWS);
+    return GCN_EINVAL;
+  }
+  a.tiles_per_cloud = (a.N + a.TP - 1) / a.TP;
+  a.total_tiles = a.B * a.tiles_per_cloud;
+  int grid = a.total_tiles < 256 ? a.total_tiles : 256;
+  auto kern = with_arg ? edgeconv_fwd_bf16_kernel<KSTEPS, CW, RWT, true> : edgeconv_fwd_bf16_kernel<KSTEPS, CW, RWT, false>;
+  GCN_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+  kern<<<grid, 64 * RWT * CW, lds_bytes, st>>>(a);
+  return check_launch("edgeconv_fwd_bf16_kernel");
+}
+
+}  // namespace gcn
+
+using namespace gcn;
+
+static int padded_channels(int C) {
+  int cp = 8;
+  while (cp < C) cp <<= 1;
+  return cp;
+}
+
+GCN_EXPORT int gcn_edgeconv_padded_channels(int C) { return padded_channels(C); }
+
+GCN_EXPORT int gcn_edgeconv_pack_x(const float *x_cm, int B, int C, int N, void *x_pm_bf16, float *x_pm_f32, void *stream) {
+  GCN_REQUIRE(x_cm && (x_pm_bf16 || x_pm_f32), "gcn_edgeconv_pack_x: null pointer");
+  GCN_REQUIRE(B >= 0 && C >= 1 && N >= 1, "gcn_edgeconv_pack_x: bad shape");
+  if (B == 0) return GCN_OK;
+  const int Cp = padded_channels(C);
+  pack_x_kernel<<<dim3(cdiv(N, 32), cdiv(Cp, 32), B), 256, 0, (hipStream_t)stream>>>(x_cm, C, N, Cp, (unsigned short *)x_pm_bf16, x_pm_f32);
+  return check_launch("pack_x_kernel");
+}
+
+GCN_EXPORT int gcn_edgeconv_pack_w(const float *w, int Cout, int C, void *wp_bf16, void *stream) {
+  GCN_REQUIRE(w && wp_bf16, "gcn_edgeconv_pack_w: null pointer");
+  GCN_REQUIRE(Cout >= 1 && C >= 1, "gcn_edgeconv_pack_w: bad shape");
+  const int Cp = padded_channels(C);
+  pack_w_kernel<<<cdiv((long)Cout * 2 * Cp, 256), 256, 0, (hipStream_t)stream>>>(w, Cout, C, Cp, (unsigned short *)wp_bf16);
+  return check_launch("pack_w_kernel");
+}
+
+GCN_EXPORT int gcn_edgeconv_fwd(const void *x_pm, const void *w, const int64_t *idx, int dtype, int B, int N, int C,
+                                int k, int Cout, int G, float *ymax, float *ymin, uint8_t *amax, uint8_t *amin,
+                                double *gsum, void *stream) {
+  GCN_REQUIRE(x_pm && w && idx && ymax && ymin && gsum, "gcn_edgeconv_fwd: null pointer");
+  GCN_REQUIRE((amax == nullptr) == (amin == nullptr), "gcn_edgeconv_fwd: pass both amax and amin or neither");
+  GCN_REQUIRE(dtype == 0 || dtype == 1, "gcn_edgeconv_fwd: dtype must be 0 (f32) or 1 (bf16)");
+  GCN_REQUIRE(B >= 0 && N >= 1 && C >= 1 && k >= 1 && k <= 255, "gcn_edgeconv_fwd: bad shape (need 1 <= k <= 255)");
+  GCN_REQUIRE(G >= 1 && Cout % G == 0, "gcn_edgeconv_fwd: Cout=%d not divisible by G=%d", Cout, G);
+  if (B == 0) return GCN_OK;
+  hipStream_t st = (hipStream_t)stream;
+  GCN_HIP(hipMemsetAsync(gsum, 0, sizeof(double) * 2 * B * G, st));
+  if (dtype == 0) {
+    const size_t lds = sizeof(float) * ((size_t)k * 2 * C + 2) + sizeof(double) * 2 * Cout;
+    GCN_REQUIRE(lds <= 150 * 1024, "gcn_edgeconv_fwd(f32): k*2C too large for the exact path (%zu B LDS)", lds);
+    GCN_HIP(hipFuncSetAttribute((const void *)edgeconv_fwd_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    edgeconv_fwd_f32_kernel<<<dim3(N, B), 256, lds, st>>>((const float *)x_pm, (const float *)w, idx, N, C, k, Cout, G,
+                                                          ymax, ymin, amax, amin, gsum);
+    return check_launch("edgeconv_fwd_f32_kernel");
+  }
+  GCN_REQUIRE(Cout == 64 || Cout == 128, "gcn_edgeconv_fwd(bf16): Cout must be 64 or 128, got %d", Cout);
+  GCN_REQUIRE((Cout / G) % 32 == 0, "gcn_edgeconv_fwd(bf16): Cout/G must be a multiple of 32");
+  const int Cp = padded_channels(C);
+  GCN_REQUIRE(Cp <= 128, "gcn_edgeconv_fwd(bf16): C=%d > 128 unsupported", C);
+  EcArgs a{};
+  a.x = (const unsigned short *)x_pm; a.wp = (const unsigned short *)w; a.idx = idx;
+  a.B = B; a.N = N; a.k = k; a.kp = (k + 31) / 32 * 32; a.Cout = Cout; a.G = G;
+  a.ymax = ymax; a.ymin = ymin; a.amax = amax; a.amin = amin; a.gsum = gsum;
+  const bool wa = amax != nullptr;
+  const int ks = Cp / 8;
+#define EC_CASE(KS, CWV, RWTV) if (ks == KS && Cout == CWV * 32) return launch_fwd_bf16<KS, CWV, RWTV>(a, wa, st);
+  EC_CASE(1, 2, 4) EC_CASE(2, 2, 4) EC_CASE(4, 2, 4) EC_CASE(8, 2, 4) EC_CASE(16, 2, 2)
+  EC_CASE(1, 4, 2) EC_CASE(2, 4, 2) EC_CASE(4, 4, 2) EC_CASE(8, 4, 2) EC_CASE(16, 4, 2)
+#undef EC_CASE
+  set_error("gcn_edgeconv_fwd(bf16): unsupported configuration");
+  return GCN_EINVAL;
+}
+
+GCN_EXPORT int gcn_edgeconv_finish(const float *ymax, const float *ymin, const double *gsum, const float *gamma,
+                                   const float *beta, int B, int N, int k, int Cout, int G, float eps, float slope,
+                                   float *out_cm, float *out_pm, float *mean_rstd, void *stream) {
+  GCN_REQUIRE(ymax && ymin && gsum && gamma && beta && (out_cm || out_pm), "gcn_edgeconv_finish: null pointer");
+  GCN_REQUIRE(B >= 0 && N >= 1 && k >= 1 && G >= 1 && Cout % G == 0, "gcn_edgeconv_finish: bad shape");
+  if (B == 0) return GCN_OK;
+  edgeconv_finish_kernel<<<dim3(cdiv(N, 32), cdiv(Cout, 32), B), 256, 0, (hipStream_t)stream>>>(
+      ymax, ymin, gsum, gamma, beta, N, k, Cout, G, eps, slope, out_cm, out_pm, mean_rstd);
+  return check_launch("edgeconv_finish_kernel");
+}

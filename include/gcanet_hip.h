@@ -188,6 +188,39 @@ int gcn_hierarchical_aggregation_host(const int32_t *semantic_label_host, const 
                                       int32_t *cluster_idxs_host, int32_t *cluster_offsets_host,
                                       int *sumNPoint, int *nCluster);
 
+/* ------------------------------------------------- fused EdgeConv (DGCNN) ------ */
+
+/* Fused replacement of get_graph_feature / get_graph_feature_with_normals (M4:93-161) +
+ * Conv2d 1x1 (no bias) + the statistics/extreme half of GroupNorm + LeakyReLU + max over k
+ * (M4:463-505).  The grouped (N*k, 2C) x (2C, Cout) contraction runs on MFMA (dtype 1, bf16
+ * operands, f32 accumulate) or as an exact k-ordered f32 fmaf chain (dtype 0, parity path).
+ * Operands are point-major so that one neighbour is one contiguous row:
+ *   dtype 1: x_pm (B,N,Cp) bf16 and w = W' (Cout,2Cp) bf16 from gcn_edgeconv_pack_x / _pack_w,
+ *            Cp = gcn_edgeconv_padded_channels(C); Cout in {64,128}, C <= 128, (Cout/G) % 32 == 0
+ *   dtype 0: x_pm (B,N,C) f32, w (Cout,2C) f32 (the reference's own Conv2d weight)
+ *   idx    (B,N,k) int64 neighbour ids within the cloud (what knn()/topk returns), 1 <= k <= 255
+ *   ymax, ymin (B,N,Cout) f32: max / min over the k neighbours of the RAW conv output
+ *   amax, amin (B,N,Cout) u8 or both NULL: neighbour slot attaining it (lowest slot on ties)
+ *   gsum   (B,G,2) f64: per-(cloud, group) sum and sum of squares of the raw conv output over
+ *          all N*k*(Cout/G) elements (zeroed by the call).
+ * y -> LeakyReLU(gamma*(y-mu)*rstd+beta) is monotone, so max_k f(y_k) = f(max_k y_k) for
+ * gamma >= 0 and f(min_k y_k) for gamma < 0, bitwise; gcn_edgeconv_finish applies it. */
+int gcn_edgeconv_padded_channels(int C);
+int gcn_edgeconv_pack_x(const float *x_cm, int B, int C, int N, void *x_pm_bf16, float *x_pm_f32,
+                        void *stream);
+int gcn_edgeconv_pack_w(const float *w, int Cout, int C, void *wp_bf16, void *stream);
+int gcn_edgeconv_fwd(const void *x_pm, const void *w, const int64_t *idx, int dtype, int B, int N,
+                     int C, int k, int Cout, int G, float *ymax, float *ymin, uint8_t *amax,
+                     uint8_t *amin, double *gsum, void *stream);
+
+/* GroupNorm(G, Cout, eps) + LeakyReLU(slope) on the routed extreme:
+ *   out_cm (B,Cout,N) f32 (the reference's layout) and/or out_pm (B,N,Cout); either may be NULL
+ *   mean_rstd (B,G,2) f32 (may be NULL): statistics for backward. */
+int gcn_edgeconv_finish(const float *ymax, const float *ymin, const double *gsum,
+                        const float *gamma, const float *beta, int B, int N, int k, int Cout,
+                        int G, float eps, float slope, float *out_cm, float *out_pm,
+                        float *mean_rstd, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

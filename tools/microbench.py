@@ -1,0 +1,54 @@
+"""Per-op timings on one GPU (development aid; bench.py is the judged entry point)."""
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, ".")
+from gcanet_amd import dgcnn  # noqa: E402
+from gcanet_amd.knn_cuda import KNN  # noqa: E402
+from gcanet_amd.pointnet2_ops import pointnet2_utils as P2  # noqa: E402
+
+
+def timeit(fn, n=10, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def main():
+    dev = torch.device("cuda:0")
+    B, N, k = 8, 8192, 64
+    g = torch.Generator().manual_seed(0)
+    for C in (3, 6, 64, 128):
+        x = torch.rand(B, C, N, generator=g).to(dev)
+        if C == 6:
+            ms = timeit(lambda: dgcnn.knn_points_normals(x, k, k))
+            tag = "knn_points_normals"
+        else:
+            ms = timeit(lambda: dgcnn.knn(x, k, k))
+            tag = "knn"
+        print("%-20s C=%3d B=%d N=%d k=%d : %8.3f ms  %8.2f Mpts/s" % (tag, C, B, N, k, ms, B * N / ms / 1e3))
+    x = torch.rand(B, 3, N, generator=g).to(dev)
+    ms = timeit(lambda: KNN(k)(x, x))
+    print("%-20s C=%3d : %8.3f ms  %8.2f Mpts/s" % ("KNN_CUDA", 3, ms, B * N / ms / 1e3))
+    f = torch.rand(B, 128, N, generator=g).to(dev).requires_grad_()
+    idx = dgcnn.knn(x, k, k).int().contiguous()
+    ms = timeit(lambda: P2.grouping_operation(f, idx))
+    byt = 4 * B * 128 * N + 4 * B * N * k + 4 * B * 128 * N * k
+    print("grouping_operation fwd: %8.3f ms  %7.1f GB/s (alg bytes %.3f GB)" % (ms, byt / ms / 1e6, byt / 1e9))
+    out = P2.grouping_operation(f, idx)
+    go = torch.rand_like(out)
+    ms = timeit(lambda: torch.autograd.grad(out, f, go, retain_graph=True))
+    print("grouping_operation bwd: %8.3f ms  %7.1f GB/s" % (ms, byt / ms / 1e6))
+
+
+if __name__ == "__main__":
+    main()
