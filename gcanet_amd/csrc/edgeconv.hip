@@ -420,6 +420,46 @@ __global__ __launch_bounds__(256) void edgeconv_finish_kernel(const float *__res
   }
 }
 
+
+// ------------------------------------------------------------------ graph aggregations for backward
+// s[n] = sum_j x[idx[n,j]]  (neighbour sum, gather) ; one wave per point, lanes across channels
+__global__ __launch_bounds__(256) void neighbor_sum_kernel(const float *__restrict__ x, const int64_t *__restrict__ idx,
+                                                           int N, int C, int k, float *__restrict__ s) {
+  const int lane = lane_id();
+  const int n = blockIdx.x * 4 + wave_id(), b = blockIdx.y;
+  if (n >= N) return;
+  const float *xb = x + (long)b * N * C;
+  const int64_t *ip = idx + ((long)b * N + n) * k;
+  for (int c0 = 0; c0 < C; c0 += 64) {
+    const int c = c0 + lane;
+    float acc = 0.f;
+    if (c < C) {
+      for (int j = 0; j < k; ++j) acc += xb[ip[j] * C + c];
+      s[((long)b * N + n) * C + c] = acc;
+    }
+  }
+}
+
+// r[m] = sum_{(n,j): idx[n,j]=m} x[n]  and indeg[m]  (scatter; 256-B contiguous f32 atomics per row)
+__global__ __launch_bounds__(256) void reverse_sum_kernel(const float *__restrict__ x, const int64_t *__restrict__ idx,
+                                                          int N, int C, int k, float *__restrict__ r,
+                                                          float *__restrict__ indeg) {
+  const int lane = lane_id();
+  const int n = blockIdx.x * 4 + wave_id(), b = blockIdx.y;
+  if (n >= N) return;
+  const float *xr = x + ((long)b * N + n) * C;
+  const int64_t *ip = idx + ((long)b * N + n) * k;
+  for (int c0 = 0; c0 < C; c0 += 64) {
+    const int c = c0 + lane;
+    if (c < C) {
+      const float v = xr[c];
+      for (int j = 0; j < k; ++j) atomicAdd(r + ((long)b * N + ip[j]) * C + c, v);
+    }
+  }
+  if (indeg)
+    for (int j = lane; j < k; j += 64) atomicAdd(indeg + (long)b * N + ip[j], 1.f);
+}
+
 template <int KSTEPS, int CW, int RWT>
 static int launch_fwd_bf16(EcArgs &a, bool with_arg, hipStream_t st) {
   constexpr int CP = KSTEPS * 8;
@@ -519,4 +559,24 @@ GCN_EXPORT int gcn_edgeconv_finish(const float *ymax, const float *ymin, const d
   edgeconv_finish_kernel<<<dim3(cdiv(N, 32), cdiv(Cout, 32), B), 256, 0, (hipStream_t)stream>>>(
       ymax, ymin, gsum, gamma, beta, N, k, Cout, G, eps, slope, out_cm, out_pm, mean_rstd);
   return check_launch("edgeconv_finish_kernel");
+}
+
+GCN_EXPORT int gcn_neighbor_sum(const float *x_pm, const int64_t *idx, int B, int N, int C, int k, float *s, void *stream) {
+  GCN_REQUIRE(x_pm && idx && s, "gcn_neighbor_sum: null pointer");
+  GCN_REQUIRE(B >= 0 && N >= 1 && C >= 1 && k >= 1, "gcn_neighbor_sum: bad shape");
+  if (B == 0) return GCN_OK;
+  neighbor_sum_kernel<<<dim3(cdiv(N, 4), B), 256, 0, (hipStream_t)stream>>>(x_pm, idx, N, C, k, s);
+  return check_launch("neighbor_sum_kernel");
+}
+
+GCN_EXPORT int gcn_reverse_sum(const float *x_pm, const int64_t *idx, int B, int N, int C, int k, float *r, float *indeg,
+                               void *stream) {
+  GCN_REQUIRE(x_pm && idx && r, "gcn_reverse_sum: null pointer");
+  GCN_REQUIRE(B >= 0 && N >= 1 && C >= 1 && k >= 1, "gcn_reverse_sum: bad shape");
+  if (B == 0) return GCN_OK;
+  hipStream_t st = (hipStream_t)stream;
+  GCN_HIP(hipMemsetAsync(r, 0, sizeof(float) * (size_t)B * N * C, st));
+  if (indeg) GCN_HIP(hipMemsetAsync(indeg, 0, sizeof(float) * (size_t)B * N, st));
+  reverse_sum_kernel<<<dim3(cdiv(N, 4), B), 256, 0, st>>>(x_pm, idx, N, C, k, r, indeg);
+  return check_launch("reverse_sum_kernel");
 }

@@ -221,6 +221,16 @@ int gcn_edgeconv_finish(const float *ymax, const float *ymin, const double *gsum
                         int G, float eps, float slope, float *out_cm, float *out_pm,
                         float *mean_rstd, void *stream);
 
+/* Graph aggregations used by the EdgeConv backward (no counterpart kernel in the reference: its
+ * autograd walks the materialised (B,2C,N,k) tensor).  x_pm (B,N,C) f32, idx (B,N,k) int64.
+ *   gcn_neighbor_sum: s[b,n,:] = sum_j x[b, idx[b,n,j], :]                      (gather)
+ *   gcn_reverse_sum : r[b,m,:] = sum_{(n,j): idx[b,n,j]==m} x[b,n,:], indeg[b,m] = #(n,j) (scatter;
+ *                     both outputs zeroed by the call; indeg (B,N) f32 may be NULL). */
+int gcn_neighbor_sum(const float *x_pm, const int64_t *idx, int B, int N, int C, int k, float *s,
+                     void *stream);
+int gcn_reverse_sum(const float *x_pm, const int64_t *idx, int B, int N, int C, int k, float *r,
+                    float *indeg, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -76,3 +76,44 @@ def test_edgeconv_forward_golden(dev, golden):
     t = lambda a: torch.from_numpy(a).to(dev)
     r = dgcnn.edgeconv_forward_raw(t(g["ec_x"]), t(g["ec_idx"]), t(g["ec_w"]), t(g["ec_gamma"]), t(g["ec_beta"]), 2, "f32")
     np.testing.assert_allclose(r["out"].cpu().numpy(), g["ec_y"], rtol=1e-4, atol=1e-4)
+
+
+def test_edgeconv_backward_golden(dev, golden):
+    """Gradients vs the reference's autograd through its own modules (golden section 3)."""
+    from gcanet_amd import dgcnn
+    g = golden
+    t = lambda a: torch.from_numpy(a).to(dev)
+    x, w = t(g["ec_x"]).requires_grad_(), t(g["ec_w"]).requires_grad_()
+    ga, be = t(g["ec_gamma"]).requires_grad_(), t(g["ec_beta"]).requires_grad_()
+    y = dgcnn.edge_conv(x, t(g["ec_idx"]), w, ga, be, 2, "f32")
+    np.testing.assert_allclose(y.detach().cpu().numpy(), g["ec_y"], rtol=1e-4, atol=1e-4)
+    (y * t(g["ec_gout"])).sum().backward()
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g["ec_dx"], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(w.grad.cpu().numpy(), g["ec_dw"], rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(ga.grad.cpu().numpy(), g["ec_dgamma"], rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(be.grad.cpu().numpy(), g["ec_dbeta"], rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("B,C,N,k,Cout,G", [(2, 64, 300, 20, 64, 2), (1, 128, 200, 64, 128, 2), (2, 6, 128, 16, 64, 2)])
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_edgeconv_backward_vs_oracle_autograd(dev, B, C, N, k, Cout, G, dtype):
+    from gcanet_amd import dgcnn
+    g = torch.Generator().manual_seed(7 + C + N)
+    x = torch.randn(B, C, N, generator=g)
+    idx = torch.stack([torch.stack([torch.randperm(N, generator=g)[:k] for _ in range(N)]) for _ in range(B)])
+    w = torch.randn(Cout, 2 * C, generator=g) / (2 * C) ** 0.5
+    gamma, beta = torch.randn(Cout, generator=g), torch.randn(Cout, generator=g) * 0.1
+    gout = torch.randn(B, Cout, N, generator=g)
+    if dtype == "bf16":   # feed both sides operands that are exactly representable in bf16
+        x = _bf16_round(x)
+        w1, wd = _bf16_round(w[:, :C]), _bf16_round(w[:, C:] - w[:, :C])
+        w = torch.cat([w1, wd + w1], 1)
+    leaves = [v.clone().requires_grad_() for v in (x, w, gamma, beta)]
+    R.edgeconv_block(leaves[0], idx, leaves[1], leaves[2], leaves[3], G).mul(gout).sum().backward()
+    dl = [v.clone().to(dev).requires_grad_() for v in (x, w, gamma, beta)]
+    y = dgcnn.edge_conv(dl[0], idx.to(dev), dl[1], dl[2], dl[3], G, dtype)
+    (y * gout.to(dev)).sum().backward()
+    for a, b, name in zip(dl, leaves, ("dx", "dw", "dgamma", "dbeta")):
+        ref = b.grad.numpy()
+        scale = np.abs(ref).max()
+        np.testing.assert_allclose(a.grad.cpu().numpy(), ref, rtol=2e-3, atol=2e-4 * scale, err_msg=name)

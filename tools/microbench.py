@@ -50,5 +50,28 @@ def main():
     print("grouping_operation bwd: %8.3f ms  %7.1f GB/s" % (ms, byt / ms / 1e6))
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "edgeconv" not in sys.argv:
     main()
+
+
+def bench_edgeconv():
+    dev = torch.device("cuda:0")
+    B, N, k = 8, 8192, 64
+    g = torch.Generator().manual_seed(0)
+    xyz = torch.rand(B, 3, N, generator=g).to(dev)
+    idx = dgcnn.knn(xyz, k, k)
+    for (C, Cout) in ((128, 128), (64, 64), (64, 128), (6, 64)):
+        x = torch.randn(B, C, N, generator=g).to(dev)
+        w = (torch.randn(Cout, 2 * C, generator=g) / (2 * C) ** 0.5).to(dev)
+        ga, be = torch.ones(Cout, device=dev), torch.zeros(Cout, device=dev)
+        for arg in (False, True):
+            ms = timeit(lambda: dgcnn.edgeconv_forward_raw(x, idx, w, ga, be, 2, "bf16", need_arg=arg))
+            Cp = max(8, 1 << (C - 1).bit_length())
+            fl = 2.0 * B * N * k * 2 * C * Cout
+            flp = 2.0 * B * N * k * 2 * Cp * Cout
+            print("edgeconv fwd bf16 C=%3d Cout=%3d arg=%d: %7.3f ms  %7.1f TFLOP/s algorithmic (%6.1f executed)"
+                  % (C, Cout, arg, ms, fl / ms / 1e9, flp / ms / 1e9))
+
+
+if __name__ == "__main__" and "edgeconv" in sys.argv:
+    bench_edgeconv()
