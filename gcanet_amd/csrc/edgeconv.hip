@@ -77,7 +77,7 @@ struct EcArgs {
   const unsigned short *x;  // (B,N,Cp) bf16
   const unsigned short *wp; // (Cout, 2Cp) bf16
   const int64_t *idx;       // (B,N,k)
-  int B, N, k, kp, Cout, G, TP;
+  int B, N, NX, k, kp, Cout, G, TP;  // NX = rows of x per cloud (== N for EdgeConv)
   int tiles_per_cloud, total_tiles;
   float *ymax, *ymin;       // (B,N,Cout)
   unsigned char *amax, *amin;
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(64 * RWT * CW) void edgeconv_fwd_bf16_kernel(EcArgs
     const int b = t / a.tiles_per_cloud;
     const int n0 = (t % a.tiles_per_cloud) * TP;
     unsigned char *abuf = lds + buf * BUF_BYTES;
-    const unsigned short *xb = a.x + (long)b * a.N * CP;
+    const unsigned short *xb = a.x + (long)b * a.NX * CP;
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
       const int p = wave + i * NW;
@@ -332,13 +332,13 @@ __global__ __launch_bounds__(64 * RWT * CW) void edgeconv_fwd_bf16_kernel(EcArgs
 // one k-ordered fmaf chain (bit-exact vs oracle).  One workgroup per point, one thread per
 // output channel; the k edge rows are staged in LDS.  Parity path, not the fast path.
 __global__ __launch_bounds__(256) void edgeconv_fwd_f32_kernel(const float *__restrict__ x, const float *__restrict__ w,
-                                                               const int64_t *__restrict__ idx, int N, int C, int k,
+                                                               const int64_t *__restrict__ idx, int N, int NX, int C, int k,
                                                                int Cout, int G, float *__restrict__ ymax,
                                                                float *__restrict__ ymin, unsigned char *__restrict__ amax,
                                                                unsigned char *__restrict__ amin, double *__restrict__ gsum) {
   extern __shared__ float e[];  // [k][2C] edge rows, then [Cout] scratch for sums
   const int n = blockIdx.x, b = blockIdx.y;
-  const float *xb = x + (long)b * N * C;
+  const float *xb = x + (long)b * NX * C;
   const float *xi = xb + (long)n * C;
   for (int t = threadIdx.x; t < k * C; t += blockDim.x) {
     const int j = t / C, c = t % C;
@@ -513,13 +513,13 @@ GCN_EXPORT int gcn_edgeconv_pack_w(const float *w, int Cout, int C, void *wp_bf1
   return check_launch("pack_w_kernel");
 }
 
-GCN_EXPORT int gcn_edgeconv_fwd(const void *x_pm, const void *w, const int64_t *idx, int dtype, int B, int N, int C,
-                                int k, int Cout, int G, float *ymax, float *ymin, uint8_t *amax, uint8_t *amin,
+GCN_EXPORT int gcn_edgeconv_fwd(const void *x_pm, const void *w, const int64_t *idx, int dtype, int B, int N, int NX,
+                                int C, int k, int Cout, int G, float *ymax, float *ymin, uint8_t *amax, uint8_t *amin,
                                 double *gsum, void *stream) {
   GCN_REQUIRE(x_pm && w && idx && ymax && ymin && gsum, "gcn_edgeconv_fwd: null pointer");
   GCN_REQUIRE((amax == nullptr) == (amin == nullptr), "gcn_edgeconv_fwd: pass both amax and amin or neither");
   GCN_REQUIRE(dtype == 0 || dtype == 1, "gcn_edgeconv_fwd: dtype must be 0 (f32) or 1 (bf16)");
-  GCN_REQUIRE(B >= 0 && N >= 1 && C >= 1 && k >= 1 && k <= 255, "gcn_edgeconv_fwd: bad shape (need 1 <= k <= 255)");
+  GCN_REQUIRE(B >= 0 && N >= 1 && NX >= N && C >= 1 && k >= 1 && k <= 255, "gcn_edgeconv_fwd: bad shape (need NX >= N, 1 <= k <= 255)");
   GCN_REQUIRE(G >= 1 && Cout % G == 0, "gcn_edgeconv_fwd: Cout=%d not divisible by G=%d", Cout, G);
   if (B == 0) return GCN_OK;
   hipStream_t st = (hipStream_t)stream;
@@ -528,7 +528,7 @@ GCN_EXPORT int gcn_edgeconv_fwd(const void *x_pm, const void *w, const int64_t *
     const size_t lds = sizeof(float) * ((size_t)k * 2 * C + 2) + sizeof(double) * 2 * Cout;
     GCN_REQUIRE(lds <= 150 * 1024, "gcn_edgeconv_fwd(f32): k*2C too large for the exact path (%zu B LDS)", lds);
     GCN_HIP(hipFuncSetAttribute((const void *)edgeconv_fwd_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    edgeconv_fwd_f32_kernel<<<dim3(N, B), 256, lds, st>>>((const float *)x_pm, (const float *)w, idx, N, C, k, Cout, G,
+    edgeconv_fwd_f32_kernel<<<dim3(N, B), 256, lds, st>>>((const float *)x_pm, (const float *)w, idx, N, NX, C, k, Cout, G,
                                                           ymax, ymin, amax, amin, gsum);
     return check_launch("edgeconv_fwd_f32_kernel");
   }
@@ -538,7 +538,7 @@ GCN_EXPORT int gcn_edgeconv_fwd(const void *x_pm, const void *w, const int64_t *
   GCN_REQUIRE(Cp <= 128, "gcn_edgeconv_fwd(bf16): C=%d > 128 unsupported", C);
   EcArgs a{};
   a.x = (const unsigned short *)x_pm; a.wp = (const unsigned short *)w; a.idx = idx;
-  a.B = B; a.N = N; a.k = k; a.kp = (k + 31) / 32 * 32; a.Cout = Cout; a.G = G;
+  a.B = B; a.N = N; a.NX = NX; a.k = k; a.kp = (k + 31) / 32 * 32; a.Cout = Cout; a.G = G;
   a.ymax = ymax; a.ymin = ymin; a.amax = amax; a.amin = amin; a.gsum = gsum;
   const bool wa = amax != nullptr;
   const int ks = Cp / 8;

@@ -73,11 +73,11 @@ def edgeconv_forward_raw(x, idx, weight, gamma, beta, groups, dtype="bf16", eps=
         wp = torch.empty(Cout, 2 * Cp, dtype=torch.bfloat16, device=dev)
         _run("gcn_edgeconv_pack_x", x, _lib.ptr(x), B, C, N, _lib.ptr(x_bf), _lib.ptr(x_pm))
         _run("gcn_edgeconv_pack_w", x, _lib.ptr(w), Cout, C, _lib.ptr(wp))
-        _run("gcn_edgeconv_fwd", x, _lib.ptr(x_bf), _lib.ptr(wp), _lib.ptr(idx), 1, B, N, C, k, Cout, groups,
+        _run("gcn_edgeconv_fwd", x, _lib.ptr(x_bf), _lib.ptr(wp), _lib.ptr(idx), 1, B, N, N, C, k, Cout, groups,
              _lib.ptr(ymax), _lib.ptr(ymin), _lib.ptr(amax), _lib.ptr(amin), _lib.ptr(gsum))
     elif dtype == "f32":
         _run("gcn_edgeconv_pack_x", x, _lib.ptr(x), B, C, N, None, _lib.ptr(x_pm))
-        _run("gcn_edgeconv_fwd", x, _lib.ptr(x_pm), _lib.ptr(w), _lib.ptr(idx), 0, B, N, C, k, Cout, groups,
+        _run("gcn_edgeconv_fwd", x, _lib.ptr(x_pm), _lib.ptr(w), _lib.ptr(idx), 0, B, N, N, C, k, Cout, groups,
              _lib.ptr(ymax), _lib.ptr(ymin), _lib.ptr(amax), _lib.ptr(amin), _lib.ptr(gsum))
     else:
         raise ValueError("dtype must be 'bf16' or 'f32'")
@@ -172,3 +172,119 @@ def edge_conv(x, idx, weight, gamma, beta, groups=2, dtype="bf16", eps=1e-5, slo
     if weight.dim() == 4:
         weight = weight[:, :, 0, 0]
     return EdgeConvFunction.apply(x, idx, weight, gamma, beta, groups, dtype, eps, slope)
+
+
+# ------------------------------------------------------------------------------------------
+# Reference-compatible graph-feature functions (materialising; for drop-in users of M4:93-205).
+# The fused path (edge_conv / grouped_block) never builds these tensors.
+# ------------------------------------------------------------------------------------------
+def _neighbours(x, idx):
+    B, C, N = x.shape
+    xt = x.transpose(2, 1).contiguous()
+    nb = torch.gather(xt.unsqueeze(1).expand(-1, N, -1, -1), 2, idx.unsqueeze(-1).expand(-1, -1, -1, C))
+    return nb, xt.unsqueeze(2)
+
+
+def get_graph_feature(x, k1=20, k2=20, idx=None):
+    """M4:93-124 -> (B,2C,N,k) = cat(x_j - x_i, x_i)."""
+    if idx is None:
+        idx = knn(x, k1, k2)
+    nb, ctr = _neighbours(x, idx)
+    ctr = ctr.expand_as(nb)
+    return torch.cat((nb - ctr, ctr), dim=3).permute(0, 3, 1, 2)
+
+
+def get_graph_feature_with_normals(x, k1=20, k2=20, idx=None):
+    """M4:127-161."""
+    if idx is None:
+        idx = knn_points_normals(x, k1, k2)
+    return get_graph_feature(x, k1, k2, idx)
+
+
+def get_graph_feature_with_normals_g(x, k1=20, k2=20, idx=None):
+    """M4:164-205 -> (B,7,N,k) = [clamp(n_i.n_j, +-0.99), n_j - n_i, n_i]."""
+    if idx is None:
+        idx = knn_points_normals(x, k1, k2)
+    nb, ctr = _neighbours(x, idx)
+    n_j, n_i = nb[..., 3:6], ctr[..., 3:6].expand(-1, -1, idx.shape[2], -1)
+    angle = (n_i * n_j).sum(-1, keepdim=True).clamp(-0.99, 0.99)
+    return torch.cat((angle, n_j - n_i, n_i), dim=3).permute(0, 3, 1, 2)
+
+
+class GroupedBlockFunction(torch.autograd.Function):
+    """max_k LeakyReLU(GroupNorm(Conv2d_1x1(ef))) for an ARBITRARY materialised edge feature
+    ef (B,N,k,F) (e.g. the 7-channel normal feature, M4:575-577,691-693).  Forward reuses the fused
+    MFMA kernel (rows are their own 'neighbours'); backward is the same closed form as EdgeConv."""
+
+    @staticmethod
+    def forward(ctx, ef, weight, gamma, beta, groups, eps, slope):
+        B, N, k, F = ef.shape
+        Cout = weight.shape[0]
+        dev = ef.device
+        rows = ef.reshape(B, N * k, F).permute(0, 2, 1).contiguous()          # (B,F,N*k) "cloud" of edge rows
+        ident = (torch.arange(N * k, device=dev, dtype=torch.int64).view(1, N, k)).expand(B, -1, -1).contiguous()
+        w2 = torch.cat([weight, weight], 1)                                   # W' = [W | 0]
+        f32 = dict(dtype=torch.float32, device=dev)
+        ymax, ymin = torch.empty(B, N, Cout, **f32), torch.empty(B, N, Cout, **f32)
+        amax = torch.empty(B, N, Cout, dtype=torch.uint8, device=dev)
+        amin = torch.empty(B, N, Cout, dtype=torch.uint8, device=dev)
+        gsum = torch.empty(B, groups, 2, dtype=torch.float64, device=dev)
+        Fp = _lib.lib().gcn_edgeconv_padded_channels(F)
+        x_bf = torch.empty(B, N * k, Fp, dtype=torch.bfloat16, device=dev)
+        wp = torch.empty(Cout, 2 * Fp, dtype=torch.bfloat16, device=dev)
+        _run("gcn_edgeconv_pack_x", ef, _lib.ptr(rows), B, F, N * k, _lib.ptr(x_bf), None)
+        _run("gcn_edgeconv_pack_w", ef, _lib.ptr(w2.contiguous()), Cout, F, _lib.ptr(wp))
+        # N "points" whose k neighbours are rows n*k..n*k+k-1; the centre rows meet zero weights
+        _run("gcn_edgeconv_fwd", ef, _lib.ptr(x_bf), _lib.ptr(wp), _lib.ptr(ident), 1, B, N, N * k, F, k, Cout, groups,
+             _lib.ptr(ymax), _lib.ptr(ymin), _lib.ptr(amax), _lib.ptr(amin), _lib.ptr(gsum))
+        out = torch.empty(B, Cout, N, **f32)
+        mean_rstd = torch.empty(B, groups, 2, **f32)
+        _run("gcn_edgeconv_finish", ef, _lib.ptr(ymax), _lib.ptr(ymin), _lib.ptr(gsum), _lib.ptr(gamma.contiguous()),
+             _lib.ptr(beta.contiguous()), B, N, k, Cout, groups, float(eps), float(slope), _lib.ptr(out), None,
+             _lib.ptr(mean_rstd))
+        ctx.save_for_backward(ef, weight, gamma, beta, ymax, ymin, amax, amin, mean_rstd)
+        ctx.cfg = (groups, slope)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        ef, W, gamma, beta, ymax, ymin, amax, amin, mean_rstd = ctx.saved_tensors
+        G, slope = ctx.cfg
+        B, N, k, F = ef.shape
+        Cout = W.shape[0]
+        cpg = Cout // G
+        Mg = float(cpg * N * k)
+        dpm = dout.permute(0, 2, 1)
+        pos = (gamma >= 0).view(1, 1, Cout)
+        ysel = torch.where(pos, ymax, ymin)
+        jsel = torch.where(pos, amax, amin).long()                            # (B,N,Cout) slot
+        mean = mean_rstd[:, :, 0].repeat_interleave(cpg, 1).unsqueeze(1)
+        rstd = mean_rstd[:, :, 1].repeat_interleave(cpg, 1).unsqueeze(1)
+        yhat = (ysel - mean) * rstd
+        z = yhat * gamma + beta
+        gz = dpm * torch.where(z > 0, torch.ones_like(z), torch.full_like(z, slope))
+        dbeta, dgamma = gz.sum((0, 1)), (gz * yhat).sum((0, 1))
+        t = gz * gamma
+        S1 = t.view(B, N, G, cpg).sum((1, 3))
+        S2 = (t * yhat).view(B, N, G, cpg).sum((1, 3))
+        rs, mu = mean_rstd[:, :, 1], mean_rstd[:, :, 0]
+        Bc = (-(rs * rs) * S2 / Mg).repeat_interleave(cpg, 1)
+        Ac = (-(rs * S1) / Mg).repeat_interleave(cpg, 1) - Bc * mu.repeat_interleave(cpg, 1)
+        coef = t * rstd                                                        # (B,N,Cout)
+        # sparse part: one selected row per (point, channel)
+        onehot = torch.zeros(B, N, k, Cout, dtype=torch.float32, device=ef.device).scatter_(2, jsel.unsqueeze(2), coef.unsqueeze(2))
+        d_ef = onehot @ W                                                      # (B,N,k,F)
+        dW = torch.einsum("bnko,bnkf->of", onehot, ef)
+        # dense part: dy = A + B*y, y = ef.W^T
+        T = torch.einsum("of,bo,og->bfg", W, Bc, W)                            # (B,F,F)
+        d_ef = d_ef + (Ac @ W).view(B, 1, 1, F) + torch.einsum("bnkf,bfg->bnkg", ef, T)
+        gram = torch.einsum("bnkf,bnkg->bfg", ef, ef)
+        dW = dW + torch.einsum("bo,bf->of", Ac, ef.sum((1, 2))) + torch.einsum("bo,og,bgf->of", Bc, W, gram)
+        return d_ef, dW, dgamma, dbeta, None, None, None
+
+
+def grouped_block(ef, weight, gamma, beta, groups=2, eps=1e-5, slope=0.2):
+    """ef (B,N,k,F) point-major edge features -> (B,Cout,N)."""
+    if weight.dim() == 4:
+        weight = weight[:, :, 0, 0]
+    return GroupedBlockFunction.apply(ef.float().contiguous(), weight, gamma, beta, groups, eps, slope)

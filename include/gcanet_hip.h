@@ -198,7 +198,9 @@ int gcn_hierarchical_aggregation_host(const int32_t *semantic_label_host, const 
  *   dtype 1: x_pm (B,N,Cp) bf16 and w = W' (Cout,2Cp) bf16 from gcn_edgeconv_pack_x / _pack_w,
  *            Cp = gcn_edgeconv_padded_channels(C); Cout in {64,128}, C <= 128, (Cout/G) % 32 == 0
  *   dtype 0: x_pm (B,N,C) f32, w (Cout,2C) f32 (the reference's own Conv2d weight)
- *   idx    (B,N,k) int64 neighbour ids within the cloud (what knn()/topk returns), 1 <= k <= 255
+ *   idx    (B,N,k) int64 neighbour ids within the cloud (what knn()/topk returns), 1 <= k <= 255;
+ *          ids index the NX rows per cloud of x_pm (NX == N for EdgeConv; a generic grouped block
+ *          passes NX = N*k materialised edge rows with identity ids)
  *   ymax, ymin (B,N,Cout) f32: max / min over the k neighbours of the RAW conv output
  *   amax, amin (B,N,Cout) u8 or both NULL: neighbour slot attaining it (lowest slot on ties)
  *   gsum   (B,G,2) f64: per-(cloud, group) sum and sum of squares of the raw conv output over
@@ -210,7 +212,7 @@ int gcn_edgeconv_pack_x(const float *x_cm, int B, int C, int N, void *x_pm_bf16,
                         void *stream);
 int gcn_edgeconv_pack_w(const float *w, int Cout, int C, void *wp_bf16, void *stream);
 int gcn_edgeconv_fwd(const void *x_pm, const void *w, const int64_t *idx, int dtype, int B, int N,
-                     int C, int k, int Cout, int G, float *ymax, float *ymin, uint8_t *amax,
+                     int NX, int C, int k, int Cout, int G, float *ymax, float *ymin, uint8_t *amax,
                      uint8_t *amin, double *gsum, void *stream);
 
 /* GroupNorm(G, Cout, eps) + LeakyReLU(slope) on the routed extreme:

@@ -117,3 +117,34 @@ def test_edgeconv_backward_vs_oracle_autograd(dev, B, C, N, k, Cout, G, dtype):
         ref = b.grad.numpy()
         scale = np.abs(ref).max()
         np.testing.assert_allclose(a.grad.cpu().numpy(), ref, rtol=2e-3, atol=2e-4 * scale, err_msg=name)
+
+
+def test_grouped_block_fwd_bwd(dev):
+    """conv_normal-style block on a materialised 7-channel edge feature (M4:575-577,691-693)."""
+    from gcanet_amd import dgcnn
+    g = torch.Generator().manual_seed(3)
+    B, N, k, F, Cout = 2, 150, 16, 7, 64
+    ef = _bf16_round(torch.randn(B, N, k, F, generator=g))
+    w = _bf16_round(torch.randn(Cout, F, generator=g) / F ** 0.5)
+    gamma, beta = torch.randn(Cout, generator=g), torch.randn(Cout, generator=g) * 0.1
+    gout = torch.randn(B, Cout, N, generator=g)
+    leaves = [v.clone().requires_grad_() for v in (ef, w, gamma, beta)]
+    R.grouped_block(leaves[0].permute(0, 3, 1, 2), leaves[1], leaves[2], leaves[3], 2).mul(gout).sum().backward()
+    ref = R.grouped_block(ef.permute(0, 3, 1, 2), w, gamma, beta, 2)
+    dl = [v.clone().to(dev).requires_grad_() for v in (ef, w, gamma, beta)]
+    y = dgcnn.grouped_block(dl[0], dl[1], dl[2], dl[3], 2)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), ref.numpy(), rtol=1e-4, atol=1e-4)
+    (y * gout.to(dev)).sum().backward()
+    for a, b, name in zip(dl, leaves, ("d_ef", "dw", "dgamma", "dbeta")):
+        r = b.grad.numpy()
+        np.testing.assert_allclose(a.grad.cpu().numpy(), r, rtol=2e-3, atol=2e-4 * np.abs(r).max(), err_msg=name)
+
+
+def test_graph_feature_functions_match_golden(dev, golden):
+    from gcanet_amd import dgcnn
+    t = lambda a: torch.from_numpy(a).to(dev)
+    f = dgcnn.get_graph_feature(t(golden["knn_feat_x"]), idx=t(golden["knn_feat_idx_k8"]))
+    np.testing.assert_array_equal(f.cpu().numpy(), golden["ggf_feat_out"])
+    xp, ip = t(golden["knnpn_rand_x"]), t(golden["knnpn_rand_idx_k16"])
+    np.testing.assert_array_equal(dgcnn.get_graph_feature_with_normals(xp, idx=ip).cpu().numpy(), golden["ggfn_out"])
+    np.testing.assert_allclose(dgcnn.get_graph_feature_with_normals_g(xp, idx=ip).cpu().numpy(), golden["ggfng_out"], rtol=0, atol=1e-6)
