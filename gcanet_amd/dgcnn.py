@@ -288,3 +288,200 @@ def grouped_block(ef, weight, gamma, beta, groups=2, eps=1e-5, slope=0.2):
     if weight.dim() == 4:
         weight = weight[:, :, 0, 0]
     return GroupedBlockFunction.apply(ef.float().contiguous(), weight, gamma, beta, groups, eps, slope)
+
+
+# ------------------------------------------------------------------------------------------
+# nn.Modules mirroring M4's hot path (same attribute / parameter names, so a reference
+# state_dict's matching keys load unchanged).
+# ------------------------------------------------------------------------------------------
+import torch.nn as nn  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+
+class _EdgeConvLayer(nn.Module):
+    """Holds Conv2d(2C->Cout,1x1,no bias)+GroupNorm like nn.Sequential(conv, bn, LeakyReLU) of M4:467-480
+    (parameter names `0.weight`; the GroupNorm is shared with encoder.bnX as in the reference)."""
+
+    def __init__(self, cin2, cout, gn):
+        super().__init__()
+        self.add_module("0", nn.Conv2d(cin2, cout, kernel_size=1, bias=False))
+        self.add_module("1", gn)
+        self.add_module("2", nn.LeakyReLU(negative_slope=0.2))
+
+    def fused(self, x, idx, dtype):
+        conv, gn = self._modules["0"], self._modules["1"]
+        return edge_conv(x, idx, conv.weight, gn.weight, gn.bias, gn.num_groups, dtype, gn.eps, 0.2)
+
+
+class DGCNNEncoderGn(nn.Module):
+    """M4:455-534.  forward(x (B,Cin,N)) -> (B,1280,N); neighbour lists of the three layers are kept
+    in `self.last_idx` (layer 1's is reused by the normal-feature branch instead of being recomputed,
+    M4:691)."""
+
+    def __init__(self, mode=0, nn_nb=80, input_channels=3, dtype="bf16"):
+        super().__init__()
+        self.k = nn_nb
+        self.mode = mode
+        self.dtype = dtype
+        self.bn1, self.bn2, self.bn3 = nn.GroupNorm(2, 64), nn.GroupNorm(2, 64), nn.GroupNorm(2, 128)
+        self.bn4, self.bn5 = nn.GroupNorm(4, 256), nn.GroupNorm(8, 1024)
+        self.conv1 = _EdgeConvLayer(input_channels * 2 if mode == 5 else input_channels, 64, self.bn1)
+        self.conv2 = _EdgeConvLayer(64 * 2, 64, self.bn2)
+        self.conv3 = _EdgeConvLayer(64 * 2, 128, self.bn3)
+        self.mlp1 = nn.Conv1d(256, 1024, 1)
+        self.bnmlp1 = nn.GroupNorm(8, 1024)
+        self.last_idx = None
+
+    def forward(self, x):
+        B, _, N = x.shape
+        k = self.k
+        idx1 = knn_points_normals(x, k, k) if self.mode == 5 else knn(x, k, k)
+        x1 = self.conv1.fused(x, idx1, self.dtype)
+        idx2 = knn(x1, k, k)
+        x2 = self.conv2.fused(x1, idx2, self.dtype)
+        idx3 = knn(x2, k, k)
+        x3 = self.conv3.fused(x2, idx3, self.dtype)
+        self.last_idx = (idx1, idx2, idx3)
+        x_features = torch.cat((x1, x2, x3), dim=1)
+        h = F.relu(self.bnmlp1(self.mlp1(x_features)))
+        x4 = h.max(dim=2)[0]
+        return torch.cat([x4.view(B, 1024, 1).expand(-1, -1, N), x_features], 1)
+
+
+def cos_dist(instance_feature, global_instance_feature):
+    """M4:326-342."""
+    a = instance_feature / instance_feature.norm(dim=-1, keepdim=True)
+    b = global_instance_feature / global_instance_feature.norm(dim=-1, keepdim=True)
+    return -(1 - torch.einsum("bnc,bkc->bnk", a, b))
+
+
+class KPAM(nn.Module):
+    """M4:351-373 (softmax over the k axis -- see oracle/ref_model.py:kpam)."""
+
+    def __init__(self, C):
+        super().__init__()
+        self.dim = C
+        self.conv1 = nn.Sequential(nn.Conv1d(C, C, kernel_size=1, bias=False), nn.ReLU(),
+                                   nn.Conv1d(C, C, kernel_size=1, bias=False))
+
+    def weights(self, attention_feature):
+        a = self.conv1(attention_feature.permute(0, 2, 1)).permute(0, 2, 1)
+        return torch.softmax(a, dim=2)                                         # (B,N,k)
+
+    def forward(self, x, attention_feature):
+        return self.weights(attention_feature).unsqueeze(-1) * x
+
+
+_KEY_CACHE = {}
+
+
+def key_point_indices(num_points, n_keys, device):
+    """M4:403-406: np.random.seed(1234); shuffle(arange(N))[:n_keys] -- legacy NumPy RNG, cached."""
+    key = (num_points, n_keys, str(device))
+    if key not in _KEY_CACHE:
+        st = np.random.get_state()
+        l = np.arange(num_points)
+        np.random.seed(1234)
+        np.random.shuffle(l)
+        np.random.set_state(st)
+        _KEY_CACHE[key] = torch.from_numpy(l[:n_keys]).long().to(device)
+    return _KEY_CACHE[key]
+
+
+class OFFSET_PRED_MODULE(nn.Module):
+    """M4:376-452.  The reference repeats key features to (B,N,120,128) (4 GB at B=8,N=8192) and runs
+    topk twice; here every edge feature is att[n,j] * [f_key[m] ; p_key[m] - p_n], so the 131->128 conv
+    factorises over the 120 key points: y[n,j,:] = att[n,j] * (U[m] - V[n]) with U = Wf.f_key + Wp.p_key
+    (120 rows) and V = Wp.p_n -- identical values, k-fold fewer FLOPs, no (B,N,120,.) tensors."""
+
+    def __init__(self, nn_nb=30, sampling_ratio=120):
+        super().__init__()
+        self.k = nn_nb
+        self.sampling_ratio = sampling_ratio
+        self.bn1 = nn.GroupNorm(2, 128)
+        self.conv1 = nn.Sequential(nn.Conv2d(131, 128, kernel_size=1, bias=False), self.bn1,
+                                   nn.LeakyReLU(negative_slope=0.2))
+        self.attention = KPAM(nn_nb)
+        self.mlp_offset = nn.Conv1d(256, 3, 1)
+
+    def forward(self, points, feature, instance_feature):
+        B, N, _ = points.shape
+        sub = key_point_indices(N, self.sampling_ratio, points.device)
+        key_pts, key_feat, key_emb = points[:, sub], feature[:, sub], instance_feature[:, sub]
+        dist = cos_dist(instance_feature, key_emb)                             # (B,N,120)
+        topk_dist, topk_idx = torch.topk(dist, self.k, dim=2, largest=True)    # once, not twice (M4:421-422)
+        att = self.attention.weights(topk_dist)                                # (B,N,k)
+        W = self.conv1[0].weight[:, :, 0, 0]                                   # (128,131)
+        Wf, Wp = W[:, :128], W[:, 128:]
+        U = key_feat @ Wf.t() + key_pts @ Wp.t()                               # (B,120,128)
+        V = points @ Wp.t()                                                    # (B,N,128)
+        bi = torch.arange(B, device=points.device).view(B, 1, 1)
+        y = att.unsqueeze(-1) * (U[bi, topk_idx] - V.unsqueeze(2))             # (B,N,k,128) raw conv output
+        y = F.leaky_relu(F.group_norm(y.permute(0, 3, 1, 2), 2, self.bn1.weight, self.bn1.bias, self.bn1.eps), 0.2)
+        y = y.max(dim=-1)[0]                                                   # (B,128,N)
+        y = torch.cat([y, feature.permute(0, 2, 1)], dim=1)
+        return self.mlp_offset(y)
+
+
+class PrimitivesEmbeddingDGCNGn(nn.Module):
+    """Hot-path part of M4:537-782 (`forward_train` up to and including `pt_offsets`): DGCNN encoder,
+    per-point heads, normal-feature EdgeConv, embedding head, offset module.  Everything after
+    (forward_grouping -> SoftGroup ops -> spconv tiny U-Net, M4:737-774) is data-dependent host code plus
+    an un-vendored third-party sparse-conv library and stays outside this module."""
+
+    def __init__(self, emb_size=64, num_primitives=10, mode=5, num_channels=6, nn_nb=80, dtype="bf16",
+                 loss_class="r"):
+        super().__init__()
+        self.mode, self.nn_nb, self.dtype, self.loss_class = mode, nn_nb, dtype, loss_class
+        self.encoder = DGCNNEncoderGn(mode=mode, nn_nb=nn_nb, input_channels=num_channels, dtype=dtype)
+        self.offset_pred_block = OFFSET_PRED_MODULE(nn_nb=30, sampling_ratio=120)
+        self.conv1, self.bn1 = nn.Conv1d(1024 + 256, 512, 1), nn.GroupNorm(8, 512)
+        self.conv2, self.bn2 = nn.Conv1d(512, 256, 1), nn.GroupNorm(4, 256)
+        self.conv3, self.bn3 = nn.Conv1d(262 if mode in (5, 3) else 259, 128, 1), nn.GroupNorm(4, 128)
+        self.mlp_seg_prob1, self.mlp_seg_prob2 = nn.Conv1d(832, 256, 1), nn.Conv1d(256, emb_size, 1)
+        self.bn_seg_prob1 = nn.GroupNorm(4, 256)
+        self.bn_normal = nn.GroupNorm(2, 64)
+        self.conv_normal = nn.Sequential(nn.Conv2d(7, 64, kernel_size=1, bias=False), self.bn_normal,
+                                         nn.LeakyReLU(negative_slope=0.2))
+        self.mlp_prim_prob1, self.mlp_prim_prob2 = nn.Conv1d(256, 256, 1), nn.Conv1d(256, num_primitives, 1)
+        self.bn_prim_prob1 = nn.GroupNorm(4, 256)
+        self.mlp_param_prob1, self.mlp_param_prob2 = nn.Conv1d(256, 256, 1), nn.Conv1d(256, 22, 1)
+        self.bn_param_prob1 = nn.GroupNorm(4, 256)
+        self.logsoftmax = nn.LogSoftmax(dim=1)
+
+    @staticmethod
+    def _unit(v):
+        return v / (torch.norm(v, dim=-1, keepdim=True) + 1e-12)
+
+    def forward(self, points, normals):
+        """points, normals (B,N,3) -> dict(type_per_point, param_per_point, semantic_scores, pt_offsets,
+        output_feats) with the reference's shapes (M4:634-747)."""
+        B, N, _ = points.shape
+        pts = torch.cat([points, normals], dim=-1).permute(0, 2, 1).contiguous() if self.mode == 5 \
+            else points.permute(0, 2, 1).contiguous()
+        x = self.encoder(pts)
+        x = F.relu(self.bn1(self.conv1(x)))
+        x_all = F.relu(self.bn2(self.conv2(x)))
+        x_type = F.relu(self.bn_prim_prob1(self.mlp_prim_prob1(x_all)))
+        type_pp = self.mlp_prim_prob2(x_type)
+        type_forgroup = type_pp.permute(0, 2, 1)
+        type_per_point = self.logsoftmax(type_pp).permute(0, 2, 1) if "r" in self.loss_class else type_forgroup
+        x_para = F.relu(self.bn_param_prob1(self.mlp_param_prob1(x_all)))
+        p = self.mlp_param_prob2(x_para).transpose(1, 2)
+        param_per_point = torch.cat([p[:, :, :4], self._unit(p[:, :, 4:7]), p[:, :, 7:8], self._unit(p[:, :, 8:11]),
+                                     p[:, :, 11:15], self._unit(p[:, :, 15:18]), p[:, :, 18:22]], dim=2)
+        # normal-feature EdgeConv: same input as encoder layer 1 -> same neighbour list (M4:691 recomputes it)
+        idx1 = self.encoder.last_idx[0]
+        ef = get_graph_feature_with_normals_g(pts, idx=idx1).permute(0, 2, 3, 1)          # (B,N,k,7)
+        normal_feature = grouped_block(ef, self.conv_normal[0].weight, self.bn_normal.weight, self.bn_normal.bias, 2,
+                                       self.bn_normal.eps, 0.2)
+        x = torch.cat([x_all, x_type, x_para, normal_feature], dim=1)
+        x = F.relu(self.bn_seg_prob1(self.mlp_seg_prob1(x)))
+        output_feats = self.mlp_seg_prob2(x).permute(0, 2, 1)                               # (B,N,emb)
+        feat_plus = torch.cat([x_all, pts], dim=1)                                          # (B,262,N)
+        feat_plus = F.relu(self.bn3(self.conv3(feat_plus))).permute(0, 2, 1)                # (B,N,128)
+        semantic_scores = type_forgroup.reshape(-1, type_forgroup.shape[-1])
+        pt_offsets = self.offset_pred_block(pts[:, 0:3, :].permute(0, 2, 1), feat_plus, output_feats)
+        pt_offsets = pt_offsets.permute(0, 2, 1).reshape(-1, 3)
+        return dict(type_per_point=type_per_point, param_per_point=param_per_point,
+                    semantic_scores=semantic_scores, pt_offsets=pt_offsets, output_feats=output_feats)
