@@ -46,6 +46,9 @@ def lib():
     """Load the library (once).  Raises if it has not been built."""
     global _lib
     if _lib is None:
+        # torch must load ITS HIP runtime first: libgcanet_hip.so then binds to the same
+        # libamdhip64 instead of pulling a second copy (two runtimes -> "no ROCm-capable device")
+        import torch  # noqa: F401
         if not os.path.exists(SO_PATH):
             raise RuntimeError(
                 "gcanet_amd: %s not found -- build it with `python -m gcanet_amd.build` "
@@ -59,10 +62,36 @@ def lib():
     return _lib
 
 
-def call(name, *args):
+# optional per-entry-point device timing (bench.py): {key: [(start_event, end_event), ...]}
+_TIMING = None
+
+
+def enable_timing(flag=True):
+    """Record a HIP event pair (on torch's current stream == the launch stream) around every call."""
+    global _TIMING
+    _TIMING = {} if flag else None
+
+
+def timing_results():
+    """-> {key: (n_calls, total_ms)}; call after torch.cuda.synchronize()."""
+    out = {}
+    for key, evs in (_TIMING or {}).items():
+        out[key] = (len(evs), sum(a.elapsed_time(b) for a, b in evs))
+    return out
+
+
+def call(name, *args, tag=None):
     """Invoke an entry point; non-zero status -> RuntimeError with gcn_last_error()."""
     dll = lib()
-    rc = getattr(dll, name)(*args)
+    if _TIMING is not None and tag is not None:
+        import torch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = getattr(dll, name)(*args)
+        e1.record()
+        _TIMING.setdefault(tag, []).append((e0, e1))
+    else:
+        rc = getattr(dll, name)(*args)
     if rc != 0:
         raise RuntimeError("%s failed (status %d): %s" % (name, rc, dll.gcn_last_error().decode()))
 

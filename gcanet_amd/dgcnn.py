@@ -20,7 +20,7 @@ def _knn_model(x, k1, k2, metric):
     xx = torch.empty(B, N, dtype=torch.float32, device=x.device)
     with torch.cuda.device_of(x):
         _lib.call("gcn_knn_model", _lib.ptr(x), B, C, N, k1, k2, metric, _lib.ptr(idx), None, _lib.ptr(xx),
-                  _lib.stream_of(x))
+                  _lib.stream_of(x), tag="knn_model[B=%d,C=%d,N=%d,k=%d]" % (B, C, N, k2))
     return idx
 
 
@@ -41,9 +41,9 @@ def knn_points_normals(x, k1, k2):
 # ------------------------------------------------------------------------------------------
 # Fused EdgeConv block: get_graph_feature -> Conv2d 1x1 -> GroupNorm -> LeakyReLU -> max_k
 # ------------------------------------------------------------------------------------------
-def _run(name, like, *args):
+def _run(name, like, *args, tag=None):
     with torch.cuda.device_of(like):
-        _lib.call(name, *args, _lib.stream_of(like))
+        _lib.call(name, *args, _lib.stream_of(like), tag=tag)
 
 
 def edgeconv_forward_raw(x, idx, weight, gamma, beta, groups, dtype="bf16", eps=1e-5, slope=0.2, need_arg=False):
@@ -74,7 +74,8 @@ def edgeconv_forward_raw(x, idx, weight, gamma, beta, groups, dtype="bf16", eps=
         _run("gcn_edgeconv_pack_x", x, _lib.ptr(x), B, C, N, _lib.ptr(x_bf), _lib.ptr(x_pm))
         _run("gcn_edgeconv_pack_w", x, _lib.ptr(w), Cout, C, _lib.ptr(wp))
         _run("gcn_edgeconv_fwd", x, _lib.ptr(x_bf), _lib.ptr(wp), _lib.ptr(idx), 1, B, N, N, C, k, Cout, groups,
-             _lib.ptr(ymax), _lib.ptr(ymin), _lib.ptr(amax), _lib.ptr(amin), _lib.ptr(gsum))
+             _lib.ptr(ymax), _lib.ptr(ymin), _lib.ptr(amax), _lib.ptr(amin), _lib.ptr(gsum),
+             tag="edgeconv_fwd[B=%d,N=%d,k=%d,C=%d,Cout=%d]" % (B, N, k, C, Cout))
     elif dtype == "f32":
         _run("gcn_edgeconv_pack_x", x, _lib.ptr(x), B, C, N, None, _lib.ptr(x_pm))
         _run("gcn_edgeconv_fwd", x, _lib.ptr(x_pm), _lib.ptr(w), _lib.ptr(idx), 0, B, N, N, C, k, Cout, groups,
@@ -217,7 +218,7 @@ class GroupedBlockFunction(torch.autograd.Function):
     MFMA kernel (rows are their own 'neighbours'); backward is the same closed form as EdgeConv."""
 
     @staticmethod
-    def forward(ctx, ef, weight, gamma, beta, groups, eps, slope):
+    def forward(ctx, ef, weight, gamma, beta, groups, eps, slope, dtype="bf16"):
         B, N, k, F = ef.shape
         Cout = weight.shape[0]
         dev = ef.device
@@ -229,14 +230,19 @@ class GroupedBlockFunction(torch.autograd.Function):
         amax = torch.empty(B, N, Cout, dtype=torch.uint8, device=dev)
         amin = torch.empty(B, N, Cout, dtype=torch.uint8, device=dev)
         gsum = torch.empty(B, groups, 2, dtype=torch.float64, device=dev)
-        Fp = _lib.lib().gcn_edgeconv_padded_channels(F)
-        x_bf = torch.empty(B, N * k, Fp, dtype=torch.bfloat16, device=dev)
-        wp = torch.empty(Cout, 2 * Fp, dtype=torch.bfloat16, device=dev)
-        _run("gcn_edgeconv_pack_x", ef, _lib.ptr(rows), B, F, N * k, _lib.ptr(x_bf), None)
-        _run("gcn_edgeconv_pack_w", ef, _lib.ptr(w2.contiguous()), Cout, F, _lib.ptr(wp))
-        # N "points" whose k neighbours are rows n*k..n*k+k-1; the centre rows meet zero weights
-        _run("gcn_edgeconv_fwd", ef, _lib.ptr(x_bf), _lib.ptr(wp), _lib.ptr(ident), 1, B, N, N * k, F, k, Cout, groups,
-             _lib.ptr(ymax), _lib.ptr(ymin), _lib.ptr(amax), _lib.ptr(amin), _lib.ptr(gsum))
+        # N "points" whose k neighbours are rows n*k..n*k+k-1 of the edge-row "cloud"
+        if dtype == "bf16":
+            Fp = _lib.lib().gcn_edgeconv_padded_channels(F)
+            x_bf = torch.empty(B, N * k, Fp, dtype=torch.bfloat16, device=dev)
+            wp = torch.empty(Cout, 2 * Fp, dtype=torch.bfloat16, device=dev)
+            _run("gcn_edgeconv_pack_x", ef, _lib.ptr(rows), B, F, N * k, _lib.ptr(x_bf), None)
+            _run("gcn_edgeconv_pack_w", ef, _lib.ptr(w2.contiguous()), Cout, F, _lib.ptr(wp))   # W' = [W | 0]
+            _run("gcn_edgeconv_fwd", ef, _lib.ptr(x_bf), _lib.ptr(wp), _lib.ptr(ident), 1, B, N, N * k, F, k, Cout,
+                 groups, _lib.ptr(ymax), _lib.ptr(ymin), _lib.ptr(amax), _lib.ptr(amin), _lib.ptr(gsum))
+        else:   # exact path: W.(x_j - x_i) + W.x_i
+            flat = ef.reshape(B, N * k, F)
+            _run("gcn_edgeconv_fwd", ef, _lib.ptr(flat), _lib.ptr(w2.contiguous()), _lib.ptr(ident), 0, B, N, N * k, F,
+                 k, Cout, groups, _lib.ptr(ymax), _lib.ptr(ymin), _lib.ptr(amax), _lib.ptr(amin), _lib.ptr(gsum))
         out = torch.empty(B, Cout, N, **f32)
         mean_rstd = torch.empty(B, groups, 2, **f32)
         _run("gcn_edgeconv_finish", ef, _lib.ptr(ymax), _lib.ptr(ymin), _lib.ptr(gsum), _lib.ptr(gamma.contiguous()),
@@ -280,14 +286,14 @@ class GroupedBlockFunction(torch.autograd.Function):
         d_ef = d_ef + (Ac @ W).view(B, 1, 1, F) + torch.einsum("bnkf,bfg->bnkg", ef, T)
         gram = torch.einsum("bnkf,bnkg->bfg", ef, ef)
         dW = dW + torch.einsum("bo,bf->of", Ac, ef.sum((1, 2))) + torch.einsum("bo,og,bgf->of", Bc, W, gram)
-        return d_ef, dW, dgamma, dbeta, None, None, None
+        return d_ef, dW, dgamma, dbeta, None, None, None, None
 
 
-def grouped_block(ef, weight, gamma, beta, groups=2, eps=1e-5, slope=0.2):
+def grouped_block(ef, weight, gamma, beta, groups=2, eps=1e-5, slope=0.2, dtype="bf16"):
     """ef (B,N,k,F) point-major edge features -> (B,Cout,N)."""
     if weight.dim() == 4:
         weight = weight[:, :, 0, 0]
-    return GroupedBlockFunction.apply(ef.float().contiguous(), weight, gamma, beta, groups, eps, slope)
+    return GroupedBlockFunction.apply(ef.float().contiguous(), weight, gamma, beta, groups, eps, slope, dtype)
 
 
 # ------------------------------------------------------------------------------------------
@@ -474,7 +480,7 @@ class PrimitivesEmbeddingDGCNGn(nn.Module):
         idx1 = self.encoder.last_idx[0]
         ef = get_graph_feature_with_normals_g(pts, idx=idx1).permute(0, 2, 3, 1)          # (B,N,k,7)
         normal_feature = grouped_block(ef, self.conv_normal[0].weight, self.bn_normal.weight, self.bn_normal.bias, 2,
-                                       self.bn_normal.eps, 0.2)
+                                       self.bn_normal.eps, 0.2, self.dtype)
         x = torch.cat([x_all, x_type, x_para, normal_feature], dim=1)
         x = F.relu(self.bn_seg_prob1(self.mlp_seg_prob1(x)))
         output_feats = self.mlp_seg_prob2(x).permute(0, 2, 1)                               # (B,N,emb)

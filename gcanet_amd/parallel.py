@@ -1,0 +1,65 @@
+"""Data parallelism for the hot path: one process per GPU, full replica each, ONE RCCL all-reduce of
+the flattened fp32 gradient per step over xGMI.  The reference wraps the
+model in single-process nn.DataParallel (trainer_new.py:94-96: broadcast params + scatter + gather
+every step); that design is not reproduced.  Clouds are independent (GroupNorm statistics are
+per-sample), so there is no collective inside forward/backward.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend=None):
+    """Initialise from torchrun-style env (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_*).  Returns
+    (rank, local_rank, world_size).  backend: 'nccl' (= RCCL on ROCm) on GPUs, 'gloo' on CPU."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+class FlatGradDP:
+    """Keeps every parameter's .grad as a view into one flat fp32 buffer, so the gradient exchange
+    is a single bucket: all_reduce(SUM) then scale by 1/world (about 20 MB for GCANet: ~0.25 ms on a
+    7-link xGMI ring)."""
+
+    def __init__(self, module, world_size=None):
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        self.world = world_size if world_size is not None else (dist.get_world_size() if dist.is_initialized() else 1)
+        n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        off = 0
+        for p in self.params:
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def zero_grad(self):
+        self.flat.zero_()
+
+    def sync_params(self, src=0):
+        """Make replicas identical at start (same seed already does; this is the belt-and-braces broadcast)."""
+        if self.world > 1:
+            for p in self.params:
+                dist.broadcast(p.data, src)
+
+    def all_reduce_grads(self):
+        if self.world > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            self.flat.mul_(1.0 / self.world)
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous shard [lo, hi) of n_items for `rank` (clouds are the unit; no data-path collective)."""
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)

@@ -263,3 +263,72 @@ def query_decoder(x, batch_offsets, sd, num_layer, nhead, iter_pred=False, attn_
     if iter_pred:
         res["aux_outputs"] = [{"labels": a[0], "scores": a[1], "masks": a[2], "parameters": a[3]} for a in outs[:-1]]
     return res
+
+
+# ----------------------------------------------------------------------------- whole hot path (CPU baseline + parity)
+def knn_torch(x, k, metric=0):
+    """Literal multi-threaded torch restatement of knn / knn_points_normals (M4:30-90): per-cloud
+    N x N matrix + topk.  Used for the CPU baseline timing (the C oracle is single-threaded)."""
+    out = []
+    with torch.no_grad():
+        for b in range(x.shape[0]):
+            if metric == 0:
+                xb = x[b:b + 1]
+                inner = -2 * torch.matmul(xb.transpose(2, 1), xb)
+                xx = torch.sum(xb ** 2, dim=1, keepdim=True)
+                pd = -xx - inner - xx.transpose(2, 1)
+            else:
+                p, n = x[b:b + 1, 0:3], x[b:b + 1, 3:6]
+                xx = torch.sum(p ** 2, dim=1, keepdim=True)
+                ppd = xx - 2 * torch.matmul(p.transpose(2, 1), p) + xx.transpose(2, 1)
+                npd = 2 - 2 * torch.matmul(n.transpose(2, 1), n)
+                pd = -(ppd * (1 + npd))
+            out.append(pd.topk(k=k, dim=-1)[1])
+    return torch.cat(out, 0)
+
+
+def hot_path(sd, points, normals, k, knn_fn=None, idxs=None):
+    """forward_train of PrimitivesEmbeddingDGCNGn up to pt_offsets (M4:634-747), functional, fp32.
+    sd: state dict with the reference's parameter names.  knn_fn(x, k, metric) -> idx."""
+    g = lambda n: sd[n]
+    if knn_fn is None:
+        knn_fn = lambda x, kk, metric: torch.from_numpy(knn_model(x.detach().numpy(), kk, kk, metric))
+    B, N, _ = points.shape
+    pts = torch.cat([points, normals], -1).permute(0, 2, 1)
+    used = []
+
+    def ec(inp, i, metric):
+        idx = idxs[i] if idxs is not None else knn_fn(inp, k, metric)
+        used.append(idx)
+        w = g("encoder.conv%d.0.weight" % (i + 1))[:, :, 0, 0]
+        return edgeconv_block(inp, idx, w, g("encoder.bn%d.weight" % (i + 1)), g("encoder.bn%d.bias" % (i + 1)), 2)
+
+    x1 = ec(pts, 0, 1)
+    x2 = ec(x1, 1, 0)
+    x3 = ec(x2, 2, 0)
+    xf = torch.cat((x1, x2, x3), 1)
+    h = F.relu(F.group_norm(F.conv1d(xf, g("encoder.mlp1.weight"), g("encoder.mlp1.bias")), 8,
+                            g("encoder.bnmlp1.weight"), g("encoder.bnmlp1.bias")))
+    x = torch.cat([h.max(dim=2)[0].view(B, 1024, 1).repeat(1, 1, N), xf], 1)
+    cgr = lambda t, c, b, G: F.relu(F.group_norm(F.conv1d(t, g(c + ".weight"), g(c + ".bias")), G, g(b + ".weight"), g(b + ".bias")))
+    x = cgr(x, "conv1", "bn1", 8)
+    x_all = cgr(x, "conv2", "bn2", 4)
+    x_type = cgr(x_all, "mlp_prim_prob1", "bn_prim_prob1", 4)
+    type_pp = F.conv1d(x_type, g("mlp_prim_prob2.weight"), g("mlp_prim_prob2.bias"))
+    type_forgroup = type_pp.permute(0, 2, 1)
+    type_per_point = F.log_softmax(type_pp, dim=1).permute(0, 2, 1)
+    x_para = cgr(x_all, "mlp_param_prob1", "bn_param_prob1", 4)
+    p = F.conv1d(x_para, g("mlp_param_prob2.weight"), g("mlp_param_prob2.bias")).transpose(1, 2)
+    unit = lambda v: v / (torch.norm(v, dim=-1, keepdim=True).repeat(1, 1, 3) + 1e-12)
+    param = torch.cat([p[:, :, :4], unit(p[:, :, 4:7]), p[:, :, 7:8], unit(p[:, :, 8:11]), p[:, :, 11:15],
+                       unit(p[:, :, 15:18]), p[:, :, 18:22]], 2)
+    nf = get_graph_feature_with_normals_g(pts, idx=used[0])       # M4:691 recomputes the identical kNN
+    nf = grouped_block(nf, g("conv_normal.0.weight")[:, :, 0, 0], g("bn_normal.weight"), g("bn_normal.bias"), 2)
+    x = cgr(torch.cat([x_all, x_type, x_para, nf], 1), "mlp_seg_prob1", "bn_seg_prob1", 4)
+    output_feats = F.conv1d(x, g("mlp_seg_prob2.weight"), g("mlp_seg_prob2.bias")).permute(0, 2, 1)
+    fp = cgr(torch.cat([x_all, pts], 1), "conv3", "bn3", 4).permute(0, 2, 1)
+    off_sd = {kk[len("offset_pred_block."):]: v for kk, v in sd.items() if kk.startswith("offset_pred_block.")}
+    off = offset_pred_module(pts[:, 0:3].permute(0, 2, 1), fp, output_feats, off_sd)
+    return dict(type_per_point=type_per_point, param_per_point=param,
+                semantic_scores=type_forgroup.reshape(-1, type_forgroup.shape[-1]),
+                pt_offsets=off.permute(0, 2, 1).reshape(-1, 3), output_feats=output_feats), used

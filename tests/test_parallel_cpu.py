@@ -1,0 +1,65 @@
+"""N>1 path on CPU: world_size-2 gloo processes exercising FlatGradDP / sharding (no GPU)."""
+import os
+import socket
+
+import torch
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from gcanet_amd import parallel
+    r, l, w = parallel.init_distributed("gloo")
+    torch.manual_seed(0)
+    model = nn.Sequential(nn.Linear(6, 5), nn.ReLU(), nn.Linear(5, 2))
+    dp = parallel.FlatGradDP(model)
+    dp.sync_params()
+    data = torch.arange(8 * 6, dtype=torch.float32).view(8, 6) / 10.0
+    lo, hi = parallel.shard_range(8, r, w)
+    dp.zero_grad()
+    # mean over the GLOBAL batch == average of per-rank means when shards are equal
+    model(data[lo:hi]).pow(2).mean().backward()
+    dp.all_reduce_grads()
+    q.put((r, dp.flat.clone(), (lo, hi)))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_flat_grad_allreduce_matches_single_process():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][2] == (0, 4) and res[1][2] == (4, 8)
+    torch.testing.assert_close(res[0][1], res[1][1])
+    torch.manual_seed(0)
+    model = nn.Sequential(nn.Linear(6, 5), nn.ReLU(), nn.Linear(5, 2))
+    data = torch.arange(8 * 6, dtype=torch.float32).view(8, 6) / 10.0
+    model(data).pow(2).mean().backward()
+    ref = torch.cat([p.grad.view(-1) for p in model.parameters()])
+    torch.testing.assert_close(res[0][1], ref, rtol=1e-5, atol=1e-6)
+
+
+def test_shard_range_covers_everything():
+    from gcanet_amd.parallel import shard_range
+    for n in (0, 1, 7, 8, 64):
+        for w in (1, 2, 3, 8):
+            spans = [shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
