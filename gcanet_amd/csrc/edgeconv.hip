@@ -460,6 +460,66 @@ __global__ __launch_bounds__(256) void reverse_sum_kernel(const float *__restric
     for (int j = lane; j < k; j += 64) atomicAdd(indeg + (long)b * N + ip[j], 1.f);
 }
 
+
+// ------------------------------------------------------------------ key-point edge block (offset module)
+// OFFSET_PRED_MODULE (M4:398-452) builds, for every point, k edges to a fixed set of NK key points,
+// scales the 131-channel edge feature by the KPAM weight att[n,j] and runs Conv2d(131->128)+GN+
+// LeakyReLU+max.  The conv is linear, so y[n,j,:] = att[n,j] * (U[m_j,:] - V[n,:]) with
+// U = Wf.f_key + Wp.p_key (NK rows per cloud) and V = Wp.p_n: the whole key table sits in LDS and the
+// (B,N,k,128) tensor (1 GB at B=8,N=8192,k=30) is never formed.  Same outputs as edgeconv_fwd.
+__global__ __launch_bounds__(256) void keyedge_fwd_kernel(const float *__restrict__ att, const int64_t *__restrict__ kidx,
+                                                          const float *__restrict__ U, const float *__restrict__ V,
+                                                          int N, int k, int NK, int Cout, int G, int pts_per_block,
+                                                          float *__restrict__ ymax, float *__restrict__ ymin,
+                                                          unsigned char *__restrict__ amax, unsigned char *__restrict__ amin,
+                                                          double *__restrict__ gsum) {
+  extern __shared__ float u_lds[];  // NK * Cout
+  const int lane = lane_id(), wave = wave_id();
+  const int b = blockIdx.y;
+  const float *Ub = U + (long)b * NK * Cout;
+  for (int i = threadIdx.x; i < NK * Cout; i += 256) u_lds[i] = Ub[i];
+  __syncthreads();
+  const int n_lo = blockIdx.x * pts_per_block;
+  const int n_hi = min(n_lo + pts_per_block, N);
+  const int cpg = Cout / G;
+  for (int c0 = 0; c0 < Cout; c0 += 64) {
+    const int c = c0 + lane;
+    const bool cv = c < Cout;
+    float s1 = 0.f, s2 = 0.f;
+    for (int n = n_lo + wave; n < n_hi; n += 4) {
+      const long pn = (long)b * N + n;
+      const float v = cv ? V[pn * Cout + c] : 0.f;
+      float mx = -__builtin_inff(), mn = __builtin_inff();
+      int ax = 0, an = 0;
+      for (int j = 0; j < k; ++j) {
+        const float a = att[pn * k + j];
+        const int m = (int)kidx[pn * k + j];
+        const float y = a * ((cv ? u_lds[m * Cout + c] : 0.f) - v);
+        if (y > mx) { mx = y; ax = j; }
+        if (y < mn) { mn = y; an = j; }
+        s1 += y;
+        s2 = fmaf(y, y, s2);
+      }
+      if (cv) {
+        ymax[pn * Cout + c] = mx; ymin[pn * Cout + c] = mn;
+        if (amax) { amax[pn * Cout + c] = (unsigned char)ax; amin[pn * Cout + c] = (unsigned char)an; }
+      }
+    }
+    if ((cpg % 64) == 0) {  // the 64 channels of this chunk share one group
+      double d1 = (double)s1, d2 = (double)s2;
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) { d1 += __shfl_xor(d1, o); d2 += __shfl_xor(d2, o); }
+      if (lane == 0) {
+        atomicAdd(gsum + ((long)b * G + c0 / cpg) * 2, d1);
+        atomicAdd(gsum + ((long)b * G + c0 / cpg) * 2 + 1, d2);
+      }
+    } else if (cv) {
+      atomicAdd(gsum + ((long)b * G + c / cpg) * 2, (double)s1);
+      atomicAdd(gsum + ((long)b * G + c / cpg) * 2 + 1, (double)s2);
+    }
+  }
+}
+
 template <int KSTEPS, int CW, int RWT>
 static int launch_fwd_bf16(EcArgs &a, bool with_arg, hipStream_t st) {
   constexpr int CP = KSTEPS * 8;
@@ -579,4 +639,23 @@ GCN_EXPORT int gcn_reverse_sum(const float *x_pm, const int64_t *idx, int B, int
   if (indeg) GCN_HIP(hipMemsetAsync(indeg, 0, sizeof(float) * (size_t)B * N, st));
   reverse_sum_kernel<<<dim3(cdiv(N, 4), B), 256, 0, st>>>(x_pm, idx, N, C, k, r, indeg);
   return check_launch("reverse_sum_kernel");
+}
+
+GCN_EXPORT int gcn_keyedge_fwd(const float *att, const int64_t *kidx, const float *U, const float *V, int B, int N, int k,
+                               int NK, int Cout, int G, float *ymax, float *ymin, uint8_t *amax, uint8_t *amin,
+                               double *gsum, void *stream) {
+  GCN_REQUIRE(att && kidx && U && V && ymax && ymin && gsum, "gcn_keyedge_fwd: null pointer");
+  GCN_REQUIRE((amax == nullptr) == (amin == nullptr), "gcn_keyedge_fwd: pass both amax and amin or neither");
+  GCN_REQUIRE(B >= 0 && N >= 1 && k >= 1 && k <= 255 && NK >= 1 && Cout >= 1 && G >= 1 && Cout % G == 0, "gcn_keyedge_fwd: bad shape");
+  const size_t lds = sizeof(float) * (size_t)NK * Cout;
+  GCN_REQUIRE(lds <= 150 * 1024, "gcn_keyedge_fwd: key table %zu B exceeds LDS", lds);
+  if (B == 0) return GCN_OK;
+  hipStream_t st = (hipStream_t)stream;
+  GCN_HIP(hipMemsetAsync(gsum, 0, sizeof(double) * 2 * B * G, st));
+  GCN_HIP(hipFuncSetAttribute((const void *)keyedge_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  int blocks_per_cloud = (512 + B - 1) / B;               // ~2 resident blocks per CU
+  if (blocks_per_cloud > (N + 3) / 4) blocks_per_cloud = (N + 3) / 4;
+  const int ppb = (N + blocks_per_cloud - 1) / blocks_per_cloud;
+  keyedge_fwd_kernel<<<dim3(cdiv(N, ppb), B), 256, lds, st>>>(att, kidx, U, V, N, k, NK, Cout, G, ppb, ymax, ymin, amax, amin, gsum);
+  return check_launch("keyedge_fwd_kernel");
 }

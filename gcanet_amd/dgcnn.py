@@ -296,6 +296,90 @@ def grouped_block(ef, weight, gamma, beta, groups=2, eps=1e-5, slope=0.2, dtype=
     return GroupedBlockFunction.apply(ef.float().contiguous(), weight, gamma, beta, groups, eps, slope, dtype)
 
 
+def _gn_route_backward(dout, gamma, beta, ymax, ymin, amax, amin, mean_rstd, G, slope, count_per_group):
+    """Shared first half of the closed-form backward of  max_k LeakyReLU(GroupNorm(y)) :
+    returns (jsel, coef, Ac, Bc, dgamma, dbeta) with dy[n,j,c] = coef[n,c]*[j==jsel[n,c]] + Ac[c] + Bc[c]*y[n,j,c]."""
+    Cout = gamma.shape[0]
+    cpg = Cout // G
+    B, N = ymax.shape[:2]
+    dpm = dout.permute(0, 2, 1)
+    pos = (gamma >= 0).view(1, 1, Cout)
+    ysel = torch.where(pos, ymax, ymin)
+    jsel = torch.where(pos, amax, amin).long()
+    mean = mean_rstd[:, :, 0].repeat_interleave(cpg, 1).unsqueeze(1)
+    rstd = mean_rstd[:, :, 1].repeat_interleave(cpg, 1).unsqueeze(1)
+    yhat = (ysel - mean) * rstd
+    z = yhat * gamma + beta
+    gz = dpm * torch.where(z > 0, torch.ones_like(z), torch.full_like(z, slope))
+    dbeta, dgamma = gz.sum((0, 1)), (gz * yhat).sum((0, 1))
+    t = gz * gamma
+    S1 = t.view(B, N, G, cpg).sum((1, 3))
+    S2 = (t * yhat).view(B, N, G, cpg).sum((1, 3))
+    rs, mu = mean_rstd[:, :, 1], mean_rstd[:, :, 0]
+    Bc = (-(rs * rs) * S2 / count_per_group).repeat_interleave(cpg, 1)
+    Ac = (-(rs * S1) / count_per_group).repeat_interleave(cpg, 1) - Bc * mu.repeat_interleave(cpg, 1)
+    return jsel, t * rstd, Ac, Bc, dgamma, dbeta
+
+
+class KeyEdgeBlockFunction(torch.autograd.Function):
+    """max_k LeakyReLU(GroupNorm(att[n,j] * (U[m_j] - V[n])))  -- the grouped block of the offset module
+    (csrc/edgeconv.hip: keyedge_fwd_kernel).  Backward: closed form; the dense GroupNorm coupling is
+    expressed through the (N x NK) incidence matrices A1 = sum_j att [m_j=m], A2 = sum_j att^2 [m_j=m]."""
+
+    @staticmethod
+    def forward(ctx, att, kidx, U, V, gamma, beta, groups, eps, slope):
+        B, N, k = att.shape
+        NK, Cout = U.shape[1], U.shape[2]
+        dev = att.device
+        att, kidx, U, V = att.float().contiguous(), kidx.contiguous(), U.float().contiguous(), V.float().contiguous()
+        f32 = dict(dtype=torch.float32, device=dev)
+        ymax, ymin = torch.empty(B, N, Cout, **f32), torch.empty(B, N, Cout, **f32)
+        amax = torch.empty(B, N, Cout, dtype=torch.uint8, device=dev)
+        amin = torch.empty(B, N, Cout, dtype=torch.uint8, device=dev)
+        gsum = torch.empty(B, groups, 2, dtype=torch.float64, device=dev)
+        _run("gcn_keyedge_fwd", att, _lib.ptr(att), _lib.ptr(kidx), _lib.ptr(U), _lib.ptr(V), B, N, k, NK, Cout, groups,
+             _lib.ptr(ymax), _lib.ptr(ymin), _lib.ptr(amax), _lib.ptr(amin), _lib.ptr(gsum),
+             tag="keyedge_fwd[B=%d,N=%d,k=%d,NK=%d,Cout=%d]" % (B, N, k, NK, Cout))
+        out = torch.empty(B, Cout, N, **f32)
+        mean_rstd = torch.empty(B, groups, 2, **f32)
+        ga, be = gamma.float().contiguous(), beta.float().contiguous()
+        _run("gcn_edgeconv_finish", att, _lib.ptr(ymax), _lib.ptr(ymin), _lib.ptr(gsum), _lib.ptr(ga), _lib.ptr(be),
+             B, N, k, Cout, groups, float(eps), float(slope), _lib.ptr(out), None, _lib.ptr(mean_rstd))
+        ctx.save_for_backward(att, kidx, U, V, ga, be, ymax, ymin, amax, amin, mean_rstd)
+        ctx.cfg = (groups, slope)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        att, kidx, U, V, gamma, beta, ymax, ymin, amax, amin, mean_rstd = ctx.saved_tensors
+        G, slope = ctx.cfg
+        B, N, k = att.shape
+        NK, Cout = U.shape[1], U.shape[2]
+        Mg = float((Cout // G) * N * k)
+        jsel, coef, Ac, Bc, dgamma, dbeta = _gn_route_backward(dout.float(), gamma, beta, ymax, ymin, amax, amin,
+                                                               mean_rstd, G, slope, Mg)
+        A_, B_ = Ac.unsqueeze(1), Bc.unsqueeze(1)                       # (B,1,Cout)
+        att_sel = torch.gather(att, 2, jsel)                            # (B,N,Cout)
+        m_sel = torch.gather(kidx, 2, jsel)
+        d_sel = torch.gather(U, 1, m_sel) - V
+        ca = coef * att_sel
+        a1, a2 = att.sum(2), (att * att).sum(2)
+        z_nk = torch.zeros(B, N, NK, dtype=torch.float32, device=att.device)
+        A1 = z_nk.scatter_add(2, kidx, att)
+        A2 = z_nk.scatter_add(2, kidx, att * att)
+        sum_att_y = A2 @ U - V * a2.unsqueeze(-1)
+        dV = -(ca + A_ * a1.unsqueeze(-1) + B_ * sum_att_y)
+        dU = torch.zeros_like(U).scatter_add_(1, m_sel, ca) + A1.sum(1).unsqueeze(-1) * A_ \
+            + B_ * (U * A2.sum(1).unsqueeze(-1) - A2.transpose(1, 2) @ V)
+        gat = lambda tab: torch.gather(tab.unsqueeze(1).expand(-1, N, -1), 2, kidx)      # (B,NK) -> (B,N,k)
+        datt = torch.zeros_like(att).scatter_add_(2, jsel, coef * d_sel)
+        datt = datt + gat((U * A_).sum(-1)) - (V * A_).sum(-1, keepdim=True)
+        VBU = (V * B_) @ U.transpose(1, 2)                                                  # (B,N,NK)
+        datt = datt + att * (gat((U * U * B_).sum(-1)) - 2 * torch.gather(VBU, 2, kidx)
+                             + (V * V * B_).sum(-1, keepdim=True))
+        return datt, None, dU, dV, dgamma, dbeta, None, None, None
+
+
 # ------------------------------------------------------------------------------------------
 # nn.Modules mirroring M4's hot path (same attribute / parameter names, so a reference
 # state_dict's matching keys load unchanged).
@@ -421,11 +505,10 @@ class OFFSET_PRED_MODULE(nn.Module):
         Wf, Wp = W[:, :128], W[:, 128:]
         U = key_feat @ Wf.t() + key_pts @ Wp.t()                               # (B,120,128)
         V = points @ Wp.t()                                                    # (B,N,128)
-        bi = torch.arange(B, device=points.device).view(B, 1, 1)
-        y = att.unsqueeze(-1) * (U[bi, topk_idx] - V.unsqueeze(2))             # (B,N,k,128) raw conv output
-        y = F.leaky_relu(F.group_norm(y.permute(0, 3, 1, 2), 2, self.bn1.weight, self.bn1.bias, self.bn1.eps), 0.2)
-        y = y.max(dim=-1)[0]                                                   # (B,128,N)
-        y = torch.cat([y, feature.permute(0, 2, 1)], dim=1)
+        # fused: conv output att*(U[m]-V) -> GroupNorm -> LeakyReLU -> max over k, (B,N,k,128) never formed
+        y = KeyEdgeBlockFunction.apply(att, topk_idx, U, V, self.bn1.weight, self.bn1.bias, self.bn1.num_groups,
+                                       self.bn1.eps, 0.2)                      # (B,128,N)
+        y = torch.cat([y, feature.permute(0, 2, 1).to(y.dtype)], dim=1)
         return self.mlp_offset(y)
 
 

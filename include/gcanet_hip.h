@@ -233,6 +233,15 @@ int gcn_neighbor_sum(const float *x_pm, const int64_t *idx, int B, int N, int C,
 int gcn_reverse_sum(const float *x_pm, const int64_t *idx, int B, int N, int C, int k, float *r,
                     float *indeg, void *stream);
 
+/* Fused conv + extreme/statistics half of OFFSET_PRED_MODULE's grouped block (M4:425-446): every
+ * point has k edges to a fixed set of NK key points; the KPAM-scaled Conv2d(131->128) output is
+ *   y[b,n,j,:] = att[b,n,j] * (U[b, kidx[b,n,j], :] - V[b,n,:])
+ * (U = Wf.f_key + Wp.p_key, V = Wp.p_n; the conv is linear).  att (B,N,k) f32, kidx (B,N,k) int64 in
+ * [0,NK), U (B,NK,Cout), V (B,N,Cout).  Outputs as gcn_edgeconv_fwd; feed them to gcn_edgeconv_finish. */
+int gcn_keyedge_fwd(const float *att, const int64_t *kidx, const float *U, const float *V, int B, int N,
+                    int k, int NK, int Cout, int G, float *ymax, float *ymin, uint8_t *amax,
+                    uint8_t *amin, double *gsum, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
