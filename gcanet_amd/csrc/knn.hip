@@ -49,6 +49,17 @@ struct TopK {
   }
   // insert (ckey, cidx) behind all entries with key <= ckey; the last entry falls off
   __device__ __forceinline__ void insert(float ckey, int cidx, int lane) {
+    if (KPL == 1) {
+      // all-VALU form: entries <= ckey stay; the rest take max(left neighbour, ckey) -- no
+      // scalar round trip (ballot/popcount) on the critical path
+      const float sk = wave_shr1_f(-KNN_INF, key[0]);
+      const int si = wave_shr1_i(0, idx[0]);
+      const bool keep = key[0] <= ckey;
+      const bool shift = sk > ckey;
+      idx[0] = keep ? idx[0] : (shift ? si : cidx);
+      key[0] = keep ? key[0] : (shift ? sk : ckey);
+      return;
+    }
     int pos = 0;
 #pragma unroll
     for (int s = 0; s < KPL; ++s) pos += __popcll(__ballot(key[s] <= ckey));
@@ -243,6 +254,149 @@ static int launch_knn(const KnnArgs &a, int B, hipStream_t st) {
   return check_launch("knn_select_kernel");
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Feature-space kNN (C >= 16) on the matrix cores.  v_mfma_f32_32x32x2_f32 is bit-for-bit a
+// k-ordered fmaf chain (cdna_hip_programming.md section 3), so dot(x_i, x_j) accumulated over
+// ascending channel pairs equals the oracle's scalar chain exactly and indices stay bit-exact,
+// while the VALU is left to the top-k bookkeeping.
+//   workgroup = 4 waves, each wave owns 32 queries (one MFMA row block); the query fragments stay
+//   in registers (CC/2 VGPRs).  Candidates stream through LDS in tiles of 64 ([channel][cand] f32,
+//   the global layout, fetched by LDS-DMA, double buffered) and are shared by the 4 waves.
+//   C/D layout: lane = candidate (l&31), register r = query row (r&3)+8(r>>2)+4(l>>5): every
+//   accumulator register carries TWO queries (one per half-wave), each with its own 64-entry sorted
+//   list spread across all 64 lanes -> 32 lists per wave, 64 VGPRs.
+// k <= 64 only (one list entry per lane); larger k uses knn_select_kernel.
+typedef __attribute__((ext_vector_type(16))) float knn_f32x16;
+
+template <int CC>
+__global__ __launch_bounds__(256) void knn_mfma_kernel(const float *__restrict__ x, const float *__restrict__ xxg,
+                                                       int N, int k, int step, int kout,
+                                                       int64_t *__restrict__ ind, float *__restrict__ val) {
+  constexpr int TC = 64;                 // candidates per tile
+  constexpr int ROWS = CC + 1;           // + one row of squared norms
+  constexpr int TILE_FLOATS = ROWS * TC;
+  constexpr int PIECES = (ROWS * TC * 4 + 1023) / 1024;  // 1-KiB DMA pieces (4 rows each)
+  extern __shared__ __attribute__((aligned(1024))) float tile[];  // 2 buffers of PIECES KiB
+
+  const int lane = lane_id(), wave = wave_id();
+  const int lr = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.y;
+  const int q0 = (blockIdx.x * 4 + wave) * 32;
+  const float *xb = x + (long)b * CC * N;
+  const float *xxb = xxg + (long)b * N;
+
+  // query fragments: A[i = lane&31][kk = lane>>5] for channel pair s -> x[2s + lh][q0 + lr]
+  const int qa = min(q0 + lr, N - 1);
+  float afrag[CC / 2];
+#pragma unroll
+  for (int s = 0; s < CC / 2; ++s) afrag[s] = xb[(long)(2 * s + lh) * N + qa];
+  // per-register query norms (two queries per register: one per half-wave)
+  float xxq[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) xxq[r] = xxb[min(q0 + (r & 3) + 8 * (r >> 2) + 4 * lh, N - 1)];
+
+  TopK<1> top[16][2];
+  float thrv[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    top[r][0].init();
+    top[r][1].init();
+    thrv[r] = KNN_INF;
+  }
+  const int klane = k - 1;
+
+  const int ntiles = (N + TC - 1) / TC;
+  auto issue_tile = [&](int t, int buf) {
+    int j0 = t * TC;
+    if (j0 + TC > N) j0 = N - TC;                   // tail tile: shifted back (N >= 64, N % 4 == 0 by dispatch)
+    for (int p = wave; p < PIECES; p += 4) {
+      const int row = p * 4 + (lane >> 4);          // 16 lanes x 16 B = one 256-B row of 64 candidates
+      const int j = j0 + (lane & 15) * 4;
+      const float *src = row < CC ? xb + (long)row * N + j : xxb + j;
+      if (row < ROWS)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)(tile + buf * PIECES * 256 + p * 256), 16, 0, 0);
+    }
+  };
+  (void)TILE_FLOATS;
+
+  issue_tile(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < ntiles) issue_tile(t + 1, buf ^ 1);
+    const float *tb = tile + buf * PIECES * 256;
+    const int j0 = t * TC;
+    // a clamped tail tile holds candidates [N-64, N): shift so that lane ids still map to real indices
+    const int jbase = (j0 + TC > N) ? N - TC : j0;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      knn_f32x16 acc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+      const float *bcol = tb + cb * 32 + lr;
+#pragma unroll
+      for (int s = 0; s < CC / 2; ++s)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[s], bcol[(2 * s + lh) * TC], acc, 0, 0, 0);
+      const int j = jbase + cb * 32 + lr;
+      const float xxj = tb[CC * TC + cb * 32 + lr];
+      const bool fresh = j >= j0 && j < N;          // not a re-visited (clamped) or out-of-range candidate
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float tt = 2.f * acc[r] - xxj;
+        const float pd = tt - xxq[r];
+        const float key = fresh ? -pd : KNN_INF;
+        unsigned long long m = __ballot(key < thrv[r]);
+        while (m) {
+          const int l = __ffsll((long long)m) - 1;
+          m &= m - 1;
+          const float ck = readlane_f(key, l);
+          const float th = readlane_f(thrv[r], l);
+          if (ck < th) {
+            const int cj = jbase + cb * 32 + (l & 31);
+            if (l < 32) {
+              top[r][0].insert(ck, cj, lane);
+              const float nt = readlane_f(top[r][0].key[0], klane);
+              thrv[r] = lh == 0 ? nt : thrv[r];
+            } else {
+              top[r][1].insert(ck, cj, lane);
+              const float nt = readlane_f(top[r][1].key[0], klane);
+              thrv[r] = lh == 1 ? nt : thrv[r];
+            }
+          }
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int q = q0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (q < N && lane < k && (lane % step) == 0) {
+        const long o = ((long)b * N + q) * kout + lane / step;
+        ind[o] = (int64_t)top[r][h].idx[0];
+        if (val) val[o] = -top[r][h].key[0];
+      }
+    }
+}
+
+template <int CC>
+static int launch_knn_mfma(const float *x, const float *xx, int B, int N, int k, int step, int kout, int64_t *ind,
+                           float *val, hipStream_t st) {
+  constexpr int PIECES = ((CC + 1) * 64 * 4 + 1023) / 1024;
+  const int lds = 2 * PIECES * 1024;
+  GCN_HIP(hipFuncSetAttribute((const void *)knn_mfma_kernel<CC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  knn_mfma_kernel<CC><<<dim3(cdiv(N, 128), B), 256, lds, st>>>(x, xx, N, k, step, kout, ind, val);
+  return check_launch("knn_mfma_kernel");
+}
+
 }  // namespace gcn
 
 using namespace gcn;
@@ -295,5 +449,10 @@ GCN_EXPORT int gcn_knn_model(const float *x, int B, int C, int N, int k1, int k2
   a.dist = val; a.ind = idx;
   if (metric == 1) return launch_knn<2, 6>(a, B, st);
   if (C == 3) return launch_knn<1, 3>(a, B, st);
+  if (k2 <= 64 && N >= 64 && (N % 4) == 0) {  // matrix-core path (bit-identical dot products)
+    if (C == 32) return launch_knn_mfma<32>(x, xx_ws, B, N, k2, step, kout, idx, val, st);
+    if (C == 64) return launch_knn_mfma<64>(x, xx_ws, B, N, k2, step, kout, idx, val, st);
+    if (C == 128) return launch_knn_mfma<128>(x, xx_ws, B, N, k2, step, kout, idx, val, st);
+  }
   return launch_knn<1, 0>(a, B, st);
 }

@@ -81,7 +81,8 @@ def _knn_model(x, k1, k2, metric):
 
 
 @pytest.mark.parametrize("C,N,k1,k2,metric", [
-    (3, 2048, 16, 16, 0), (3, 1000, 4, 16, 0), (64, 700, 20, 20, 0), (128, 513, 64, 64, 0),
+    (3, 2048, 16, 16, 0), (3, 1000, 4, 16, 0), (64, 700, 20, 20, 0), (128, 513, 64, 64, 0), (64, 2048, 64, 64, 0),
+    (32, 256, 8, 16, 0), (128, 1028, 33, 33, 0), (64, 64, 64, 64, 0),
     (6, 2048, 16, 16, 1), (6, 999, 80, 80, 1), (3, 300, 100, 200, 0), (9, 64, 64, 64, 0)])
 def test_knn_model_matches_oracle_exactly(dev, C, N, k1, k2, metric):
     g = torch.Generator().manual_seed(1234 + C + N)
