@@ -133,3 +133,19 @@ def test_knn_full_size_properties(dev):
     _, I = KNN(64, transpose_mode=False)(x, x)
     a = torch.sort(I.permute(0, 2, 1), dim=-1)[0]
     assert (a == s).float().mean() > 0.999
+
+
+def test_search_knn_known_answer_on_gpu(dev):
+    """The reference's only golden table (models/search_knn.py:183-243) through the drop-in SoftProjection."""
+    import json
+    import os
+    from gcanet_amd.search_knn import SoftProjection
+    ka = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "search_knn_known_answer.json")))
+    t = lambda a: torch.tensor(a, dtype=torch.float32).t().unsqueeze(0).contiguous().to(dev)
+    pc, qc, pf = t(ka["point_cloud"]), t(ka["query_cloud"]), t(ka["point_features"])
+    sp = SoftProjection(3, initial_temperature=1.0).to(dev)
+    prop = sp.propagate(pc, pf, qc)[0].t().detach().cpu().numpy()
+    np.testing.assert_allclose(prop, np.asarray(ka["expected_features_nn_3"]), atol=1.5e-3)
+    sp._temperature.data = torch.tensor(0.1, device=dev)      # sigma := 0.1**2 (search_knn.py:279)
+    proj = sp.project(qc, pc)[0].t().detach().cpu().numpy()
+    np.testing.assert_allclose(proj, np.asarray(ka["expected_nn_cloud"]), atol=1.5e-3)
