@@ -61,6 +61,17 @@ __global__ __launch_bounds__(256) void pack_x_kernel(const float *__restrict__ x
   }
 }
 
+
+// x (R, C) f32 row-major -> (R, Cp) bf16 zero padded (point-major operand of the fused kernel)
+__global__ __launch_bounds__(256) void cast_pad_bf16_kernel(const float *__restrict__ x, long R, int C, int Cp,
+                                                            unsigned short *__restrict__ y) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= R * Cp) return;
+  const long r = e / Cp;
+  const int c = (int)(e % Cp);
+  y[e] = c < C ? f32_to_bf16(x[r * C + c]) : (unsigned short)0;
+}
+
 // w (Cout, 2C) f32 -> wp (Cout, 2Cp) bf16 = [W1 | 0 | W2 - W1 | 0]
 __global__ void pack_w_kernel(const float *__restrict__ w, int Cout, int C, int Cp, unsigned short *__restrict__ wp) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -658,4 +669,13 @@ GCN_EXPORT int gcn_keyedge_fwd(const float *att, const int64_t *kidx, const floa
   const int ppb = (N + blocks_per_cloud - 1) / blocks_per_cloud;
   keyedge_fwd_kernel<<<dim3(cdiv(N, ppb), B), 256, lds, st>>>(att, kidx, U, V, N, k, NK, Cout, G, ppb, ymax, ymin, amax, amin, gsum);
   return check_launch("keyedge_fwd_kernel");
+}
+
+GCN_EXPORT int gcn_cast_pad_bf16(const float *x_pm, long rows, int C, void *x_pm_bf16, void *stream) {
+  GCN_REQUIRE(x_pm && x_pm_bf16, "gcn_cast_pad_bf16: null pointer");
+  GCN_REQUIRE(rows >= 0 && C >= 1, "gcn_cast_pad_bf16: bad shape");
+  if (rows == 0) return GCN_OK;
+  const int Cp = padded_channels(C);
+  cast_pad_bf16_kernel<<<cdiv(rows * Cp, 256), 256, 0, (hipStream_t)stream>>>(x_pm, rows, C, Cp, (unsigned short *)x_pm_bf16);
+  return check_launch("cast_pad_bf16_kernel");
 }

@@ -1,0 +1,265 @@
+// gn.hip -- GroupNorm (+ReLU) for POINT-MAJOR activations (B, N, C), forward and backward.
+//
+// The reference runs its per-point heads as Conv1d(1x1) + GroupNorm + ReLU on (B, C, N) tensors
+// (M4:556-603,644-699).  torch's GroupNorm launches one workgroup per (sample, group) for the
+// statistics -- 16..64 workgroups on a 256-CU part -- and the channel-major layout forces a transpose
+// in front of every row gather.  Here activations stay point-major (one point = one contiguous row,
+// which is also what the per-point GEMMs want) and the normalisation is two HBM-bound passes:
+//   stats : every workgroup streams a slab of rows with 16-B loads, f64 atomics per (sample, group)
+//   apply : y = ReLU((x - mu) * rstd * gamma + beta), 16-B loads/stores
+// backward is the same shape: one reduction pass (S1 = sum gamma*g, S2 = sum gamma*g*xhat per
+// (sample, group); dgamma, dbeta per channel) and one apply pass.
+// dtype 0 = f32, 1 = bf16 (statistics and arithmetic always in f32).
+#include "common.h"
+
+namespace gcn {
+
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned int)h) << 16); }
+__device__ __forceinline__ unsigned short f2bf(float f) {
+  __bf16 h = (__bf16)f;
+  return __builtin_bit_cast(unsigned short, h);
+}
+
+template <bool BF16>
+__device__ __forceinline__ void load4(const void *p, long i, float (&v)[4]) {
+  if (BF16) {
+    const ushort4 u = *reinterpret_cast<const ushort4 *>(reinterpret_cast<const unsigned short *>(p) + i);
+    v[0] = bf2f(u.x); v[1] = bf2f(u.y); v[2] = bf2f(u.z); v[3] = bf2f(u.w);
+  } else {
+    const float4 f = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(p) + i);
+    v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+  }
+}
+template <bool BF16>
+__device__ __forceinline__ void store4(void *p, long i, const float (&v)[4]) {
+  if (BF16) {
+    ushort4 u;
+    u.x = f2bf(v[0]); u.y = f2bf(v[1]); u.z = f2bf(v[2]); u.w = f2bf(v[3]);
+    *reinterpret_cast<ushort4 *>(reinterpret_cast<unsigned short *>(p) + i) = u;
+  } else {
+    *reinterpret_cast<float4 *>(reinterpret_cast<float *>(p) + i) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+// A workgroup owns rows [r0, r1) of one sample.  Thread t owns the 4 channels c4 = (t % (C/4))*4 of
+// rows t/(C/4), t/(C/4) + 256/(C/4), ... (C/4 divides 256 or is a multiple of it).
+struct Slab {
+  int c4, row0, rstep, nc4, reps;  // reps > 1 when C/4 > 256: thread also owns c4 + 1024*i
+};
+__device__ __forceinline__ Slab make_slab(int C) {
+  Slab s;
+  const int q = C / 4;
+  if (q <= 256) {
+    s.c4 = (threadIdx.x % q) * 4; s.row0 = threadIdx.x / q; s.rstep = 256 / q; s.nc4 = q; s.reps = 1;
+  } else {
+    s.c4 = threadIdx.x * 4; s.row0 = 0; s.rstep = 1; s.nc4 = q; s.reps = q / 256;
+  }
+  return s;
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const void *__restrict__ x, int N, int C, int G, int rows_per_block,
+                                                       double *__restrict__ gsum) {
+  extern __shared__ double sm[];
+  for (int i = threadIdx.x; i < 2 * G; i += 256) sm[i] = 0.0;
+  __syncthreads();
+  const int b = blockIdx.y;
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, N);
+  const Slab s = make_slab(C);
+  const int cpg = C / G;
+  for (int rep = 0; rep < s.reps; ++rep) {
+    const int c = s.c4 + rep * 1024;
+    float a1 = 0.f, a2 = 0.f;
+    for (int r = r0 + s.row0; r < r1; r += s.rstep) {
+      float v[4];
+      load4<BF16>(x, ((long)b * N + r) * C + c, v);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { a1 += v[i]; a2 = fmaf(v[i], v[i], a2); }
+    }
+    // 4 consecutive channels share a group (cpg % 4 == 0)
+    atomicAdd(&sm[(c / cpg) * 2], (double)a1);
+    atomicAdd(&sm[(c / cpg) * 2 + 1], (double)a2);
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < 2 * G) atomicAdd(gsum + (long)b * G * 2 + threadIdx.x, sm[threadIdx.x]);
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const void *__restrict__ x, const double *__restrict__ gsum,
+                                                       const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                       int N, int C, int G, float eps, int relu, void *__restrict__ y,
+                                                       float *__restrict__ mean_rstd) {
+  const int b = blockIdx.y;
+  const long per = (long)N * C / 4;
+  const int cpg = C / G;
+  const double cnt = (double)cpg * N;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < per; e += (long)gridDim.x * 256) {
+    const int c = (int)((e * 4) % C);
+    const int g = c / cpg;
+    const double m = gsum[((long)b * G + g) * 2] / cnt;
+    double var = gsum[((long)b * G + g) * 2 + 1] / cnt - m * m;
+    if (var < 0.0) var = 0.0;
+    const float mean = (float)m, rstd = (float)(1.0 / sqrt(var + (double)eps));
+    if (mean_rstd && e * 4 < C && (c % cpg) == 0) {
+      mean_rstd[((long)b * G + g) * 2] = mean;
+      mean_rstd[((long)b * G + g) * 2 + 1] = rstd;
+    }
+    float v[4];
+    load4<BF16>(x, (long)b * N * C + e * 4, v);
+    const float4 ga = *reinterpret_cast<const float4 *>(gamma + c);
+    const float4 be = *reinterpret_cast<const float4 *>(beta + c);
+    const float gg[4] = {ga.x, ga.y, ga.z, ga.w}, bb[4] = {be.x, be.y, be.z, be.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float z = (v[i] - mean) * rstd * gg[i] + bb[i];
+      v[i] = (relu && !(z > 0.f)) ? 0.f : z;
+    }
+    store4<BF16>(y, (long)b * N * C + e * 4, v);
+  }
+}
+
+// backward pass 1: S (B,G,2) = [sum gamma*g, sum gamma*g*xhat], dgamma/dbeta (C) (accumulated, pre-zeroed)
+template <bool BF16>
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const void *__restrict__ dy, const void *__restrict__ x,
+                                                            const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                            const float *__restrict__ mean_rstd, int N, int C, int G,
+                                                            int relu, int rows_per_block, double *__restrict__ S,
+                                                            float *__restrict__ dgamma, float *__restrict__ dbeta) {
+  extern __shared__ double sm[];
+  for (int i = threadIdx.x; i < 2 * G; i += 256) sm[i] = 0.0;
+  __syncthreads();
+  const int b = blockIdx.y;
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, N);
+  const Slab s = make_slab(C);
+  const int cpg = C / G;
+  for (int rep = 0; rep < s.reps; ++rep) {
+    const int c = s.c4 + rep * 1024;
+    const int g = c / cpg;
+    const float mean = mean_rstd[((long)b * G + g) * 2], rstd = mean_rstd[((long)b * G + g) * 2 + 1];
+    const float4 ga = *reinterpret_cast<const float4 *>(gamma + c);
+    const float4 be = *reinterpret_cast<const float4 *>(beta + c);
+    const float gg[4] = {ga.x, ga.y, ga.z, ga.w}, bb[4] = {be.x, be.y, be.z, be.w};
+    float dg[4] = {0.f, 0.f, 0.f, 0.f}, db[4] = {0.f, 0.f, 0.f, 0.f};
+    float s1 = 0.f, s2 = 0.f;
+    for (int r = r0 + s.row0; r < r1; r += s.rstep) {
+      float xv[4], gv[4];
+      const long o = ((long)b * N + r) * C + c;
+      load4<BF16>(x, o, xv);
+      load4<BF16>(dy, o, gv);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float xh = (xv[i] - mean) * rstd;
+        const float z = xh * gg[i] + bb[i];
+        const float gz = (relu && !(z > 0.f)) ? 0.f : gv[i];
+        dg[i] = fmaf(gz, xh, dg[i]);
+        db[i] += gz;
+        s1 = fmaf(gg[i], gz, s1);
+        s2 = fmaf(gg[i] * gz, xh, s2);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      atomicAdd(dgamma + c + i, dg[i]);
+      atomicAdd(dbeta + c + i, db[i]);
+    }
+    atomicAdd(&sm[g * 2], (double)s1);
+    atomicAdd(&sm[g * 2 + 1], (double)s2);
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < 2 * G) atomicAdd(S + (long)b * G * 2 + threadIdx.x, sm[threadIdx.x]);
+}
+
+// backward pass 2: dx = rstd * (gamma*g - S1/M - xhat*S2/M)
+template <bool BF16>
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const void *__restrict__ dy, const void *__restrict__ x,
+                                                           const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                           const float *__restrict__ mean_rstd, const double *__restrict__ S,
+                                                           int N, int C, int G, int relu, void *__restrict__ dx) {
+  const int b = blockIdx.y;
+  const long per = (long)N * C / 4;
+  const int cpg = C / G;
+  const float invM = 1.f / ((float)cpg * (float)N);
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < per; e += (long)gridDim.x * 256) {
+    const int c = (int)((e * 4) % C);
+    const int g = c / cpg;
+    const float mean = mean_rstd[((long)b * G + g) * 2], rstd = mean_rstd[((long)b * G + g) * 2 + 1];
+    const float m1 = (float)S[((long)b * G + g) * 2] * invM, m2 = (float)S[((long)b * G + g) * 2 + 1] * invM;
+    const float4 ga = *reinterpret_cast<const float4 *>(gamma + c);
+    const float4 be = *reinterpret_cast<const float4 *>(beta + c);
+    const float gg[4] = {ga.x, ga.y, ga.z, ga.w}, bb[4] = {be.x, be.y, be.z, be.w};
+    float xv[4], gv[4], o[4];
+    load4<BF16>(x, (long)b * N * C + e * 4, xv);
+    load4<BF16>(dy, (long)b * N * C + e * 4, gv);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float xh = (xv[i] - mean) * rstd;
+      const float z = xh * gg[i] + bb[i];
+      const float gz = (relu && !(z > 0.f)) ? 0.f : gv[i];
+      o[i] = rstd * (gg[i] * gz - m1 - xh * m2);
+    }
+    store4<BF16>(dx, (long)b * N * C + e * 4, o);
+  }
+}
+
+static int gn_check(const char *who, int B, int N, int C, int G, int dtype) {
+  GCN_REQUIRE(dtype == 0 || dtype == 1, "%s: dtype must be 0 (f32) or 1 (bf16)", who);
+  GCN_REQUIRE(B >= 0 && N >= 1 && C >= 4 && G >= 1 && C % G == 0, "%s: bad shape", who);
+  GCN_REQUIRE((C / G) % 4 == 0, "%s: C/G must be a multiple of 4", who);
+  GCN_REQUIRE((C / 4 <= 256 && 256 % (C / 4) == 0) || (C / 4) % 256 == 0, "%s: C=%d unsupported (C/4 must divide 256 or be a multiple of it)", who, C);
+  return GCN_OK;
+}
+
+static int slab_rows(int N, int B) {
+  int blocks = (1024 + B - 1) / B;  // ~4 workgroups per CU in total
+  int rows = (N + blocks - 1) / blocks;
+  return rows < 8 ? 8 : rows;
+}
+
+}  // namespace gcn
+
+using namespace gcn;
+
+GCN_EXPORT int gcn_gn_fwd(const void *x, int dtype, const float *gamma, const float *beta, int B, int N, int C, int G,
+                          float eps, int relu, void *y, float *mean_rstd, double *gsum_ws, void *stream) {
+  int rc = gn_check("gcn_gn_fwd", B, N, C, G, dtype);
+  if (rc) return rc;
+  GCN_REQUIRE(x && gamma && beta && y && gsum_ws, "gcn_gn_fwd: null pointer");
+  if (B == 0) return GCN_OK;
+  hipStream_t st = (hipStream_t)stream;
+  GCN_HIP(hipMemsetAsync(gsum_ws, 0, sizeof(double) * 2 * B * G, st));
+  const int rows = slab_rows(N, B);
+  const dim3 g1(cdiv(N, rows), B);
+  const int g2 = (int)(((long)N * C / 4 + 255) / 256 > 2048 ? 2048 : ((long)N * C / 4 + 255) / 256);
+  if (dtype == 1) {
+    gn_stats_kernel<true><<<g1, 256, sizeof(double) * 2 * G, st>>>(x, N, C, G, rows, gsum_ws);
+    gn_apply_kernel<true><<<dim3(g2, B), 256, 0, st>>>(x, gsum_ws, gamma, beta, N, C, G, eps, relu, y, mean_rstd);
+  } else {
+    gn_stats_kernel<false><<<g1, 256, sizeof(double) * 2 * G, st>>>(x, N, C, G, rows, gsum_ws);
+    gn_apply_kernel<false><<<dim3(g2, B), 256, 0, st>>>(x, gsum_ws, gamma, beta, N, C, G, eps, relu, y, mean_rstd);
+  }
+  return check_launch("gn_fwd");
+}
+
+GCN_EXPORT int gcn_gn_bwd(const void *dy, const void *x, int dtype, const float *gamma, const float *beta,
+                          const float *mean_rstd, int B, int N, int C, int G, int relu, void *dx, float *dgamma,
+                          float *dbeta, double *s_ws, void *stream) {
+  int rc = gn_check("gcn_gn_bwd", B, N, C, G, dtype);
+  if (rc) return rc;
+  GCN_REQUIRE(dy && x && gamma && beta && mean_rstd && dx && dgamma && dbeta && s_ws, "gcn_gn_bwd: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  GCN_HIP(hipMemsetAsync(dgamma, 0, sizeof(float) * C, st));
+  GCN_HIP(hipMemsetAsync(dbeta, 0, sizeof(float) * C, st));
+  if (B == 0) return GCN_OK;
+  GCN_HIP(hipMemsetAsync(s_ws, 0, sizeof(double) * 2 * B * G, st));
+  const int rows = slab_rows(N, B);
+  const dim3 g1(cdiv(N, rows), B);
+  const int g2 = (int)(((long)N * C / 4 + 255) / 256 > 2048 ? 2048 : ((long)N * C / 4 + 255) / 256);
+  if (dtype == 1) {
+    gn_bwd_reduce_kernel<true><<<g1, 256, sizeof(double) * 2 * G, st>>>(dy, x, gamma, beta, mean_rstd, N, C, G, relu, rows, s_ws, dgamma, dbeta);
+    gn_bwd_apply_kernel<true><<<dim3(g2, B), 256, 0, st>>>(dy, x, gamma, beta, mean_rstd, s_ws, N, C, G, relu, dx);
+  } else {
+    gn_bwd_reduce_kernel<false><<<g1, 256, sizeof(double) * 2 * G, st>>>(dy, x, gamma, beta, mean_rstd, N, C, G, relu, rows, s_ws, dgamma, dbeta);
+    gn_bwd_apply_kernel<false><<<dim3(g2, B), 256, 0, st>>>(dy, x, gamma, beta, mean_rstd, s_ws, N, C, G, relu, dx);
+  }
+  return check_launch("gn_bwd");
+}

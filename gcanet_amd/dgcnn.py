@@ -117,33 +117,22 @@ class EdgeConvFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        x, idx, W, gamma, beta, ymax, ymin, amax, amin, mean_rstd = ctx.saved_tensors
-        G, slope = ctx.cfg
+        dx_pm, dW, dgamma, dbeta = _edgeconv_backward(ctx.saved_tensors, ctx.cfg, dout, pm=False)
+        return dx_pm.permute(0, 2, 1).contiguous(), None, dW, dgamma, dbeta, None, None, None, None
+
+
+def _edgeconv_backward(saved, cfg, dout, pm):
+    """Closed-form EdgeConv backward; dout (B,Cout,N) (pm=False) or (B,N,Cout) (pm=True) -> dx (B,N,C), dW, dgamma, dbeta."""
+    if True:
+        x, idx, W, gamma, beta, ymax, ymin, amax, amin, mean_rstd = saved
+        G, slope = cfg
         B, N, C = x.shape
         k = idx.shape[2]
         Cout = W.shape[0]
-        cpg = Cout // G
-        Mg = float(cpg * N * k)
         W1, Wd = W[:, :C], W[:, C:] - W[:, :C]
-        dpm = dout.permute(0, 2, 1)                                   # (B,N,Cout) view
-        pos = (gamma >= 0).view(1, 1, Cout)
-        ysel = torch.where(pos, ymax, ymin)
-        jsel = torch.where(pos, amax, amin).long()                    # neighbour slot
+        jsel, coef, Ac, Bc, dgamma, dbeta = _gn_route_backward(dout.float(), gamma, beta, ymax, ymin, amax, amin, mean_rstd,
+                                                               G, slope, float((Cout // G) * N * k), pm=pm)
         msel = torch.gather(idx, 2, jsel)                             # (B,N,Cout) global neighbour id
-        mean = mean_rstd[:, :, 0].repeat_interleave(cpg, 1).unsqueeze(1)   # (B,1,Cout)
-        rstd = mean_rstd[:, :, 1].repeat_interleave(cpg, 1).unsqueeze(1)
-        yhat = (ysel - mean) * rstd
-        z = yhat * gamma + beta
-        gz = dpm * torch.where(z > 0, torch.ones_like(z), torch.full_like(z, slope))
-        dbeta = gz.sum((0, 1))
-        dgamma = (gz * yhat).sum((0, 1))
-        t = gz * gamma
-        S1 = t.view(B, N, G, cpg).sum((1, 3))                          # (B,G)
-        S2 = (t * yhat).view(B, N, G, cpg).sum((1, 3))
-        rs, mu = mean_rstd[:, :, 1], mean_rstd[:, :, 0]
-        Bc = (-(rs * rs) * S2 / Mg).repeat_interleave(cpg, 1)          # (B,Cout)
-        Ac = (-(rs * S1) / Mg).repeat_interleave(cpg, 1) - Bc * mu.repeat_interleave(cpg, 1)
-        coef = t * rstd                                                # sparse part of dy
         # graph aggregations
         s = torch.empty_like(x)
         r = torch.empty_like(x)
@@ -164,7 +153,7 @@ class EdgeConvFunction(torch.autograd.Function):
             + torch.einsum("bo,boc->oc", Bc, torch.einsum("oc,bcd->bod", W1, G11) + torch.einsum("oc,bcd->bod", Wd, G21))
         dWd = torch.einsum("bno,bnc->oc", D2, x)
         dW = torch.cat([dW1 - dWd, dWd], 1)
-        return dx_pm.permute(0, 2, 1).contiguous(), None, dW, dgamma, dbeta, None, None, None, None
+        return dx_pm, dW, dgamma, dbeta
 
 
 def edge_conv(x, idx, weight, gamma, beta, groups=2, dtype="bf16", eps=1e-5, slope=0.2):
@@ -218,7 +207,7 @@ class GroupedBlockFunction(torch.autograd.Function):
     MFMA kernel (rows are their own 'neighbours'); backward is the same closed form as EdgeConv."""
 
     @staticmethod
-    def forward(ctx, ef, weight, gamma, beta, groups, eps, slope, dtype="bf16"):
+    def forward(ctx, ef, weight, gamma, beta, groups, eps, slope, dtype="bf16", pm_out=False):
         B, N, k, F = ef.shape
         Cout = weight.shape[0]
         dev = ef.device
@@ -243,40 +232,21 @@ class GroupedBlockFunction(torch.autograd.Function):
             flat = ef.reshape(B, N * k, F)
             _run("gcn_edgeconv_fwd", ef, _lib.ptr(flat), _lib.ptr(w2.contiguous()), _lib.ptr(ident), 0, B, N, N * k, F,
                  k, Cout, groups, _lib.ptr(ymax), _lib.ptr(ymin), _lib.ptr(amax), _lib.ptr(amin), _lib.ptr(gsum))
-        out = torch.empty(B, Cout, N, **f32)
-        mean_rstd = torch.empty(B, groups, 2, **f32)
-        _run("gcn_edgeconv_finish", ef, _lib.ptr(ymax), _lib.ptr(ymin), _lib.ptr(gsum), _lib.ptr(gamma.contiguous()),
-             _lib.ptr(beta.contiguous()), B, N, k, Cout, groups, float(eps), float(slope), _lib.ptr(out), None,
-             _lib.ptr(mean_rstd))
+        out_cm, out_pm, mean_rstd = _finish(ymax, ymin, gsum, gamma.float().contiguous(), beta.float().contiguous(),
+                                            B, N, k, Cout, groups, eps, slope, not pm_out, pm_out)
         ctx.save_for_backward(ef, weight, gamma, beta, ymax, ymin, amax, amin, mean_rstd)
-        ctx.cfg = (groups, slope)
-        return out
+        ctx.cfg = (groups, slope, pm_out)
+        return out_pm if pm_out else out_cm
 
     @staticmethod
     def backward(ctx, dout):
         ef, W, gamma, beta, ymax, ymin, amax, amin, mean_rstd = ctx.saved_tensors
-        G, slope = ctx.cfg
+        G, slope, pm_out = ctx.cfg
         B, N, k, F = ef.shape
         Cout = W.shape[0]
-        cpg = Cout // G
-        Mg = float(cpg * N * k)
-        dpm = dout.permute(0, 2, 1)
-        pos = (gamma >= 0).view(1, 1, Cout)
-        ysel = torch.where(pos, ymax, ymin)
-        jsel = torch.where(pos, amax, amin).long()                            # (B,N,Cout) slot
-        mean = mean_rstd[:, :, 0].repeat_interleave(cpg, 1).unsqueeze(1)
-        rstd = mean_rstd[:, :, 1].repeat_interleave(cpg, 1).unsqueeze(1)
-        yhat = (ysel - mean) * rstd
-        z = yhat * gamma + beta
-        gz = dpm * torch.where(z > 0, torch.ones_like(z), torch.full_like(z, slope))
-        dbeta, dgamma = gz.sum((0, 1)), (gz * yhat).sum((0, 1))
-        t = gz * gamma
-        S1 = t.view(B, N, G, cpg).sum((1, 3))
-        S2 = (t * yhat).view(B, N, G, cpg).sum((1, 3))
-        rs, mu = mean_rstd[:, :, 1], mean_rstd[:, :, 0]
-        Bc = (-(rs * rs) * S2 / Mg).repeat_interleave(cpg, 1)
-        Ac = (-(rs * S1) / Mg).repeat_interleave(cpg, 1) - Bc * mu.repeat_interleave(cpg, 1)
-        coef = t * rstd                                                        # (B,N,Cout)
+        jsel, coef, Ac, Bc, dgamma, dbeta = _gn_route_backward(dout.float().contiguous(), gamma, beta, ymax, ymin, amax,
+                                                               amin, mean_rstd, G, slope, float((Cout // G) * N * k),
+                                                               pm=pm_out)
         # sparse part: one selected row per (point, channel)
         onehot = torch.zeros(B, N, k, Cout, dtype=torch.float32, device=ef.device).scatter_(2, jsel.unsqueeze(2), coef.unsqueeze(2))
         d_ef = onehot @ W                                                      # (B,N,k,F)
@@ -286,23 +256,23 @@ class GroupedBlockFunction(torch.autograd.Function):
         d_ef = d_ef + (Ac @ W).view(B, 1, 1, F) + torch.einsum("bnkf,bfg->bnkg", ef, T)
         gram = torch.einsum("bnkf,bnkg->bfg", ef, ef)
         dW = dW + torch.einsum("bo,bf->of", Ac, ef.sum((1, 2))) + torch.einsum("bo,og,bgf->of", Bc, W, gram)
-        return d_ef, dW, dgamma, dbeta, None, None, None, None
+        return d_ef, dW, dgamma, dbeta, None, None, None, None, None
 
 
-def grouped_block(ef, weight, gamma, beta, groups=2, eps=1e-5, slope=0.2, dtype="bf16"):
-    """ef (B,N,k,F) point-major edge features -> (B,Cout,N)."""
+def grouped_block(ef, weight, gamma, beta, groups=2, eps=1e-5, slope=0.2, dtype="bf16", pm_out=False):
+    """ef (B,N,k,F) point-major edge features -> (B,Cout,N), or (B,N,Cout) with pm_out."""
     if weight.dim() == 4:
         weight = weight[:, :, 0, 0]
-    return GroupedBlockFunction.apply(ef.float().contiguous(), weight, gamma, beta, groups, eps, slope, dtype)
+    return GroupedBlockFunction.apply(ef.float().contiguous(), weight, gamma, beta, groups, eps, slope, dtype, pm_out)
 
 
-def _gn_route_backward(dout, gamma, beta, ymax, ymin, amax, amin, mean_rstd, G, slope, count_per_group):
+def _gn_route_backward(dout, gamma, beta, ymax, ymin, amax, amin, mean_rstd, G, slope, count_per_group, pm=False):
     """Shared first half of the closed-form backward of  max_k LeakyReLU(GroupNorm(y)) :
     returns (jsel, coef, Ac, Bc, dgamma, dbeta) with dy[n,j,c] = coef[n,c]*[j==jsel[n,c]] + Ac[c] + Bc[c]*y[n,j,c]."""
     Cout = gamma.shape[0]
     cpg = Cout // G
     B, N = ymax.shape[:2]
-    dpm = dout.permute(0, 2, 1)
+    dpm = dout if pm else dout.permute(0, 2, 1)
     pos = (gamma >= 0).view(1, 1, Cout)
     ysel = torch.where(pos, ymax, ymin)
     jsel = torch.where(pos, amax, amin).long()
@@ -321,13 +291,24 @@ def _gn_route_backward(dout, gamma, beta, ymax, ymin, amax, amin, mean_rstd, G, 
     return jsel, t * rstd, Ac, Bc, dgamma, dbeta
 
 
+def _tall_skinny_tn(A, Bm, chunks=64):
+    """A^T @ B for A (B,N,P), B (B,N,Q) with N >> P,Q: split the long reduction into `chunks` batched
+    GEMMs (rocBLAS picks a 1-workgroup-per-tile kernel for the direct call: 1.7 ms at N=8192)."""
+    Bsz, N, P = A.shape
+    Q = Bm.shape[2]
+    if N % chunks != 0 or N // chunks < 16:
+        return A.transpose(1, 2) @ Bm
+    part = A.view(Bsz * chunks, N // chunks, P).transpose(1, 2) @ Bm.view(Bsz * chunks, N // chunks, Q)
+    return part.view(Bsz, chunks, P, Q).sum(1)
+
+
 class KeyEdgeBlockFunction(torch.autograd.Function):
     """max_k LeakyReLU(GroupNorm(att[n,j] * (U[m_j] - V[n])))  -- the grouped block of the offset module
     (csrc/edgeconv.hip: keyedge_fwd_kernel).  Backward: closed form; the dense GroupNorm coupling is
     expressed through the (N x NK) incidence matrices A1 = sum_j att [m_j=m], A2 = sum_j att^2 [m_j=m]."""
 
     @staticmethod
-    def forward(ctx, att, kidx, U, V, gamma, beta, groups, eps, slope):
+    def forward(ctx, att, kidx, U, V, gamma, beta, groups, eps, slope, pm_out=False):
         B, N, k = att.shape
         NK, Cout = U.shape[1], U.shape[2]
         dev = att.device
@@ -340,24 +321,21 @@ class KeyEdgeBlockFunction(torch.autograd.Function):
         _run("gcn_keyedge_fwd", att, _lib.ptr(att), _lib.ptr(kidx), _lib.ptr(U), _lib.ptr(V), B, N, k, NK, Cout, groups,
              _lib.ptr(ymax), _lib.ptr(ymin), _lib.ptr(amax), _lib.ptr(amin), _lib.ptr(gsum),
              tag="keyedge_fwd[B=%d,N=%d,k=%d,NK=%d,Cout=%d]" % (B, N, k, NK, Cout))
-        out = torch.empty(B, Cout, N, **f32)
-        mean_rstd = torch.empty(B, groups, 2, **f32)
         ga, be = gamma.float().contiguous(), beta.float().contiguous()
-        _run("gcn_edgeconv_finish", att, _lib.ptr(ymax), _lib.ptr(ymin), _lib.ptr(gsum), _lib.ptr(ga), _lib.ptr(be),
-             B, N, k, Cout, groups, float(eps), float(slope), _lib.ptr(out), None, _lib.ptr(mean_rstd))
+        out_cm, out_pm, mean_rstd = _finish(ymax, ymin, gsum, ga, be, B, N, k, Cout, groups, eps, slope, not pm_out, pm_out)
         ctx.save_for_backward(att, kidx, U, V, ga, be, ymax, ymin, amax, amin, mean_rstd)
-        ctx.cfg = (groups, slope)
-        return out
+        ctx.cfg = (groups, slope, pm_out)
+        return out_pm if pm_out else out_cm
 
     @staticmethod
     def backward(ctx, dout):
         att, kidx, U, V, gamma, beta, ymax, ymin, amax, amin, mean_rstd = ctx.saved_tensors
-        G, slope = ctx.cfg
+        G, slope, pm_out = ctx.cfg
         B, N, k = att.shape
         NK, Cout = U.shape[1], U.shape[2]
         Mg = float((Cout // G) * N * k)
-        jsel, coef, Ac, Bc, dgamma, dbeta = _gn_route_backward(dout.float(), gamma, beta, ymax, ymin, amax, amin,
-                                                               mean_rstd, G, slope, Mg)
+        jsel, coef, Ac, Bc, dgamma, dbeta = _gn_route_backward(dout.float().contiguous(), gamma, beta, ymax, ymin, amax,
+                                                               amin, mean_rstd, G, slope, Mg, pm=pm_out)
         A_, B_ = Ac.unsqueeze(1), Bc.unsqueeze(1)                       # (B,1,Cout)
         att_sel = torch.gather(att, 2, jsel)                            # (B,N,Cout)
         m_sel = torch.gather(kidx, 2, jsel)
@@ -370,14 +348,14 @@ class KeyEdgeBlockFunction(torch.autograd.Function):
         sum_att_y = A2 @ U - V * a2.unsqueeze(-1)
         dV = -(ca + A_ * a1.unsqueeze(-1) + B_ * sum_att_y)
         dU = torch.zeros_like(U).scatter_add_(1, m_sel, ca) + A1.sum(1).unsqueeze(-1) * A_ \
-            + B_ * (U * A2.sum(1).unsqueeze(-1) - A2.transpose(1, 2) @ V)
+            + B_ * (U * A2.sum(1).unsqueeze(-1) - _tall_skinny_tn(A2, V))
         gat = lambda tab: torch.gather(tab.unsqueeze(1).expand(-1, N, -1), 2, kidx)      # (B,NK) -> (B,N,k)
         datt = torch.zeros_like(att).scatter_add_(2, jsel, coef * d_sel)
         datt = datt + gat((U * A_).sum(-1)) - (V * A_).sum(-1, keepdim=True)
         VBU = (V * B_) @ U.transpose(1, 2)                                                  # (B,N,NK)
         datt = datt + att * (gat((U * U * B_).sum(-1)) - 2 * torch.gather(VBU, 2, kidx)
                              + (V * V * B_).sum(-1, keepdim=True))
-        return datt, None, dU, dV, dgamma, dbeta, None, None, None
+        return datt, None, dU, dV, dgamma, dbeta, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------
@@ -422,20 +400,29 @@ class DGCNNEncoderGn(nn.Module):
         self.bnmlp1 = nn.GroupNorm(8, 1024)
         self.last_idx = None
 
-    def forward(self, x):
-        B, _, N = x.shape
+    def forward_pm(self, x_cm, x_pm=None):
+        """Point-major core: x_cm (B,Cin,N) feeds the kNN, x_pm (B,N,Cin) the row gathers.
+        Returns (x_features (B,N,256) f32, x4 (B,1024))."""
+        from .layers import conv1x1, group_norm_relu
         k = self.k
-        idx1 = knn_points_normals(x, k, k) if self.mode == 5 else knn(x, k, k)
-        x1 = self.conv1.fused(x, idx1, self.dtype)
-        idx2 = knn(x1, k, k)
-        x2 = self.conv2.fused(x1, idx2, self.dtype)
-        idx3 = knn(x2, k, k)
-        x3 = self.conv3.fused(x2, idx3, self.dtype)
+        if x_pm is None:
+            x_pm = x_cm.transpose(1, 2).contiguous()
+        idx1 = knn_points_normals(x_cm, k, k) if self.mode == 5 else knn(x_cm, k, k)
+        x1, x1_cm = edge_conv_pm(x_pm, idx1, self.conv1._modules["0"].weight, self.bn1, self.dtype)
+        idx2 = knn(x1_cm, k, k)
+        x2, x2_cm = edge_conv_pm(x1, idx2, self.conv2._modules["0"].weight, self.bn2, self.dtype)
+        idx3 = knn(x2_cm, k, k)
+        x3, _ = edge_conv_pm(x2, idx3, self.conv3._modules["0"].weight, self.bn3, self.dtype, want_cm=False)
         self.last_idx = (idx1, idx2, idx3)
-        x_features = torch.cat((x1, x2, x3), dim=1)
-        h = F.relu(self.bnmlp1(self.mlp1(x_features)))
-        x4 = h.max(dim=2)[0]
-        return torch.cat([x4.view(B, 1024, 1).expand(-1, -1, N), x_features], 1)
+        x_features = torch.cat((x1, x2, x3), dim=2)                            # (B,N,256)
+        h = group_norm_relu(conv1x1(x_features, self.mlp1), self.bnmlp1)      # (B,N,1024)
+        return x_features, h.amax(dim=1)
+
+    def forward(self, x):
+        """Reference signature: x (B,Cin,N) -> (B,1280,N)  (M4:492-534)."""
+        B, _, N = x.shape
+        xf, x4 = self.forward_pm(x)
+        return torch.cat([x4.float().view(B, 1024, 1).expand(-1, -1, N), xf.transpose(1, 2)], 1)
 
 
 def cos_dist(instance_feature, global_instance_feature):
@@ -494,7 +481,8 @@ class OFFSET_PRED_MODULE(nn.Module):
         self.attention = KPAM(nn_nb)
         self.mlp_offset = nn.Conv1d(256, 3, 1)
 
-    def forward(self, points, feature, instance_feature):
+    def forward(self, points, feature, instance_feature, pm_out=False):
+        """points (B,N,3), feature (B,N,128), instance_feature (B,N,64) -> offsets (B,3,N) [(B,N,3) if pm_out]."""
         B, N, _ = points.shape
         sub = key_point_indices(N, self.sampling_ratio, points.device)
         key_pts, key_feat, key_emb = points[:, sub], feature[:, sub], instance_feature[:, sub]
@@ -506,6 +494,11 @@ class OFFSET_PRED_MODULE(nn.Module):
         U = key_feat @ Wf.t() + key_pts @ Wp.t()                               # (B,120,128)
         V = points @ Wp.t()                                                    # (B,N,128)
         # fused: conv output att*(U[m]-V) -> GroupNorm -> LeakyReLU -> max over k, (B,N,k,128) never formed
+        if pm_out:
+            from .layers import conv1x1
+            y = KeyEdgeBlockFunction.apply(att, topk_idx, U, V, self.bn1.weight, self.bn1.bias, self.bn1.num_groups,
+                                           self.bn1.eps, 0.2, True)            # (B,N,128)
+            return conv1x1(torch.cat([y, feature.to(y.dtype)], dim=2), self.mlp_offset)
         y = KeyEdgeBlockFunction.apply(att, topk_idx, U, V, self.bn1.weight, self.bn1.bias, self.bn1.num_groups,
                                        self.bn1.eps, 0.2)                      # (B,128,N)
         y = torch.cat([y, feature.permute(0, 2, 1).to(y.dtype)], dim=1)
@@ -543,34 +536,107 @@ class PrimitivesEmbeddingDGCNGn(nn.Module):
         return v / (torch.norm(v, dim=-1, keepdim=True) + 1e-12)
 
     def forward(self, points, normals):
-        """points, normals (B,N,3) -> dict(type_per_point, param_per_point, semantic_scores, pt_offsets,
-        output_feats) with the reference's shapes (M4:634-747)."""
+        """points, normals (B,N,3) -> dict(type_per_point (B,N,P), param_per_point (B,N,22), semantic_scores
+        (B*N,P), pt_offsets (B*N,3), output_feats (B,N,emb)) -- the reference's shapes (M4:634-747).
+        Activations are point-major (B,N,C) end to end; the reference's (B,C,N) Conv1d tensors are the same
+        values transposed.  conv1 on cat[x4 repeated, x_features] (M4:510-511,644) is evaluated as
+        W[:, :1024].x4 (once per cloud) + W[:, 1024:].x_features -- identical, 5x fewer FLOPs."""
+        from .layers import conv1x1, group_norm_relu
         B, N, _ = points.shape
-        pts = torch.cat([points, normals], dim=-1).permute(0, 2, 1).contiguous() if self.mode == 5 \
-            else points.permute(0, 2, 1).contiguous()
-        x = self.encoder(pts)
-        x = F.relu(self.bn1(self.conv1(x)))
-        x_all = F.relu(self.bn2(self.conv2(x)))
-        x_type = F.relu(self.bn_prim_prob1(self.mlp_prim_prob1(x_all)))
-        type_pp = self.mlp_prim_prob2(x_type)
-        type_forgroup = type_pp.permute(0, 2, 1)
-        type_per_point = self.logsoftmax(type_pp).permute(0, 2, 1) if "r" in self.loss_class else type_forgroup
-        x_para = F.relu(self.bn_param_prob1(self.mlp_param_prob1(x_all)))
-        p = self.mlp_param_prob2(x_para).transpose(1, 2)
+        pts = torch.cat([points, normals], dim=-1).contiguous() if self.mode == 5 else points.contiguous()   # (B,N,6)
+        pts_cm = pts.transpose(1, 2).contiguous()
+        xf, x4 = self.encoder.forward_pm(pts_cm, pts)
+        w1 = self.conv1.weight[:, :, 0]
+        h = F.linear(xf, w1[:, 1024:]) + F.linear(x4, w1[:, :1024], self.conv1.bias).unsqueeze(1)
+        x = group_norm_relu(h, self.bn1)
+        x_all = group_norm_relu(conv1x1(x, self.conv2), self.bn2)                             # (B,N,256)
+        x_type = group_norm_relu(conv1x1(x_all, self.mlp_prim_prob1), self.bn_prim_prob1)
+        type_forgroup = conv1x1(x_type, self.mlp_prim_prob2)                                  # (B,N,P)
+        type_per_point = F.log_softmax(type_forgroup.float(), dim=-1) if "r" in self.loss_class else type_forgroup
+        x_para = group_norm_relu(conv1x1(x_all, self.mlp_param_prob1), self.bn_param_prob1)
+        p = conv1x1(x_para, self.mlp_param_prob2).float()
         param_per_point = torch.cat([p[:, :, :4], self._unit(p[:, :, 4:7]), p[:, :, 7:8], self._unit(p[:, :, 8:11]),
                                      p[:, :, 11:15], self._unit(p[:, :, 15:18]), p[:, :, 18:22]], dim=2)
         # normal-feature EdgeConv: same input as encoder layer 1 -> same neighbour list (M4:691 recomputes it)
         idx1 = self.encoder.last_idx[0]
-        ef = get_graph_feature_with_normals_g(pts, idx=idx1).permute(0, 2, 3, 1)          # (B,N,k,7)
+        bi = torch.arange(B, device=pts.device).view(B, 1, 1)
+        n_i = pts[:, :, 3:6].unsqueeze(2)
+        n_j = pts[bi, idx1][..., 3:6]                                                          # (B,N,k,3)
+        angle = (n_i * n_j).sum(-1, keepdim=True).clamp(-0.99, 0.99)
+        ef = torch.cat((angle, n_j - n_i, n_i.expand_as(n_j)), dim=3)                          # (B,N,k,7)
         normal_feature = grouped_block(ef, self.conv_normal[0].weight, self.bn_normal.weight, self.bn_normal.bias, 2,
-                                       self.bn_normal.eps, 0.2, self.dtype)
-        x = torch.cat([x_all, x_type, x_para, normal_feature], dim=1)
-        x = F.relu(self.bn_seg_prob1(self.mlp_seg_prob1(x)))
-        output_feats = self.mlp_seg_prob2(x).permute(0, 2, 1)                               # (B,N,emb)
-        feat_plus = torch.cat([x_all, pts], dim=1)                                          # (B,262,N)
-        feat_plus = F.relu(self.bn3(self.conv3(feat_plus))).permute(0, 2, 1)                # (B,N,128)
+                                       self.bn_normal.eps, 0.2, self.dtype, pm_out=True)       # (B,N,64)
+        x = torch.cat([x_all, x_type, x_para, normal_feature.to(x_all.dtype)], dim=2)          # (B,N,832)
+        x = group_norm_relu(conv1x1(x, self.mlp_seg_prob1), self.bn_seg_prob1)
+        output_feats = conv1x1(x, self.mlp_seg_prob2).float()                                  # (B,N,emb)
+        feat_plus = torch.cat([x_all, pts.to(x_all.dtype)], dim=2)                             # (B,N,262)
+        feat_plus = group_norm_relu(conv1x1(feat_plus, self.conv3), self.bn3)                  # (B,N,128)
         semantic_scores = type_forgroup.reshape(-1, type_forgroup.shape[-1])
-        pt_offsets = self.offset_pred_block(pts[:, 0:3, :].permute(0, 2, 1), feat_plus, output_feats)
-        pt_offsets = pt_offsets.permute(0, 2, 1).reshape(-1, 3)
+        pt_offsets = self.offset_pred_block(pts[:, :, 0:3], feat_plus.float(), output_feats, pm_out=True)
+        pt_offsets = pt_offsets.reshape(-1, 3)
         return dict(type_per_point=type_per_point, param_per_point=param_per_point,
                     semantic_scores=semantic_scores, pt_offsets=pt_offsets, output_feats=output_feats)
+
+
+# ------------------------------------------------------------------------------------------
+# Point-major (B,N,C) fast path: same math, no layout round trips.  Used by PrimitivesEmbeddingDGCNGn.
+# ------------------------------------------------------------------------------------------
+def _finish(ymax, ymin, gsum, gamma, beta, B, N, k, Cout, groups, eps, slope, want_cm, want_pm):
+    f32 = dict(dtype=torch.float32, device=ymax.device)
+    out_cm = torch.empty(B, Cout, N, **f32) if want_cm else None
+    out_pm = torch.empty(B, N, Cout, **f32) if want_pm else None
+    mean_rstd = torch.empty(B, groups, 2, **f32)
+    _run("gcn_edgeconv_finish", ymax, _lib.ptr(ymax), _lib.ptr(ymin), _lib.ptr(gsum), _lib.ptr(gamma), _lib.ptr(beta),
+         B, N, k, Cout, groups, float(eps), float(slope), _lib.ptr(out_cm), _lib.ptr(out_pm), _lib.ptr(mean_rstd))
+    return out_cm, out_pm, mean_rstd
+
+
+class EdgeConvPMFunction(torch.autograd.Function):
+    """EdgeConv on point-major x (B,N,C) f32 -> (out_pm (B,N,Cout), out_cm (B,Cout,N) or None).
+    out_cm is a non-differentiable copy in the channel-major layout the kNN kernels read."""
+
+    @staticmethod
+    def forward(ctx, x, idx, weight, gamma, beta, groups, dtype, eps, slope, want_cm):
+        _lib.require_cuda(x, idx)
+        B, N, C = x.shape
+        k = idx.shape[2]
+        Cout = weight.shape[0]
+        dev = x.device
+        x = x.float().contiguous()
+        idx = idx.contiguous()
+        w = weight.float().contiguous()
+        ga, be = gamma.float().contiguous(), beta.float().contiguous()
+        f32 = dict(dtype=torch.float32, device=dev)
+        ymax, ymin = torch.empty(B, N, Cout, **f32), torch.empty(B, N, Cout, **f32)
+        amax = torch.empty(B, N, Cout, dtype=torch.uint8, device=dev)
+        amin = torch.empty(B, N, Cout, dtype=torch.uint8, device=dev)
+        gsum = torch.empty(B, groups, 2, dtype=torch.float64, device=dev)
+        if dtype == "bf16":
+            Cp = _lib.lib().gcn_edgeconv_padded_channels(C)
+            x_bf = torch.empty(B, N, Cp, dtype=torch.bfloat16, device=dev)
+            wp = torch.empty(Cout, 2 * Cp, dtype=torch.bfloat16, device=dev)
+            _run("gcn_cast_pad_bf16", x, _lib.ptr(x), B * N, C, _lib.ptr(x_bf))
+            _run("gcn_edgeconv_pack_w", x, _lib.ptr(w), Cout, C, _lib.ptr(wp))
+            _run("gcn_edgeconv_fwd", x, _lib.ptr(x_bf), _lib.ptr(wp), _lib.ptr(idx), 1, B, N, N, C, k, Cout, groups,
+                 _lib.ptr(ymax), _lib.ptr(ymin), _lib.ptr(amax), _lib.ptr(amin), _lib.ptr(gsum),
+                 tag="edgeconv_fwd[B=%d,N=%d,k=%d,C=%d,Cout=%d]" % (B, N, k, C, Cout))
+        else:
+            _run("gcn_edgeconv_fwd", x, _lib.ptr(x), _lib.ptr(w), _lib.ptr(idx), 0, B, N, N, C, k, Cout, groups,
+                 _lib.ptr(ymax), _lib.ptr(ymin), _lib.ptr(amax), _lib.ptr(amin), _lib.ptr(gsum))
+        out_cm, out_pm, mean_rstd = _finish(ymax, ymin, gsum, ga, be, B, N, k, Cout, groups, eps, slope, want_cm, True)
+        ctx.save_for_backward(x, idx, w, ga, be, ymax, ymin, amax, amin, mean_rstd)
+        ctx.cfg = (groups, slope)
+        if out_cm is None:
+            out_cm = torch.empty(0, device=dev)
+        ctx.mark_non_differentiable(out_cm)
+        return out_pm, out_cm
+
+    @staticmethod
+    def backward(ctx, dout_pm, _unused):
+        dx_pm, dW, dgamma, dbeta = _edgeconv_backward(ctx.saved_tensors, ctx.cfg, dout_pm.contiguous(), pm=True)
+        return dx_pm, None, dW, dgamma, dbeta, None, None, None, None, None
+
+
+def edge_conv_pm(x_pm, idx, conv_weight, gn, dtype="bf16", want_cm=True):
+    w = conv_weight[:, :, 0, 0] if conv_weight.dim() == 4 else conv_weight
+    return EdgeConvPMFunction.apply(x_pm, idx, w, gn.weight, gn.bias, gn.num_groups, dtype, gn.eps, 0.2, want_cm)

@@ -215,6 +215,10 @@ int gcn_edgeconv_fwd(const void *x_pm, const void *w, const int64_t *idx, int dt
                      int NX, int C, int k, int Cout, int G, float *ymax, float *ymin, uint8_t *amax,
                      uint8_t *amin, double *gsum, void *stream);
 
+/* Point-major operand preparation when activations are already (rows, C) f32: cast to bf16 and zero-pad
+ * the channel axis to gcn_edgeconv_padded_channels(C) (no transpose, unlike gcn_edgeconv_pack_x). */
+int gcn_cast_pad_bf16(const float *x_pm, long rows, int C, void *x_pm_bf16, void *stream);
+
 /* GroupNorm(G, Cout, eps) + LeakyReLU(slope) on the routed extreme:
  *   out_cm (B,Cout,N) f32 (the reference's layout) and/or out_pm (B,N,Cout); either may be NULL
  *   mean_rstd (B,G,2) f32 (may be NULL): statistics for backward. */
@@ -241,6 +245,22 @@ int gcn_reverse_sum(const float *x_pm, const int64_t *idx, int B, int N, int C, 
 int gcn_keyedge_fwd(const float *att, const int64_t *kidx, const float *U, const float *V, int B, int N,
                     int k, int NK, int Cout, int G, float *ymax, float *ymin, uint8_t *amax,
                     uint8_t *amin, double *gsum, void *stream);
+
+/* ------------------------------------------- GroupNorm(+ReLU), point-major (B,N,C) ------ */
+
+/* Replaces the `F.relu(self.bnX(self.convX(x)))` normalisation of the per-point heads (M4:644-726;
+ * torch GroupNorm on (B,C,N)) for POINT-MAJOR activations x (B,N,C), dtype 0 = f32 / 1 = bf16
+ * (statistics always f32/f64).  y = [ReLU]((x - mean_g) * rstd_g * gamma_c + beta_c), statistics per
+ * (sample, group) over N*(C/G) elements.  Constraints: (C/G) % 4 == 0; C/4 divides 256 or is a
+ * multiple of 256.  mean_rstd (B,G,2) f32 is written for backward; gsum_ws (B,G,2) f64 workspace. */
+int gcn_gn_fwd(const void *x, int dtype, const float *gamma, const float *beta, int B, int N, int C,
+               int G, float eps, int relu, void *y, float *mean_rstd, double *gsum_ws, void *stream);
+
+/* Backward of the above: dx (same dtype as x), dgamma/dbeta (C) f32 (zeroed by the call),
+ * s_ws (B,G,2) f64 workspace. */
+int gcn_gn_bwd(const void *dy, const void *x, int dtype, const float *gamma, const float *beta,
+               const float *mean_rstd, int B, int N, int C, int G, int relu, void *dx, float *dgamma,
+               float *dbeta, double *s_ws, void *stream);
 
 #ifdef __cplusplus
 }

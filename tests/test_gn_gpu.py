@@ -1,0 +1,33 @@
+"""GPU parity: point-major GroupNorm(+ReLU) (csrc/gn.hip) vs torch.nn.functional.group_norm in fp32."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("B,N,C,G", [(2, 300, 64, 2), (1, 1000, 256, 4), (2, 513, 512, 8), (1, 128, 1024, 8), (2, 77, 128, 4)])
+@pytest.mark.parametrize("relu", [True, False])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_group_norm_relu_fwd_bwd(dev, B, N, C, G, relu, dtype):
+    from gcanet_amd.layers import GroupNormReLUFunction
+    g = torch.Generator().manual_seed(B + N + C)
+    x = (torch.randn(B, N, C, generator=g) * 2 + 0.5).to(dtype).float()
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g) * 0.3
+    gy = torch.randn(B, N, C, generator=g).to(dtype).float()
+    xs = [v.clone().requires_grad_() for v in (x, gamma, beta)]
+    ref = F.group_norm(xs[0].permute(0, 2, 1), G, xs[1], xs[2], 1e-5)
+    ref = (F.relu(ref) if relu else ref).permute(0, 2, 1)
+    (ref * gy).sum().backward()
+    xd = [x.to(dtype).to(dev).requires_grad_(), gamma.to(dev).requires_grad_(), beta.to(dev).requires_grad_()]
+    y = GroupNormReLUFunction.apply(xd[0], xd[1], xd[2], G, 1e-5, relu)
+    assert y.dtype == dtype
+    tol = dict(rtol=1e-4, atol=1e-4) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+    np.testing.assert_allclose(y.float().detach().cpu().numpy(), ref.detach().numpy(), **tol)
+    (y.float() * gy.to(dev)).sum().backward()
+    for a, b, name in zip(xd, xs, ("dx", "dgamma", "dbeta")):
+        r = b.grad.numpy()
+        t2 = dict(rtol=1e-3, atol=1e-4 * max(1.0, np.abs(r).max())) if dtype == torch.float32 else \
+            dict(rtol=5e-2, atol=2e-2 * max(1.0, np.abs(r).max()))
+        np.testing.assert_allclose(a.grad.float().cpu().numpy(), r, err_msg=name, **t2)
