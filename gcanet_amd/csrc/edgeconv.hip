@@ -531,6 +531,72 @@ __global__ __launch_bounds__(256) void keyedge_fwd_kernel(const float *__restric
   }
 }
 
+
+// Backward of the key-point edge block.  dy[n,j,c] = coef[n,c]*[j == jsel[n,c]] + A[b,c] + B[b,c]*y[n,j,c]
+// (sparse routed gradient + GroupNorm coupling, see gcanet_amd/dgcnn.py) with y = att*(U[m]-V):
+//   datt[n,j] = sum_c dy*(U[m,c]-V[n,c]);  dV[n,c] = -sum_j att*dy;  dU[m,c] = sum_{(n,j)->m} att*dy.
+// One wave per point, lanes across channels; U and the dU accumulator live in LDS (one flush of
+// contiguous f32 atomics per workgroup).
+__global__ __launch_bounds__(256) void keyedge_bwd_kernel(const float *__restrict__ att, const int64_t *__restrict__ kidx,
+                                                          const float *__restrict__ U, const float *__restrict__ V,
+                                                          const float *__restrict__ coef, const int64_t *__restrict__ jsel,
+                                                          const float *__restrict__ Ac, const float *__restrict__ Bc,
+                                                          int N, int k, int NK, int Cout, int pts_per_block,
+                                                          float *__restrict__ datt, float *__restrict__ dV,
+                                                          float *__restrict__ dU) {
+  extern __shared__ float lds_f[];  // U table, then dU accumulator (NK*Cout each)
+  float *u_lds = lds_f, *du_lds = lds_f + NK * Cout;
+  const int lane = lane_id(), wave = wave_id();
+  const int b = blockIdx.y;
+  for (int i = threadIdx.x; i < NK * Cout; i += 256) {
+    u_lds[i] = U[(long)b * NK * Cout + i];
+    du_lds[i] = 0.f;
+  }
+  __syncthreads();
+  const int n_lo = blockIdx.x * pts_per_block;
+  const int n_hi = min(n_lo + pts_per_block, N);
+  for (int n = n_lo + wave; n < n_hi; n += 4) {
+    const long pn = (long)b * N + n;
+    float pj[32];  // per-lane partial of datt[n,j] (k <= 32)
+#pragma unroll
+    for (int j = 0; j < 32; ++j) pj[j] = 0.f;
+    for (int c0 = 0; c0 < Cout; c0 += 64) {
+      const int c = c0 + lane;
+      const bool cv = c < Cout;
+      const float v = cv ? V[pn * Cout + c] : 0.f;
+      const float a_c = cv ? Ac[(long)b * Cout + c] : 0.f, b_c = cv ? Bc[(long)b * Cout + c] : 0.f;
+      const float cf = cv ? coef[pn * Cout + c] : 0.f;
+      const int js = cv ? (int)jsel[pn * Cout + c] : -1;
+      float dv = 0.f;
+#pragma unroll
+      for (int j = 0; j < 32; ++j) {
+        if (j < k) {
+          const float a = att[pn * k + j];
+          const int m = (int)kidx[pn * k + j];
+          const float d = (cv ? u_lds[m * Cout + c] : 0.f) - v;
+          const float dy = (j == js ? cf : 0.f) + a_c + b_c * (a * d);
+          const float ady = a * dy;
+          dv -= ady;
+          if (cv) atomicAdd(&du_lds[m * Cout + c], ady);
+          pj[j] = fmaf(dy, d, pj[j]);
+        }
+      }
+      if (cv) dV[pn * Cout + c] = dv;
+    }
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      if (j < k) {
+        float t = pj[j];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) t += __shfl_xor(t, o);
+        if (lane == 0) datt[pn * k + j] = t;
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < NK * Cout; i += 256) atomicAdd(dU + (long)b * NK * Cout + i, du_lds[i]);
+}
+
 template <int KSTEPS, int CW, int RWT>
 static int launch_fwd_bf16(EcArgs &a, bool with_arg, hipStream_t st) {
   constexpr int CP = KSTEPS * 8;
@@ -678,4 +744,22 @@ GCN_EXPORT int gcn_cast_pad_bf16(const float *x_pm, long rows, int C, void *x_pm
   const int Cp = padded_channels(C);
   cast_pad_bf16_kernel<<<cdiv(rows * Cp, 256), 256, 0, (hipStream_t)stream>>>(x_pm, rows, C, Cp, (unsigned short *)x_pm_bf16);
   return check_launch("cast_pad_bf16_kernel");
+}
+
+GCN_EXPORT int gcn_keyedge_bwd(const float *att, const int64_t *kidx, const float *U, const float *V, const float *coef,
+                               const int64_t *jsel, const float *Ac, const float *Bc, int B, int N, int k, int NK,
+                               int Cout, float *datt, float *dV, float *dU, void *stream) {
+  GCN_REQUIRE(att && kidx && U && V && coef && jsel && Ac && Bc && datt && dV && dU, "gcn_keyedge_bwd: null pointer");
+  GCN_REQUIRE(B >= 0 && N >= 1 && k >= 1 && k <= 32 && NK >= 1 && Cout >= 1, "gcn_keyedge_bwd: bad shape (need k <= 32)");
+  const size_t lds = sizeof(float) * 2 * (size_t)NK * Cout;
+  GCN_REQUIRE(lds <= 150 * 1024, "gcn_keyedge_bwd: key tables %zu B exceed LDS", lds);
+  if (B == 0) return GCN_OK;
+  hipStream_t st = (hipStream_t)stream;
+  GCN_HIP(hipMemsetAsync(dU, 0, sizeof(float) * (size_t)B * NK * Cout, st));
+  GCN_HIP(hipFuncSetAttribute((const void *)keyedge_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  int blocks_per_cloud = (256 + B - 1) / B;
+  if (blocks_per_cloud > (N + 3) / 4) blocks_per_cloud = (N + 3) / 4;
+  const int ppb = (N + blocks_per_cloud - 1) / blocks_per_cloud;
+  keyedge_bwd_kernel<<<dim3(cdiv(N, ppb), B), 256, lds, st>>>(att, kidx, U, V, coef, jsel, Ac, Bc, N, k, NK, Cout, ppb, datt, dV, dU);
+  return check_launch("keyedge_bwd_kernel");
 }

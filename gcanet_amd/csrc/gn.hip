@@ -127,6 +127,10 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const void *__restri
                                                             float *__restrict__ dgamma, float *__restrict__ dbeta) {
   extern __shared__ double sm[];
   for (int i = threadIdx.x; i < 2 * G; i += 256) sm[i] = 0.0;
+  {
+    float *cs0 = reinterpret_cast<float *>(sm + 2 * G);
+    for (int i = threadIdx.x; i < 2 * C; i += 256) cs0[i] = 0.f;
+  }
   __syncthreads();
   const int b = blockIdx.y;
   const int r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, N);
@@ -157,16 +161,26 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const void *__restri
         s2 = fmaf(gg[i] * gz, xh, s2);
       }
     }
+    // per-channel partials: combine the row slices of the workgroup in LDS, then ONE global atomic per
+    // (workgroup, channel) -- per-thread global atomics on C addresses were 14x contended
+    float *cs = reinterpret_cast<float *>(sm + 2 * G);   // [2][C]
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      atomicAdd(dgamma + c + i, dg[i]);
-      atomicAdd(dbeta + c + i, db[i]);
+      atomicAdd(&cs[c + i], dg[i]);
+      atomicAdd(&cs[C + c + i], db[i]);
     }
     atomicAdd(&sm[g * 2], (double)s1);
     atomicAdd(&sm[g * 2 + 1], (double)s2);
   }
   __syncthreads();
   if ((int)threadIdx.x < 2 * G) atomicAdd(S + (long)b * G * 2 + threadIdx.x, sm[threadIdx.x]);
+  {
+    const float *cs = reinterpret_cast<const float *>(sm + 2 * G);
+    for (int i = threadIdx.x; i < C; i += 256) {
+      atomicAdd(dgamma + i, cs[i]);
+      atomicAdd(dbeta + i, cs[C + i]);
+    }
+  }
 }
 
 // backward pass 2: dx = rstd * (gamma*g - S1/M - xhat*S2/M)
@@ -210,7 +224,7 @@ static int gn_check(const char *who, int B, int N, int C, int G, int dtype) {
 }
 
 static int slab_rows(int N, int B) {
-  int blocks = (1024 + B - 1) / B;  // ~4 workgroups per CU in total
+  int blocks = (512 + B - 1) / B;  // ~2 workgroups per CU in total
   int rows = (N + blocks - 1) / blocks;
   return rows < 8 ? 8 : rows;
 }
@@ -255,10 +269,10 @@ GCN_EXPORT int gcn_gn_bwd(const void *dy, const void *x, int dtype, const float 
   const dim3 g1(cdiv(N, rows), B);
   const int g2 = (int)(((long)N * C / 4 + 255) / 256 > 2048 ? 2048 : ((long)N * C / 4 + 255) / 256);
   if (dtype == 1) {
-    gn_bwd_reduce_kernel<true><<<g1, 256, sizeof(double) * 2 * G, st>>>(dy, x, gamma, beta, mean_rstd, N, C, G, relu, rows, s_ws, dgamma, dbeta);
+    gn_bwd_reduce_kernel<true><<<g1, 256, sizeof(double) * 2 * G + sizeof(float) * 2 * C, st>>>(dy, x, gamma, beta, mean_rstd, N, C, G, relu, rows, s_ws, dgamma, dbeta);
     gn_bwd_apply_kernel<true><<<dim3(g2, B), 256, 0, st>>>(dy, x, gamma, beta, mean_rstd, s_ws, N, C, G, relu, dx);
   } else {
-    gn_bwd_reduce_kernel<false><<<g1, 256, sizeof(double) * 2 * G, st>>>(dy, x, gamma, beta, mean_rstd, N, C, G, relu, rows, s_ws, dgamma, dbeta);
+    gn_bwd_reduce_kernel<false><<<g1, 256, sizeof(double) * 2 * G + sizeof(float) * 2 * C, st>>>(dy, x, gamma, beta, mean_rstd, N, C, G, relu, rows, s_ws, dgamma, dbeta);
     gn_bwd_apply_kernel<false><<<dim3(g2, B), 256, 0, st>>>(dy, x, gamma, beta, mean_rstd, s_ws, N, C, G, relu, dx);
   }
   return check_launch("gn_bwd");

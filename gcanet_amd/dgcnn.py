@@ -247,10 +247,11 @@ class GroupedBlockFunction(torch.autograd.Function):
         jsel, coef, Ac, Bc, dgamma, dbeta = _gn_route_backward(dout.float().contiguous(), gamma, beta, ymax, ymin, amax,
                                                                amin, mean_rstd, G, slope, float((Cout // G) * N * k),
                                                                pm=pm_out)
-        # sparse part: one selected row per (point, channel)
-        onehot = torch.zeros(B, N, k, Cout, dtype=torch.float32, device=ef.device).scatter_(2, jsel.unsqueeze(2), coef.unsqueeze(2))
-        d_ef = onehot @ W                                                      # (B,N,k,F)
-        dW = torch.einsum("bnko,bnkf->of", onehot, ef)
+        # sparse part: one selected edge row per (point, channel) -- never a (B,N,k,Cout) one-hot
+        jx = jsel.unsqueeze(-1).expand(-1, -1, -1, F)                          # (B,N,Cout,F)
+        contrib = coef.unsqueeze(-1) * W.view(1, 1, Cout, F)                   # coef[n,c] * W[c,:]
+        d_ef = torch.zeros_like(ef).scatter_add_(2, jx, contrib)               # (B,N,k,F)
+        dW = torch.einsum("bno,bnof->of", coef, torch.gather(ef, 2, jx))
         # dense part: dy = A + B*y, y = ef.W^T
         T = torch.einsum("of,bo,og->bfg", W, Bc, W)                            # (B,F,F)
         d_ef = d_ef + (Ac @ W).view(B, 1, 1, F) + torch.einsum("bnkf,bfg->bnkg", ef, T)
@@ -336,6 +337,13 @@ class KeyEdgeBlockFunction(torch.autograd.Function):
         Mg = float((Cout // G) * N * k)
         jsel, coef, Ac, Bc, dgamma, dbeta = _gn_route_backward(dout.float().contiguous(), gamma, beta, ymax, ymin, amax,
                                                                amin, mean_rstd, G, slope, Mg, pm=pm_out)
+        if k <= 32:
+            datt, dV, dU = torch.empty_like(att), torch.empty_like(V), torch.empty_like(U)
+            _run("gcn_keyedge_bwd", att, _lib.ptr(att), _lib.ptr(kidx), _lib.ptr(U), _lib.ptr(V), _lib.ptr(coef.contiguous()),
+                 _lib.ptr(jsel.contiguous()), _lib.ptr(Ac.contiguous()), _lib.ptr(Bc.contiguous()), B, N, k, NK, Cout,
+                 _lib.ptr(datt), _lib.ptr(dV), _lib.ptr(dU))
+            return datt, None, dU, dV, dgamma, dbeta, None, None, None, None
+        # generic-k fallback in torch ops (incidence matrices A1 = sum_j att [m_j=m], A2 = sum_j att^2 [m_j=m])
         A_, B_ = Ac.unsqueeze(1), Bc.unsqueeze(1)                       # (B,1,Cout)
         att_sel = torch.gather(att, 2, jsel)                            # (B,N,Cout)
         m_sel = torch.gather(kidx, 2, jsel)

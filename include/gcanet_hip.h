@@ -246,6 +246,14 @@ int gcn_keyedge_fwd(const float *att, const int64_t *kidx, const float *U, const
                     int k, int NK, int Cout, int G, float *ymax, float *ymin, uint8_t *amax,
                     uint8_t *amin, double *gsum, void *stream);
 
+/* Backward of gcn_keyedge_fwd given the routed/affine decomposition of the conv-output gradient
+ *   dy[b,n,j,c] = coef[b,n,c]*[j == jsel[b,n,c]] + Ac[b,c] + Bc[b,c]*y[b,n,j,c]
+ * (coef (B,N,Cout) f32, jsel (B,N,Cout) int64 neighbour slot, Ac/Bc (B,Cout) f32).  Writes
+ * datt (B,N,k), dV (B,N,Cout), dU (B,NK,Cout) (zeroed by the call).  k <= 32. */
+int gcn_keyedge_bwd(const float *att, const int64_t *kidx, const float *U, const float *V,
+                    const float *coef, const int64_t *jsel, const float *Ac, const float *Bc, int B,
+                    int N, int k, int NK, int Cout, float *datt, float *dV, float *dU, void *stream);
+
 /* ------------------------------------------- GroupNorm(+ReLU), point-major (B,N,C) ------ */
 
 /* Replaces the `F.relu(self.bnX(self.convX(x)))` normalisation of the per-point heads (M4:644-726;
