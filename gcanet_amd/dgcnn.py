@@ -121,6 +121,11 @@ class EdgeConvFunction(torch.autograd.Function):
         return dx_pm.permute(0, 2, 1).contiguous(), None, dW, dgamma, dbeta, None, None, None, None
 
 
+def _ts2(a, b):
+    from .layers import tall_skinny_tn
+    return tall_skinny_tn(a, b)
+
+
 def _edgeconv_backward(saved, cfg, dout, pm):
     """Closed-form EdgeConv backward; dout (B,Cout,N) (pm=False) or (B,N,Cout) (pm=True) -> dx (B,N,C), dW, dgamma, dbeta."""
     if True:
@@ -146,12 +151,13 @@ def _edgeconv_backward(saved, cfg, dout, pm):
         D1 = Dsp + indeg.unsqueeze(2) * (Ac.unsqueeze(1) + Bc.unsqueeze(1) * P1) + Bc.unsqueeze(1) * (r @ Wd.t())
         dx_pm = D1 @ W1 + D2 @ Wd                                      # (B,N,C)
         # weight gradients
-        G11 = torch.einsum("bnc,bn,bnd->bcd", x, indeg, x)             # X^T diag(indeg) X
-        G21 = torch.einsum("bnc,bnd->bcd", x, s)                       # X^T S
+        G11 = _tall_skinny_tn(x * indeg.unsqueeze(2), x)               # X^T diag(indeg) X   (B,C,C)
+        G21 = _tall_skinny_tn(x, s)                                    # X^T S
         ssum = s.sum(1)                                                # (B,C)
-        dW1 = torch.einsum("bno,bnc->oc", Dsp, x) + torch.einsum("bo,bc->oc", Ac, ssum) \
+        xf2 = x.reshape(B * N, C)
+        dW1 = _ts2(Dsp.reshape(B * N, Cout), xf2) + torch.einsum("bo,bc->oc", Ac, ssum) \
             + torch.einsum("bo,boc->oc", Bc, torch.einsum("oc,bcd->bod", W1, G11) + torch.einsum("oc,bcd->bod", Wd, G21))
-        dWd = torch.einsum("bno,bnc->oc", D2, x)
+        dWd = _ts2(D2.reshape(B * N, Cout), xf2)
         dW = torch.cat([dW1 - dWd, dWd], 1)
         return dx_pm, dW, dgamma, dbeta
 
@@ -549,13 +555,13 @@ class PrimitivesEmbeddingDGCNGn(nn.Module):
         Activations are point-major (B,N,C) end to end; the reference's (B,C,N) Conv1d tensors are the same
         values transposed.  conv1 on cat[x4 repeated, x_features] (M4:510-511,644) is evaluated as
         W[:, :1024].x4 (once per cloud) + W[:, 1024:].x_features -- identical, 5x fewer FLOPs."""
-        from .layers import conv1x1, group_norm_relu
+        from .layers import conv1x1, group_norm_relu, linear_pm
         B, N, _ = points.shape
         pts = torch.cat([points, normals], dim=-1).contiguous() if self.mode == 5 else points.contiguous()   # (B,N,6)
         pts_cm = pts.transpose(1, 2).contiguous()
         xf, x4 = self.encoder.forward_pm(pts_cm, pts)
         w1 = self.conv1.weight[:, :, 0]
-        h = F.linear(xf, w1[:, 1024:]) + F.linear(x4, w1[:, :1024], self.conv1.bias).unsqueeze(1)
+        h = linear_pm(xf, w1[:, 1024:]) + F.linear(x4, w1[:, :1024], self.conv1.bias).unsqueeze(1)
         x = group_norm_relu(h, self.bn1)
         x_all = group_norm_relu(conv1x1(x, self.conv2), self.bn2)                             # (B,N,256)
         x_type = group_norm_relu(conv1x1(x_all, self.mlp_prim_prob1), self.bn_prim_prob1)

@@ -51,6 +51,47 @@ def group_norm_relu(x, gn, relu=True):
     return GroupNormReLUFunction.apply(x, gn.weight, gn.bias, gn.num_groups, gn.eps, relu)
 
 
+def tall_skinny_tn(a, b, chunks=32):
+    """a^T @ b for a (M,P), b (M,Q) with M >> P,Q (weight-gradient shape).  The library picks a tile
+    config with a few dozen workgroups for the direct call (each looping over all M rows: 150-350 us at
+    M=65536 on MI355X); splitting the long reduction into `chunks` batched GEMMs + a sum fills the chip."""
+    M = a.shape[0]
+    if M % chunks != 0 or M // chunks < 64:
+        return a.t() @ b
+    part = torch.bmm(a.view(chunks, M // chunks, -1).transpose(1, 2), b.view(chunks, M // chunks, -1))
+    return part.sum(0)
+
+
+class LinearPMFunction(torch.autograd.Function):
+    """y = x @ W^T + b on point-major rows with a split-K weight gradient (see tall_skinny_tn).
+    Runs in the autocast dtype (bf16 under torch.autocast, as the plain F.linear would)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        dt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else x.dtype
+        xc, wc = x.to(dt), weight.to(dt)
+        ctx.save_for_backward(xc, wc)
+        ctx.has_bias = bias is not None
+        ctx.in_dtypes = (x.dtype, weight.dtype)
+        with torch.autocast("cuda", enabled=False):
+            return torch.nn.functional.linear(xc, wc, None if bias is None else bias.to(dt))
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, wc = ctx.saved_tensors
+        dy = dy.to(xc.dtype).contiguous()
+        with torch.autocast("cuda", enabled=False):
+            dx = (dy @ wc).to(ctx.in_dtypes[0])
+            rows = dy.reshape(-1, dy.shape[-1])
+            dw = tall_skinny_tn(rows, xc.reshape(-1, xc.shape[-1])).to(ctx.in_dtypes[1])
+            db = rows.float().sum(0) if ctx.has_bias else None
+        return dx, dw, db
+
+
+def linear_pm(x, weight, bias=None):
+    return LinearPMFunction.apply(x, weight, bias)
+
+
 def conv1x1(x, conv):
     """Conv1d(kernel 1) applied to point-major x (B,N,Cin) as a GEMM with the SAME parameter tensor."""
-    return torch.nn.functional.linear(x, conv.weight[:, :, 0], conv.bias)
+    return linear_pm(x, conv.weight[:, :, 0], conv.bias)
