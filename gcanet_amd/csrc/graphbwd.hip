@@ -1,0 +1,222 @@
+// graphbwd.hip -- fused pieces of the closed-form backward of the grouped blocks
+// (max_k LeakyReLU(GroupNorm(conv(edge features)))), see gcanet_amd/dgcnn.py:
+//   route_bwd_kernel     one pass over (B,N,Cout): selected extreme -> yhat, z, routed gradient;
+//                        per-channel dgamma/dbeta, per-(cloud,group) S1/S2, coef = rstd*gamma*g,
+//                        the selected neighbour slot / id and the sparse scatter Dsp[m_sel] += coef
+//   edge_combine_kernel  D1/D2 (the per-point sums of dy over incoming / outgoing edges)
+//   graph inversion      count -> scan -> fill of the reverse neighbour lists, and the gather form of
+//                        r[m] = sum_{n: m in idx[n]} x[n]  (replaces 2.1 GB of f32 atomics per call)
+// The reference has no counterpart kernels: its autograd walks the materialised (B,Cout,N,k) tensor.
+#include "common.h"
+
+namespace gcn {
+
+__global__ __launch_bounds__(256) void route_bwd_kernel(const float *__restrict__ dout, const float *__restrict__ ymax,
+                                                        const float *__restrict__ ymin, const unsigned char *__restrict__ amax,
+                                                        const unsigned char *__restrict__ amin, const float *__restrict__ gamma,
+                                                        const float *__restrict__ beta, const float *__restrict__ mean_rstd,
+                                                        const int64_t *__restrict__ idx, int N, int k, int Cout, int G,
+                                                        float slope, int rows_per_block, float *__restrict__ coef,
+                                                        int64_t *__restrict__ jsel, int64_t *__restrict__ msel,
+                                                        float *__restrict__ dsp, float *__restrict__ dgamma,
+                                                        float *__restrict__ dbeta, double *__restrict__ S) {
+  extern __shared__ double sm[];             // 2*G doubles, then 2*Cout floats
+  float *cs = reinterpret_cast<float *>(sm + 2 * G);
+  for (int i = threadIdx.x; i < 2 * G; i += 256) sm[i] = 0.0;
+  for (int i = threadIdx.x; i < 2 * Cout; i += 256) cs[i] = 0.f;
+  __syncthreads();
+  const int b = blockIdx.y;
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, N);
+  const int cpg = Cout / G;
+  // thread -> fixed channel (Cout <= 256 and divides 256, or a multiple of 256)
+  const int nct = Cout <= 256 ? Cout : 256;
+  const int rstep = 256 / nct > 0 ? 256 / nct : 1;
+  for (int c = threadIdx.x % nct; c < Cout; c += 256) {
+    const int g = c / cpg;
+    const float mean = mean_rstd[((long)b * G + g) * 2], rstd = mean_rstd[((long)b * G + g) * 2 + 1];
+    const float ga = gamma[c], be = beta[c];
+    const bool pos = ga >= 0.f;
+    float dg = 0.f, db = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int n = r0 + threadIdx.x / nct; n < r1; n += rstep) {
+      const long o = ((long)b * N + n) * Cout + c;
+      const float ys = pos ? ymax[o] : ymin[o];
+      const int js = pos ? amax[o] : amin[o];
+      const float yh = (ys - mean) * rstd;
+      const float z = yh * ga + be;
+      const float gz = dout[o] * (z > 0.f ? 1.f : slope);
+      const float t = gz * ga;
+      db += gz;
+      dg = fmaf(gz, yh, dg);
+      s1 += t;
+      s2 = fmaf(t, yh, s2);
+      const float cf = t * rstd;
+      coef[o] = cf;
+      if (jsel) jsel[o] = js;
+      if (idx) {
+        const int64_t m = idx[((long)b * N + n) * k + js];
+        if (msel) msel[o] = m;
+        if (dsp) atomicAdd(dsp + ((long)b * N + m) * Cout + c, cf);
+      }
+    }
+    atomicAdd(&cs[c], dg);
+    atomicAdd(&cs[Cout + c], db);
+    atomicAdd(&sm[g * 2], (double)s1);
+    atomicAdd(&sm[g * 2 + 1], (double)s2);
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < 2 * G) atomicAdd(S + (long)b * G * 2 + threadIdx.x, sm[threadIdx.x]);
+  for (int i = threadIdx.x; i < Cout; i += 256) {
+    atomicAdd(dgamma + i, cs[i]);
+    atomicAdd(dbeta + i, cs[Cout + i]);
+  }
+}
+
+// D2[n,c] = coef + k*A + B*(SW + k*XW) ; D1[m,c] = Dsp + indeg*(A + B*P1) + B*RW      (all (B,N,Cout))
+__global__ __launch_bounds__(256) void edge_combine_kernel(const float *__restrict__ coef, const float *__restrict__ dsp,
+                                                           const float *__restrict__ indeg, const float *__restrict__ Ac,
+                                                           const float *__restrict__ Bc, const float *__restrict__ P1,
+                                                           const float *__restrict__ SW, const float *__restrict__ XW,
+                                                           const float *__restrict__ RW, int N, int Cout, float kf,
+                                                           float *__restrict__ D1, float *__restrict__ D2) {
+  const int b = blockIdx.y;
+  const long per = (long)N * Cout;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < per; e += (long)gridDim.x * 256) {
+    const int c = (int)(e % Cout);
+    const long n = e / Cout;
+    const long o = (long)b * per + e;
+    const float a = Ac[(long)b * Cout + c], bb = Bc[(long)b * Cout + c];
+    const float dg = indeg[(long)b * N + n];
+    D2[o] = coef[o] + kf * a + bb * (SW[o] + kf * XW[o]);
+    D1[o] = dsp[o] + dg * (a + bb * P1[o]) + bb * RW[o];
+  }
+}
+
+// ---------------------------------------------------------------- reverse neighbour lists
+__global__ void graph_count_kernel(const int64_t *__restrict__ idx, long E, int N, int k, int *__restrict__ cnt) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const long b = e / ((long)N * k);
+  atomicAdd(cnt + b * N + idx[e], 1);
+}
+
+// one workgroup per cloud: exclusive scan of cnt[b,0..N) -> start[b,0..N], start[b,N] = N*k; cursor := start
+__global__ __launch_bounds__(1024) void graph_scan_kernel(int N, const int *__restrict__ cnt, int *__restrict__ start,
+                                                          int *__restrict__ cursor) {
+  __shared__ int part[1024];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int chunk = (N + 1023) / 1024;
+  const int lo = min(tid * chunk, N), hi = min(lo + chunk, N);
+  int s = 0;
+  for (int i = lo; i < hi; ++i) s += cnt[(long)b * N + i];
+  part[tid] = s;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const int v = tid >= off ? part[tid - off] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int run = part[tid] - s;
+  for (int i = lo; i < hi; ++i) {
+    start[(long)b * (N + 1) + i] = run;
+    cursor[(long)b * N + i] = run;
+    run += cnt[(long)b * N + i];
+  }
+  if (tid == 1023) start[(long)b * (N + 1) + N] = part[1023];
+}
+
+__global__ void graph_fill_kernel(const int64_t *__restrict__ idx, long E, int N, int k, int *__restrict__ cursor,
+                                  int *__restrict__ rev) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const long b = e / ((long)N * k);
+  const int n = (int)((e / k) % N);
+  const int pos = atomicAdd(cursor + b * N + idx[e], 1);
+  rev[b * (long)N * k + pos] = n;
+}
+
+// r[m] = sum over reverse neighbours; lists are first sorted in-wave... (order only affects f32 rounding)
+__global__ __launch_bounds__(256) void reverse_gather_kernel(const float *__restrict__ x, const int *__restrict__ start,
+                                                             const int *__restrict__ rev, int N, int C, int k,
+                                                             float *__restrict__ r, float *__restrict__ indeg) {
+  const int lane = lane_id();
+  const int m = blockIdx.x * 4 + wave_id(), b = blockIdx.y;
+  if (m >= N) return;
+  const int s0 = start[(long)b * (N + 1) + m], s1 = start[(long)b * (N + 1) + m + 1];
+  const int *lst = rev + (long)b * N * k;
+  const float *xb = x + (long)b * N * C;
+  for (int c0 = 0; c0 < C; c0 += 64) {
+    const int c = c0 + lane;
+    if (c < C) {
+      float acc = 0.f;
+      for (int t = s0; t < s1; ++t) acc += xb[(long)lst[t] * C + c];
+      r[((long)b * N + m) * C + c] = acc;
+    }
+  }
+  if (indeg && lane == 0) indeg[(long)b * N + m] = (float)(s1 - s0);
+}
+
+}  // namespace gcn
+
+using namespace gcn;
+
+GCN_EXPORT int gcn_route_bwd(const float *dout_pm, const float *ymax, const float *ymin, const uint8_t *amax,
+                             const uint8_t *amin, const float *gamma, const float *beta, const float *mean_rstd,
+                             const int64_t *idx, int B, int N, int k, int Cout, int G, float slope, float *coef,
+                             int64_t *jsel, int64_t *msel, float *dsp, float *dgamma, float *dbeta, double *S,
+                             void *stream) {
+  GCN_REQUIRE(dout_pm && ymax && ymin && amax && amin && gamma && beta && mean_rstd && coef && dgamma && dbeta && S,
+              "gcn_route_bwd: null pointer");
+  GCN_REQUIRE(B >= 0 && N >= 1 && Cout >= 1 && G >= 1 && Cout % G == 0, "gcn_route_bwd: bad shape");
+  GCN_REQUIRE((Cout <= 256 && 256 % Cout == 0) || Cout % 256 == 0, "gcn_route_bwd: Cout=%d unsupported", Cout);
+  GCN_REQUIRE(!(dsp || msel) || idx, "gcn_route_bwd: dsp/msel need idx");
+  hipStream_t st = (hipStream_t)stream;
+  GCN_HIP(hipMemsetAsync(dgamma, 0, sizeof(float) * Cout, st));
+  GCN_HIP(hipMemsetAsync(dbeta, 0, sizeof(float) * Cout, st));
+  if (B == 0) return GCN_OK;
+  GCN_HIP(hipMemsetAsync(S, 0, sizeof(double) * 2 * B * G, st));
+  if (dsp) GCN_HIP(hipMemsetAsync(dsp, 0, sizeof(float) * (size_t)B * N * Cout, st));
+  int blocks = (512 + B - 1) / B;
+  int rows = (N + blocks - 1) / blocks;
+  if (rows < 8) rows = 8;
+  route_bwd_kernel<<<dim3(cdiv(N, rows), B), 256, sizeof(double) * 2 * G + sizeof(float) * 2 * Cout, st>>>(
+      dout_pm, ymax, ymin, amax, amin, gamma, beta, mean_rstd, idx, N, k, Cout, G, slope, rows, coef, jsel, msel, dsp,
+      dgamma, dbeta, S);
+  return check_launch("route_bwd_kernel");
+}
+
+GCN_EXPORT int gcn_edge_combine(const float *coef, const float *dsp, const float *indeg, const float *Ac, const float *Bc,
+                                const float *P1, const float *SW, const float *XW, const float *RW, int B, int N, int k,
+                                int Cout, float *D1, float *D2, void *stream) {
+  GCN_REQUIRE(coef && dsp && indeg && Ac && Bc && P1 && SW && XW && RW && D1 && D2, "gcn_edge_combine: null pointer");
+  GCN_REQUIRE(B >= 0 && N >= 1 && Cout >= 1, "gcn_edge_combine: bad shape");
+  if (B == 0) return GCN_OK;
+  const long per = (long)N * Cout;
+  const int g = (int)((per + 255) / 256 > 1024 ? 1024 : (per + 255) / 256);
+  edge_combine_kernel<<<dim3(g, B), 256, 0, (hipStream_t)stream>>>(coef, dsp, indeg, Ac, Bc, P1, SW, XW, RW, N, Cout, (float)k, D1, D2);
+  return check_launch("edge_combine_kernel");
+}
+
+GCN_EXPORT int gcn_graph_invert(const int64_t *idx, int B, int N, int k, int32_t *rev_start, int32_t *rev_list,
+                                int32_t *ws, void *stream) {
+  GCN_REQUIRE(idx && rev_start && rev_list && ws, "gcn_graph_invert: null pointer");
+  GCN_REQUIRE(B >= 0 && N >= 1 && k >= 1, "gcn_graph_invert: bad shape");
+  if (B == 0) return GCN_OK;
+  hipStream_t st = (hipStream_t)stream;
+  int32_t *cnt = ws, *cursor = ws + (size_t)B * N;
+  GCN_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t) * (size_t)B * N, st));
+  const long E = (long)B * N * k;
+  graph_count_kernel<<<cdiv(E, 256), 256, 0, st>>>(idx, E, N, k, cnt);
+  graph_scan_kernel<<<B, 1024, 0, st>>>(N, cnt, rev_start, cursor);
+  graph_fill_kernel<<<cdiv(E, 256), 256, 0, st>>>(idx, E, N, k, cursor, rev_list);
+  return check_launch("graph_invert");
+}
+
+GCN_EXPORT int gcn_reverse_gather(const float *x_pm, const int32_t *rev_start, const int32_t *rev_list, int B, int N,
+                                  int C, int k, float *r, float *indeg, void *stream) {
+  GCN_REQUIRE(x_pm && rev_start && rev_list && r, "gcn_reverse_gather: null pointer");
+  GCN_REQUIRE(B >= 0 && N >= 1 && C >= 1 && k >= 1, "gcn_reverse_gather: bad shape");
+  if (B == 0) return GCN_OK;
+  reverse_gather_kernel<<<dim3(cdiv(N, 4), B), 256, 0, (hipStream_t)stream>>>(x_pm, rev_start, rev_list, N, C, k, r, indeg);
+  return check_launch("reverse_gather_kernel");
+}

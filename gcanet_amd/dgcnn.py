@@ -135,20 +135,25 @@ def _edgeconv_backward(saved, cfg, dout, pm):
         k = idx.shape[2]
         Cout = W.shape[0]
         W1, Wd = W[:, :C], W[:, C:] - W[:, :C]
-        jsel, coef, Ac, Bc, dgamma, dbeta = _gn_route_backward(dout.float(), gamma, beta, ymax, ymin, amax, amin, mean_rstd,
-                                                               G, slope, float((Cout // G) * N * k), pm=pm)
-        msel = torch.gather(idx, 2, jsel)                             # (B,N,Cout) global neighbour id
-        # graph aggregations
+        Mg = float((Cout // G) * N * k)
+        dpm = dout if pm else dout.permute(0, 2, 1)
+        _, coef, Ac, Bc, dgamma, dbeta, Dsp = _route_backward_fused(dpm, gamma, beta, ymax, ymin, amax, amin, mean_rstd,
+                                                                    G, slope, Mg, idx=idx, want_dsp=True)
+        # graph aggregations: s = Adj.x (gather), r = Adj^T.x (gather over the inverted lists), in-degree
         s = torch.empty_like(x)
         r = torch.empty_like(x)
         indeg = torch.empty(B, N, dtype=torch.float32, device=x.device)
+        rev_start = torch.empty(B, N + 1, dtype=torch.int32, device=x.device)
+        rev_list = torch.empty(B, N * k, dtype=torch.int32, device=x.device)
+        ws = torch.empty(2 * B * N, dtype=torch.int32, device=x.device)
         _run("gcn_neighbor_sum", x, _lib.ptr(x), _lib.ptr(idx), B, N, C, k, _lib.ptr(s))
-        _run("gcn_reverse_sum", x, _lib.ptr(x), _lib.ptr(idx), B, N, C, k, _lib.ptr(r), _lib.ptr(indeg))
-        Dsp = torch.zeros(B, N, Cout, dtype=torch.float32, device=x.device).scatter_add_(1, msel, coef)
-        P1 = x @ W1.t()                                                # (B,N,Cout)  W1.x_m
-        # D2[n,c] = sum_j dy[n,j,c] ; D1[m,c] = sum over edges into m
-        D2 = coef + k * Ac.unsqueeze(1) + Bc.unsqueeze(1) * (s @ W1.t() + k * (x @ Wd.t()))
-        D1 = Dsp + indeg.unsqueeze(2) * (Ac.unsqueeze(1) + Bc.unsqueeze(1) * P1) + Bc.unsqueeze(1) * (r @ Wd.t())
+        _run("gcn_graph_invert", x, _lib.ptr(idx), B, N, k, _lib.ptr(rev_start), _lib.ptr(rev_list), _lib.ptr(ws))
+        _run("gcn_reverse_gather", x, _lib.ptr(x), _lib.ptr(rev_start), _lib.ptr(rev_list), B, N, C, k, _lib.ptr(r),
+             _lib.ptr(indeg))
+        P1, SW, XW, RW = x @ W1.t(), s @ W1.t(), x @ Wd.t(), r @ Wd.t()        # (B,N,Cout) each
+        D1, D2 = torch.empty_like(coef), torch.empty_like(coef)
+        _run("gcn_edge_combine", x, _lib.ptr(coef), _lib.ptr(Dsp), _lib.ptr(indeg), _lib.ptr(Ac), _lib.ptr(Bc), _lib.ptr(P1),
+             _lib.ptr(SW), _lib.ptr(XW), _lib.ptr(RW), B, N, k, Cout, _lib.ptr(D1), _lib.ptr(D2))
         dx_pm = D1 @ W1 + D2 @ Wd                                      # (B,N,C)
         # weight gradients
         G11 = _tall_skinny_tn(x * indeg.unsqueeze(2), x)               # X^T diag(indeg) X   (B,C,C)
@@ -250,9 +255,10 @@ class GroupedBlockFunction(torch.autograd.Function):
         G, slope, pm_out = ctx.cfg
         B, N, k, F = ef.shape
         Cout = W.shape[0]
-        jsel, coef, Ac, Bc, dgamma, dbeta = _gn_route_backward(dout.float().contiguous(), gamma, beta, ymax, ymin, amax,
-                                                               amin, mean_rstd, G, slope, float((Cout // G) * N * k),
-                                                               pm=pm_out)
+        dpm = dout if pm_out else dout.permute(0, 2, 1)
+        jsel, coef, Ac, Bc, dgamma, dbeta, _ = _route_backward_fused(dpm, gamma.float().contiguous(), beta.float().contiguous(),
+                                                                     ymax, ymin, amax, amin, mean_rstd, G, slope,
+                                                                     float((Cout // G) * N * k), want_jsel=True)
         # sparse part: one selected edge row per (point, channel) -- never a (B,N,k,Cout) one-hot
         jx = jsel.unsqueeze(-1).expand(-1, -1, -1, F)                          # (B,N,Cout,F)
         contrib = coef.unsqueeze(-1) * W.view(1, 1, Cout, F)                   # coef[n,c] * W[c,:]
@@ -271,6 +277,32 @@ def grouped_block(ef, weight, gamma, beta, groups=2, eps=1e-5, slope=0.2, dtype=
     if weight.dim() == 4:
         weight = weight[:, :, 0, 0]
     return GroupedBlockFunction.apply(ef.float().contiguous(), weight, gamma, beta, groups, eps, slope, dtype, pm_out)
+
+
+def _route_backward_fused(dout_pm, gamma, beta, ymax, ymin, amax, amin, mean_rstd, G, slope, count_per_group,
+                          idx=None, want_jsel=False, want_dsp=False):
+    """Single-kernel version of _gn_route_backward (csrc/graphbwd.hip) for point-major dout.
+    Returns (jsel|None, coef, Ac, Bc, dgamma, dbeta, dsp|None)."""
+    B, N, Cout = ymax.shape
+    dev = ymax.device
+    k = idx.shape[2] if idx is not None else 1
+    cpg = Cout // G
+    dout_pm = dout_pm.float().contiguous()
+    coef = torch.empty(B, N, Cout, dtype=torch.float32, device=dev)
+    jsel = torch.empty(B, N, Cout, dtype=torch.int64, device=dev) if want_jsel else None
+    dsp = torch.empty(B, N, Cout, dtype=torch.float32, device=dev) if want_dsp else None
+    dgamma = torch.empty(Cout, dtype=torch.float32, device=dev)
+    dbeta = torch.empty(Cout, dtype=torch.float32, device=dev)
+    S = torch.empty(B, G, 2, dtype=torch.float64, device=dev)
+    _run("gcn_route_bwd", ymax, _lib.ptr(dout_pm), _lib.ptr(ymax), _lib.ptr(ymin), _lib.ptr(amax), _lib.ptr(amin),
+         _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(mean_rstd), _lib.ptr(idx), B, N, k, Cout, G, float(slope),
+         _lib.ptr(coef), _lib.ptr(jsel), None, _lib.ptr(dsp), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(S))
+    rs, mu = mean_rstd[:, :, 1].double(), mean_rstd[:, :, 0].double()
+    Bg = -(rs * rs) * S[:, :, 1] / count_per_group
+    Ag = -(rs * S[:, :, 0]) / count_per_group - Bg * mu
+    Ac = Ag.float().repeat_interleave(cpg, 1).contiguous()
+    Bc = Bg.float().repeat_interleave(cpg, 1).contiguous()
+    return jsel, coef, Ac, Bc, dgamma, dbeta, dsp
 
 
 def _gn_route_backward(dout, gamma, beta, ymax, ymin, amax, amin, mean_rstd, G, slope, count_per_group, pm=False):
@@ -341,8 +373,9 @@ class KeyEdgeBlockFunction(torch.autograd.Function):
         B, N, k = att.shape
         NK, Cout = U.shape[1], U.shape[2]
         Mg = float((Cout // G) * N * k)
-        jsel, coef, Ac, Bc, dgamma, dbeta = _gn_route_backward(dout.float().contiguous(), gamma, beta, ymax, ymin, amax,
-                                                               amin, mean_rstd, G, slope, Mg, pm=pm_out)
+        dpm = dout if pm_out else dout.permute(0, 2, 1)
+        jsel, coef, Ac, Bc, dgamma, dbeta, _ = _route_backward_fused(dpm, gamma, beta, ymax, ymin, amax, amin, mean_rstd,
+                                                                     G, slope, Mg, want_jsel=True)
         if k <= 32:
             datt, dV, dU = torch.empty_like(att), torch.empty_like(V), torch.empty_like(U)
             _run("gcn_keyedge_bwd", att, _lib.ptr(att), _lib.ptr(kidx), _lib.ptr(U), _lib.ptr(V), _lib.ptr(coef.contiguous()),

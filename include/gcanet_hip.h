@@ -254,6 +254,35 @@ int gcn_keyedge_bwd(const float *att, const int64_t *kidx, const float *U, const
                     const float *coef, const int64_t *jsel, const float *Ac, const float *Bc, int B,
                     int N, int k, int NK, int Cout, float *datt, float *dV, float *dU, void *stream);
 
+/* ------------------------- fused pieces of the closed-form grouped-block backward ------ */
+
+/* One pass over (B,N,Cout): selected extreme (max for gamma >= 0, else min) -> yhat, z, routed
+ * gradient gz = dout * LeakyReLU'(z).  Outputs: coef = rstd*gamma*gz (B,N,Cout); jsel (slot, may be
+ * NULL), msel = idx[b,n,jsel] (may be NULL), dsp[b, msel, c] += coef (may be NULL; zeroed by the
+ * call), dgamma/dbeta (Cout) and S (B,G,2) f64 = [sum gamma*gz, sum gamma*gz*yhat] (zeroed by the call).
+ * idx (B,N,k) int64 may be NULL when neither msel nor dsp is wanted. */
+int gcn_route_bwd(const float *dout_pm, const float *ymax, const float *ymin, const uint8_t *amax,
+                  const uint8_t *amin, const float *gamma, const float *beta, const float *mean_rstd,
+                  const int64_t *idx, int B, int N, int k, int Cout, int G, float slope, float *coef,
+                  int64_t *jsel, int64_t *msel, float *dsp, float *dgamma, float *dbeta, double *S,
+                  void *stream);
+
+/* D2 = coef + k*A + B*(SW + k*XW);  D1 = dsp + indeg*(A + B*P1) + B*RW   (all (B,N,Cout) f32;
+ * A, B (B,Cout); indeg (B,N)): per-point sums of dy over outgoing / incoming edges. */
+int gcn_edge_combine(const float *coef, const float *dsp, const float *indeg, const float *Ac,
+                     const float *Bc, const float *P1, const float *SW, const float *XW, const float *RW,
+                     int B, int N, int k, int Cout, float *D1, float *D2, void *stream);
+
+/* Reverse neighbour lists of a kNN graph idx (B,N,k) int64: rev_start (B,N+1) i32, rev_list (B,N*k) i32
+ * (order inside a list unspecified); ws: 2*B*N i32 workspace. */
+int gcn_graph_invert(const int64_t *idx, int B, int N, int k, int32_t *rev_start, int32_t *rev_list,
+                     int32_t *ws, void *stream);
+
+/* r[b,m,:] = sum over reverse neighbours n of x[b,n,:]; indeg[b,m] = list length (may be NULL).
+ * Gather form of gcn_reverse_sum (no atomics). */
+int gcn_reverse_gather(const float *x_pm, const int32_t *rev_start, const int32_t *rev_list, int B, int N,
+                       int C, int k, float *r, float *indeg, void *stream);
+
 /* ------------------------------------------- GroupNorm(+ReLU), point-major (B,N,C) ------ */
 
 /* Replaces the `F.relu(self.bnX(self.convX(x)))` normalisation of the per-point heads (M4:644-726;
