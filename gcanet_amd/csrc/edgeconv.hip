@@ -537,7 +537,7 @@ __global__ __launch_bounds__(256) void keyedge_fwd_kernel(const float *__restric
 //   datt[n,j] = sum_c dy*(U[m,c]-V[n,c]);  dV[n,c] = -sum_j att*dy;  dU[m,c] = sum_{(n,j)->m} att*dy.
 // One wave per point, lanes across channels; U and the dU accumulator live in LDS (one flush of
 // contiguous f32 atomics per workgroup).
-__global__ __launch_bounds__(256) void keyedge_bwd_kernel(const float *__restrict__ att, const int64_t *__restrict__ kidx,
+__global__ __launch_bounds__(1024) void keyedge_bwd_kernel(const float *__restrict__ att, const int64_t *__restrict__ kidx,
                                                           const float *__restrict__ U, const float *__restrict__ V,
                                                           const float *__restrict__ coef, const int64_t *__restrict__ jsel,
                                                           const float *__restrict__ Ac, const float *__restrict__ Bc,
@@ -548,14 +548,14 @@ __global__ __launch_bounds__(256) void keyedge_bwd_kernel(const float *__restric
   float *u_lds = lds_f, *du_lds = lds_f + NK * Cout;
   const int lane = lane_id(), wave = wave_id();
   const int b = blockIdx.y;
-  for (int i = threadIdx.x; i < NK * Cout; i += 256) {
+  for (int i = threadIdx.x; i < NK * Cout; i += blockDim.x) {
     u_lds[i] = U[(long)b * NK * Cout + i];
     du_lds[i] = 0.f;
   }
   __syncthreads();
   const int n_lo = blockIdx.x * pts_per_block;
   const int n_hi = min(n_lo + pts_per_block, N);
-  for (int n = n_lo + wave; n < n_hi; n += 4) {
+  for (int n = n_lo + wave; n < n_hi; n += (int)(blockDim.x >> 6)) {
     const long pn = (long)b * N + n;
     float pj[32];  // per-lane partial of datt[n,j] (k <= 32)
 #pragma unroll
@@ -594,7 +594,7 @@ __global__ __launch_bounds__(256) void keyedge_bwd_kernel(const float *__restric
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < NK * Cout; i += 256) atomicAdd(dU + (long)b * NK * Cout + i, du_lds[i]);
+  for (int i = threadIdx.x; i < NK * Cout; i += blockDim.x) atomicAdd(dU + (long)b * NK * Cout + i, du_lds[i]);
 }
 
 template <int KSTEPS, int CW, int RWT>
@@ -760,6 +760,6 @@ GCN_EXPORT int gcn_keyedge_bwd(const float *att, const int64_t *kidx, const floa
   int blocks_per_cloud = (256 + B - 1) / B;
   if (blocks_per_cloud > (N + 3) / 4) blocks_per_cloud = (N + 3) / 4;
   const int ppb = (N + blocks_per_cloud - 1) / blocks_per_cloud;
-  keyedge_bwd_kernel<<<dim3(cdiv(N, ppb), B), 256, lds, st>>>(att, kidx, U, V, coef, jsel, Ac, Bc, N, k, NK, Cout, ppb, datt, dV, dU);
+  keyedge_bwd_kernel<<<dim3(cdiv(N, ppb), B), 1024, lds, st>>>(att, kidx, U, V, coef, jsel, Ac, Bc, N, k, NK, Cout, ppb, datt, dV, dU);
   return check_launch("keyedge_bwd_kernel");
 }
