@@ -98,8 +98,15 @@ struct EcArgs {
 // KSTEPS = 2*Cp/16 (= Cp/8 = 16-B chunks per row), CW = Cout/32 column groups,
 // RWT = 128-row groups per tile; block = 64*RWT*CW threads.  A wave owns 128 rows x 32 cols
 // (4 MFMA blocks): 64 VGPRs of B fragments + 64 accumulators, so two waves fit per SIMD.
+//
+// RWT == 1 (k <= 128, the normal case): the tile is ONE wave-row-group, every point's rows live in a
+// single wave, so max/min/arg are combined in registers and stored straight from the epilogue -- one
+// barrier per tile, no LDS round trip.  Workgroups are small (CW waves, <= 66 KB LDS) so that TWO of
+// them share a CU and drift out of phase: one workgroup's VALU epilogue overlaps the other's MFMAs.
+// The neighbour ids of tile t+2 are fetched while tile t computes, so the DMA issue of tile t+1 never
+// waits on a dependent global load.  RWT == 2 (128 < k <= 255) keeps the cross-wave LDS combine.
 template <int KSTEPS, int CW, int RWT, bool WITH_ARG>
-__global__ __launch_bounds__(64 * RWT * CW) void edgeconv_fwd_bf16_kernel(EcArgs a) {
+__global__ __launch_bounds__(64 * RWT * CW, 2) void edgeconv_fwd_bf16_kernel(EcArgs a) {
   constexpr int NC = KSTEPS;               // chunks per x row
   constexpr int CP = KSTEPS * 8;           // padded channels
   constexpr int K = 2 * CP;
@@ -137,7 +144,27 @@ __global__ __launch_bounds__(64 * RWT * CW) void edgeconv_fwd_bf16_kernel(EcArgs
   const int kp = a.kp, k = a.k, TP = a.TP;
   const int rows_used = TP * kp;
 
-  // issue the LDS-DMA gather of tile t into buffer `buf`
+  // neighbour row ids of this lane's DMA pieces for one tile (always PPW loads, clamped, so that the
+  // number of VMEM operations per wave is a compile-time constant for the counted waits below)
+  int grow[PPW];
+  auto load_ids = [&](int t) {
+    const int tt = t < t_end ? t : t_end - 1;
+    const int b = tt / a.tiles_per_cloud;
+    const int n0 = (tt % a.tiles_per_cloud) * TP;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      int p = wave + i * NW;
+      if (p >= PIECES) p = PIECES - 1;
+      int row = p * RPP + lane / NC;
+      if (row >= rows_used) row = rows_used - 1;
+      int pt = row / kp, j = row % kp;
+      if (j >= k) j = 0;
+      int n = n0 + pt;
+      if (n >= a.N) n = a.N - 1;
+      grow[i] = (int)a.idx[((long)b * a.N + n) * k + j];
+    }
+  };
+  // issue the LDS-DMA gather of tile t into buffer `buf` from the ids in grow[]
   auto issue_gather = [&](int t, int buf) {
     const int b = t / a.tiles_per_cloud;
     const int n0 = (t % a.tiles_per_cloud) * TP;
@@ -150,12 +177,7 @@ __global__ __launch_bounds__(64 * RWT * CW) void edgeconv_fwd_bf16_kernel(EcArgs
         const int row = p * RPP + lane / NC;
         const int cs = lane % NC;                       // physical chunk slot
         const int c = cs ^ ((row / RPB) & (NC - 1));    // logical chunk (swizzle on the source side)
-        int pt = row / kp, j = row % kp;
-        if (j >= k) j = 0;
-        int n = n0 + pt;
-        if (n >= a.N) n = a.N - 1;
-        const long g = a.idx[((long)b * a.N + n) * k + j];
-        const unsigned short *src = xb + g * CP + c * 8;
+        const unsigned short *src = xb + (long)grow[i] * CP + c * 8;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                          (__attribute__((address_space(3))) void *)(abuf + p * 1024), 16, 0, 0);
       }
@@ -191,7 +213,9 @@ __global__ __launch_bounds__(64 * RWT * CW) void edgeconv_fwd_bf16_kernel(EcArgs
     s2 = 0.f;
   };
 
+  load_ids(t_begin);
   issue_gather(t_begin, 0);
+  load_ids(t_begin + 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -203,7 +227,8 @@ __global__ __launch_bounds__(64 * RWT * CW) void edgeconv_fwd_bf16_kernel(EcArgs
       flush_stats(cur_b);
       cur_b = b;
     }
-    if (t + 1 < t_end) issue_gather(t + 1, buf ^ 1);
+    if (t + 1 < t_end) issue_gather(t + 1, buf ^ 1);   // ids were fetched one tile ago
+    load_ids(t + 2);                                   // PPW plain loads, consumed next iteration
 
     unsigned char *abuf = lds + buf * BUF_BYTES;
     const unsigned char *cbuf = abuf + A_BYTES;
@@ -240,70 +265,114 @@ __global__ __launch_bounds__(64 * RWT * CW) void edgeconv_fwd_bf16_kernel(EcArgs
       }
     }
     // ---- per 32-row block: max / min (/ arg) over rows per column, sums for GroupNorm
-    float *pmax = reinterpret_cast<float *>(lds + 2 * BUF_BYTES);  // [blocks][Cout], own LDS region
+    float *pmax = reinterpret_cast<float *>(lds + 2 * BUF_BYTES);  // RWT > 1 only: [blocks][Cout]
     float *pmin = pmax + (TILE_ROWS / 32) * COUT;
     int *pamax = reinterpret_cast<int *>(pmin + (TILE_ROWS / 32) * COUT);
     int *pamin = pamax + (TILE_ROWS / 32) * COUT;
+    float bmx[4], bmn[4];
+    int bax[4], ban[4];
     if (active) {
 #pragma unroll
       for (int rb = 0; rb < 4; ++rb) {
         const int blk = rg * 4 + rb;
-        if (blk * 32 >= rows_used) break;            // wave-uniform: block beyond the tile's points
-        if (n0 + (blk * 32) / kp >= a.N) break;      // tail tile: point past the end of the cloud
-        const int rbase = (blk * 32) % kp + 4 * lh;  // point-row of register 0 (kp % 32 == 0)
-        {
-          float mx = acc[rb][0], mn = acc[rb][0];
+        bmx[rb] = -__builtin_inff(); bmn[rb] = __builtin_inff(); bax[rb] = 0; ban[rb] = 0;
+        if (blk * 32 >= rows_used) continue;          // wave-uniform: block beyond the tile's points
+        if (n0 + (blk * 32) / kp >= a.N) continue;    // tail tile: point past the end of the cloud
+        const int rbase = (blk * 32) % kp + 4 * lh;   // point-row of register 0 (kp % 32 == 0)
+        float mx = acc[rb][0], mn = acc[rb][0];
 #pragma unroll
-          for (int i = 1; i < 16; ++i) {
-            mx = fmaxf(mx, acc[rb][i]);
-            mn = fminf(mn, acc[rb][i]);
-          }
-          float ps = 0.f, pq = 0.f;
+        for (int i = 1; i < 16; ++i) {
+          mx = fmaxf(mx, acc[rb][i]);
+          mn = fminf(mn, acc[rb][i]);
+        }
+        float ps = 0.f, pq = 0.f;
 #pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const int rr = rbase + (i & 3) + 8 * (i >> 2);
-            const float v = (kp == k || rr < k) ? acc[rb][i] : 0.f;
-            ps += v;
-            pq = fmaf(v, v, pq);
+        for (int i = 0; i < 16; ++i) {
+          const int rr = rbase + (i & 3) + 8 * (i >> 2);
+          const float v = (kp == k || rr < k) ? acc[rb][i] : 0.f;
+          ps += v;
+          pq = fmaf(v, v, pq);
+        }
+        s1 += ps;
+        s2 += pq;
+        int ax = 0x7fffffff, an = 0x7fffffff;
+        if (WITH_ARG) {
+          // the point-row of register i grows with i, so the lowest row is the lowest i
+          int ix = 0, in_ = 0;
+#pragma unroll
+          for (int i = 15; i >= 0; --i) {
+            ix = acc[rb][i] == mx ? i : ix;
+            in_ = acc[rb][i] == mn ? i : in_;
           }
-          s1 += ps;
-          s2 += pq;
-          int ax = 0x7fffffff, an = 0x7fffffff;
+          ax = rbase + (ix & 3) + 8 * (ix >> 2);
+          an = rbase + (in_ & 3) + 8 * (in_ >> 2);
+        }
+        // combine the two half-waves (rows 4h..)
+        const float mx2 = __shfl_xor(mx, 32), mn2 = __shfl_xor(mn, 32);
+        if (WITH_ARG) {
+          const int ax2 = __shfl_xor(ax, 32), an2 = __shfl_xor(an, 32);
+          ax = mx2 > mx ? ax2 : (mx2 == mx ? min(ax, ax2) : ax);
+          an = mn2 < mn ? an2 : (mn2 == mn ? min(an, an2) : an);
+        }
+        mx = fmaxf(mx, mx2);
+        mn = fminf(mn, mn2);
+        bmx[rb] = mx; bmn[rb] = mn; bax[rb] = ax; ban[rb] = an;
+        if (RWT > 1 && lh == 0) {
+          const int o = blk * COUT + cg * 32 + lr;
+          pmax[o] = mx;
+          pmin[o] = mn;
           if (WITH_ARG) {
-            // the point-row of register i grows with i, so the lowest row is the lowest i
-            int ix = 0, in_ = 0;
-#pragma unroll
-            for (int i = 15; i >= 0; --i) {
-              ix = acc[rb][i] == mx ? i : ix;
-              in_ = acc[rb][i] == mn ? i : in_;
-            }
-            ax = rbase + (ix & 3) + 8 * (ix >> 2);
-            an = rbase + (in_ & 3) + 8 * (in_ >> 2);
-          }
-          // combine the two half-waves (rows 4h..)
-          const float mx2 = __shfl_xor(mx, 32), mn2 = __shfl_xor(mn, 32);
-          if (WITH_ARG) {
-            const int ax2 = __shfl_xor(ax, 32), an2 = __shfl_xor(an, 32);
-            ax = mx2 > mx ? ax2 : (mx2 == mx ? min(ax, ax2) : ax);
-            an = mn2 < mn ? an2 : (mn2 == mn ? min(an, an2) : an);
-          }
-          mx = fmaxf(mx, mx2);
-          mn = fminf(mn, mn2);
-          if (lh == 0) {
-            const int o = blk * COUT + cg * 32 + lr;
-            pmax[o] = mx;
-            pmin[o] = mn;
-            if (WITH_ARG) {
-              pamax[o] = ax;
-              pamin[o] = an;
-            }
+            pamax[o] = ax;
+            pamin[o] = an;
           }
         }
       }
     }
+    if (RWT == 1) {
+      // every point of the tile lives in this wave: combine its kp/32 blocks in registers and store
+      if (lh == 0) {
+        const int nb = kp / 32;   // 1, 2 or 4 (3 when k in (64, 96]: TP == 1, blocks 0..2)
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) {
+          if (pt < TP && n0 + pt < a.N) {
+            float mx = -__builtin_inff(), mn = __builtin_inff();
+            int ax = 0, an = 0;
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) {
+              if (rb >= pt * nb && rb < (pt + 1) * nb) {
+                if (WITH_ARG) {
+                  if (bmx[rb] > mx) ax = bax[rb];   // blocks ascend in point-row: strict > keeps the lowest row
+                  if (bmn[rb] < mn) an = ban[rb];
+                }
+                mx = fmaxf(mx, bmx[rb]);
+                mn = fminf(mn, bmn[rb]);
+              }
+            }
+            const long o = ((long)b * a.N + n0 + pt) * COUT + cg * 32 + lr;
+            a.ymax[o] = mx;
+            a.ymin[o] = mn;
+            if (WITH_ARG) {
+              a.amax[o] = (unsigned char)ax;
+              a.amin[o] = (unsigned char)an;
+            }
+          }
+        }
+      }
+      // DMA of tile t+1 is older than the PPW id loads issued after it: wait for everything but those
+      if (PPW == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+      else if (PPW == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else if (PPW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if (PPW == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // NOTE: the stores above are younger than the id loads, so the counted wait is conservative
+      // (it also covers them only when they retire in order); correctness needs only the DMA.
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      continue;
+    }
     __syncthreads();
 
-    // ---- combine the kp/32 blocks of each point, write (B,N,Cout)
+    // ---- RWT > 1: combine the kp/32 blocks of each point through LDS, write (B,N,Cout)
     {
       const int nb = kp / 32;
       const int Cout = COUT;
@@ -603,7 +672,7 @@ static int launch_fwd_bf16(EcArgs &a, bool with_arg, hipStream_t st) {
   constexpr int TILE_ROWS = RWT * 128;
   constexpr int A_BYTES = TILE_ROWS * CP * 2;
   constexpr int C_BYTES = (((TILE_ROWS / 32) * CP * 2 + 1023) / 1024) * 1024;
-  constexpr int PART_BYTES = (TILE_ROWS / 32) * CW * 32 * 16;
+  constexpr int PART_BYTES = RWT == 1 ? 0 : (TILE_ROWS / 32) * CW * 32 * 16;
   constexpr int BUF_BYTES = A_BYTES + C_BYTES;
   const int lds_bytes = 2 * BUF_BYTES + PART_BYTES;
   static_assert(2 * BUF_BYTES + PART_BYTES <= 160 * 1024, "LDS budget");
@@ -612,9 +681,14 @@ static int launch_fwd_bf16(EcArgs &a, bool with_arg, hipStream_t st) {
     set_error("gcn_edgeconv_fwd: k=%d needs %d rows per point > tile of %d rows", a.k, a.kp, TILE_ROWS);
     return GCN_EINVAL;
   }
+  if (RWT == 1 && a.TP > 4) a.TP = 4;
   a.tiles_per_cloud = (a.N + a.TP - 1) / a.TP;
   a.total_tiles = a.B * a.tiles_per_cloud;
-  int grid = a.total_tiles < 256 ? a.total_tiles : 256;
+  // persistent grid: as many workgroups as stay resident (2 waves per SIMD = 8 waves per CU)
+  const int wg_per_cu = 8 / (RWT * CW) > 0 ? 8 / (RWT * CW) : 1;
+  const int by_lds = (160 * 1024) / (lds_bytes > 0 ? lds_bytes : 1);
+  const int resident = 256 * (wg_per_cu < by_lds ? wg_per_cu : by_lds);
+  int grid = a.total_tiles < resident ? a.total_tiles : resident;
   auto kern = with_arg ? edgeconv_fwd_bf16_kernel<KSTEPS, CW, RWT, true> : edgeconv_fwd_bf16_kernel<KSTEPS, CW, RWT, false>;
   GCN_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
   kern<<<grid, 64 * RWT * CW, lds_bytes, st>>>(a);
@@ -679,9 +753,10 @@ GCN_EXPORT int gcn_edgeconv_fwd(const void *x_pm, const void *w, const int64_t *
   a.ymax = ymax; a.ymin = ymin; a.amax = amax; a.amin = amin; a.gsum = gsum;
   const bool wa = amax != nullptr;
   const int ks = Cp / 8;
-#define EC_CASE(KS, CWV, RWTV) if (ks == KS && Cout == CWV * 32) return launch_fwd_bf16<KS, CWV, RWTV>(a, wa, st);
-  EC_CASE(1, 2, 4) EC_CASE(2, 2, 4) EC_CASE(4, 2, 4) EC_CASE(8, 2, 4) EC_CASE(16, 2, 2)
-  EC_CASE(1, 4, 2) EC_CASE(2, 4, 2) EC_CASE(4, 4, 2) EC_CASE(8, 4, 2) EC_CASE(16, 4, 2)
+#define EC_CASE(KS, CWV) \
+  if (ks == KS && Cout == CWV * 32) return a.kp <= 128 ? launch_fwd_bf16<KS, CWV, 1>(a, wa, st) : launch_fwd_bf16<KS, CWV, 2>(a, wa, st);
+  EC_CASE(1, 2) EC_CASE(2, 2) EC_CASE(4, 2) EC_CASE(8, 2) EC_CASE(16, 2)
+  EC_CASE(1, 4) EC_CASE(2, 4) EC_CASE(4, 4) EC_CASE(8, 4) EC_CASE(16, 4)
 #undef EC_CASE
   set_error("gcn_edgeconv_fwd(bf16): unsupported configuration");
   return GCN_EINVAL;

@@ -4,7 +4,8 @@ import time
 
 import torch
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gcanet_amd import dgcnn  # noqa: E402
 from gcanet_amd.knn_cuda import KNN  # noqa: E402
 from gcanet_amd.pointnet2_ops import pointnet2_utils as P2  # noqa: E402
