@@ -102,6 +102,37 @@ __global__ __launch_bounds__(256) void group_points_kernel(int c, int n, long E,
   }
 }
 
+
+// group_points with the source rows staged in LDS: the random 4-B gathers hit LDS banks instead of
+// 64 different cache lines per wave-instruction (the texture-address path capped the first version at
+// ~1.6 TB/s); the (b, CT-channel) workgroup streams all E = npoints*nsample outputs with 16-B stores.
+template <int CT>
+__global__ __launch_bounds__(512) void group_points_lds_kernel(int c, int n, long E, const float *__restrict__ points,
+                                                               const int32_t *__restrict__ idx, float *__restrict__ out) {
+  extern __shared__ float rows[];  // CT * n
+  const int b = blockIdx.y;
+  const int c0 = blockIdx.x * CT;
+  for (int i = threadIdx.x; i < CT * n; i += 512) {
+    const int ch = c0 + i / n;
+    rows[i] = ch < c ? points[((long)b * c + ch) * n + (i % n)] : 0.f;
+  }
+  __syncthreads();
+  const int32_t *ip = idx + (long)b * E;
+  const long E4 = E >> 2;  // E % 4 == 0 (checked by the launcher)
+  for (long q = threadIdx.x; q < E4; q += 512) {
+    const int4 v = *reinterpret_cast<const int4 *>(ip + q * 4);
+#pragma unroll
+    for (int cc = 0; cc < CT; ++cc) {
+      const int ch = c0 + cc;
+      if (ch >= c) break;
+      const float *r = rows + cc * n;
+      float4 o;
+      o.x = r[v.x]; o.y = r[v.y]; o.z = r[v.z]; o.w = r[v.w];
+      *reinterpret_cast<float4 *>(out + ((long)b * c + ch) * E + q * 4) = o;
+    }
+  }
+}
+
 // group_points_gpu.cu:43-64 (atomicAdd scatter).  One workgroup owns CT (b,c) rows of n
 // floats in LDS, streams the row's E gradients (coalesced) and adds them with LDS float
 // atomics, then writes the rows out.  Also serves gather_points_grad (E = m).
@@ -116,12 +147,29 @@ __global__ __launch_bounds__(512) void scatter_rows_lds_kernel(int c, int n, lon
   for (int i = threadIdx.x; i < CT * n; i += blockDim.x) acc[i] = 0.f;
   __syncthreads();
   const int32_t *ip = idx + (long)b * E;
-  for (long e = threadIdx.x; e < E; e += blockDim.x) {
-    const int ii = ip[e];
+  if ((E & 3) == 0) {   // 16-B loads of ids and gradients
+    for (long q = threadIdx.x; q < (E >> 2); q += blockDim.x) {
+      const int4 v = *reinterpret_cast<const int4 *>(ip + q * 4);
 #pragma unroll
-    for (int cc = 0; cc < CT; ++cc) {
-      const int ch = c0 + cc;
-      if (ch < c) atomicAdd(&acc[cc * n + ii], grad_out[((long)b * c + ch) * E + e]);
+      for (int cc = 0; cc < CT; ++cc) {
+        const int ch = c0 + cc;
+        if (ch < c) {
+          const float4 g = *reinterpret_cast<const float4 *>(grad_out + ((long)b * c + ch) * E + q * 4);
+          atomicAdd(&acc[cc * n + v.x], g.x);
+          atomicAdd(&acc[cc * n + v.y], g.y);
+          atomicAdd(&acc[cc * n + v.z], g.z);
+          atomicAdd(&acc[cc * n + v.w], g.w);
+        }
+      }
+    }
+  } else {
+    for (long e = threadIdx.x; e < E; e += blockDim.x) {
+      const int ii = ip[e];
+#pragma unroll
+      for (int cc = 0; cc < CT; ++cc) {
+        const int ch = c0 + cc;
+        if (ch < c) atomicAdd(&acc[cc * n + ii], grad_out[((long)b * c + ch) * E + e]);
+      }
     }
   }
   __syncthreads();
@@ -338,8 +386,14 @@ GCN_EXPORT int gcn_group_points(int b, int c, int n, int npoints, int nsample, c
   GCN_REQUIRE(b >= 0 && c >= 0 && n >= 1 && npoints >= 0 && nsample >= 0, "gcn_group_points: bad shape");
   const long E = (long)npoints * nsample;
   if (b == 0 || c == 0 || E == 0) return GCN_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t row_bytes = (size_t)n * sizeof(float);
+  if ((E & 3) == 0 && E >= 4096 && row_bytes * 2 <= 64 * 1024) {
+    group_points_lds_kernel<2><<<dim3(cdiv(c, 2), b), 512, row_bytes * 2, st>>>(c, n, E, points, idx, out);
+    return check_launch("group_points_lds_kernel");
+  }
   constexpr int CT = 8;
-  group_points_kernel<CT><<<dim3(cdiv(E, 1024), cdiv(c, CT), b), 256, 0, (hipStream_t)stream>>>(c, n, E, points, idx, out);
+  group_points_kernel<CT><<<dim3(cdiv(E, 1024), cdiv(c, CT), b), 256, 0, st>>>(c, n, E, points, idx, out);
   return check_launch("group_points_kernel");
 }
 
