@@ -55,6 +55,23 @@ def kernel_model(tag):
     return None
 
 
+def pmc_traffic(tag):
+    """HBM bytes per launch of the kernel behind `tag`, from the committed rocprofv3 PMC passes of this same
+    command (profiles/r01_pmc_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 read
+    correction applied).  Counters cannot be read from inside the process, hence the file; null if absent or if
+    the profile was taken at another shape."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if not os.path.exists(path) or "B=8" not in tag or "N=8192" not in tag:
+        return None
+    ks = json.load(open(path))["kernels"]
+    name = {"knn_model[B=8,C=64": "gcn::knn_mfma_kernel<64>", "knn_model[B=8,C=6,": "gcn::knn_select_kernel<1, 8, 2, 6>",
+            "edgeconv_fwd[B=8,N=8192,k=64,C=64,Cout=128": "gcn::edgeconv_fwd_bf16_kernel<8, 4, 1, true>"}
+    for pre, kn in name.items():
+        if tag.startswith(pre) and kn in ks:
+            return ks[kn]["hbm_bytes_corrected"]
+    return None
+
+
 def cpu_baseline(N, k, seconds_budget=25.0):
     """The same hot-path step (fwd+bwd, fp32) through the CPU oracle on ONE cloud; all host cores."""
     from gcanet_amd import dgcnn
@@ -156,7 +173,7 @@ def main():
         avg_ms = tot / n
         ach = km["flops"] / avg_ms / 1e9
         roofline = {"kernel": tag, "bound": km["bound"], "achieved": round(ach, 2), "peak": km["peak"],
-                    "unit": "TFLOP/s", "frac": round(ach / km["peak"], 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(ach / km["peak"], 4), "traffic": pmc_traffic(tag),
                     "avg_launch_ms": round(avg_ms, 4), "launches_per_step": n / args.steps}
     knn_ms = sum(tot for tag, (n, tot) in timing.items() if tag.startswith("knn_model")) / args.steps
     res = {
