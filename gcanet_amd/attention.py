@@ -1,0 +1,49 @@
+"""Attention core shared by gcanet_amd.transformer and gcanet_amd.query_decoder: forward through the
+fused HIP kernel (csrc/attention.hip), backward by recomputing the probabilities from the saved
+log-sum-exp (flash-attention style, in torch ops this round)."""
+import torch
+
+from . import _lib
+
+
+class SDPAFunction(torch.autograd.Function):
+    """out = softmax(scale * q k^T [+ mask]) v  for q (BH,Lq,D), k/v (BH,Lk,D); mask: bool, True = masked out."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, mask, scale):
+        _lib.require_cuda(q, k, v)
+        q, k, v = q.float().contiguous(), k.float().contiguous(), v.float().contiguous()
+        BH, Lq, D = q.shape
+        Lk = k.shape[1]
+        out = torch.empty_like(q)
+        lse = torch.empty(BH, Lq, dtype=torch.float32, device=q.device)
+        m8, per_bh = None, 0
+        if mask is not None:
+            m8 = mask.to(torch.uint8).contiguous()
+            per_bh = 1 if m8.dim() == 3 else 0
+        with torch.cuda.device_of(q):
+            _lib.call("gcn_attention_fwd", _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(m8), per_bh, BH, Lq, Lk, D,
+                      float(scale), _lib.ptr(out), _lib.ptr(lse), _lib.stream_of(q),
+                      tag="attention_fwd[BH=%d,Lq=%d,Lk=%d,D=%d]" % (BH, Lq, Lk, D))
+        ctx.save_for_backward(q, k, v, out, lse, m8 if m8 is not None else torch.empty(0, device=q.device))
+        ctx.scale = scale
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, out, lse, m8 = ctx.saved_tensors
+        s = torch.bmm(q, k.transpose(1, 2)) * ctx.scale
+        if m8.numel():
+            s = s.masked_fill(m8.bool() if m8.dim() == 3 else m8.bool().unsqueeze(0), float("-inf"))
+        p = torch.exp(s - lse.unsqueeze(-1))                      # recomputed probabilities
+        dv = torch.bmm(p.transpose(1, 2), dout)
+        dp = torch.bmm(dout, v.transpose(1, 2))
+        delta = (dout * out).sum(-1, keepdim=True)
+        ds = p * (dp - delta) * ctx.scale
+        return torch.bmm(ds, k), torch.bmm(ds.transpose(1, 2), q), dv, None, None
+
+
+def sdpa(q, k, v, mask=None, scale=None):
+    if scale is None:
+        scale = q.shape[-1] ** -0.5
+    return SDPAFunction.apply(q, k, v, mask, scale)

@@ -299,6 +299,17 @@ int gcn_gn_bwd(const void *dy, const void *x, int dtype, const float *gamma, con
                const float *mean_rstd, int B, int N, int C, int G, int relu, void *dx, float *dgamma,
                float *dbeta, double *s_ws, void *stream);
 
+/* ------------------------------------------------------------- attention stacks ------ */
+
+/* Fused scaled-dot-product attention forward (online softmax; the (Lq x Lk) score matrix never
+ * reaches HBM).  Replaces the unfused einsum -> softmax -> einsum of models/transformer.py:52-69
+ * (which materialises (b,h,n,n)) and the attention core of nn.MultiheadAttention used by
+ * models/query_decoder.py:12,54.  q (BH,Lq,D), k/v (BH,Lk,D) f32 contiguous (BH = batch*heads);
+ * mask: optional bytes, 1 = key masked out, (Lq,Lk) shared by all BH or (BH,Lq,Lk) if mask_per_bh;
+ * out (BH,Lq,D) = softmax(scale * q.k^T) v;  lse (BH,Lq) optional log-sum-exp.  D in {8,16,32,64}. */
+int gcn_attention_fwd(const float *q, const float *k, const float *v, const uint8_t *mask, int mask_per_bh,
+                      int BH, int Lq, int Lk, int D, float scale, float *out, float *lse, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
