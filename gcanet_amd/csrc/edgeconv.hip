@@ -93,6 +93,7 @@ struct EcArgs {
   float *ymax, *ymin;       // (B,N,Cout)
   unsigned char *amax, *amin;
   double *gsum;             // (B,G,2)
+  const float *gamma_route; // non-null: keep only the extreme GroupNorm+LeakyReLU will route (max if gamma>=0 else min)
 };
 
 // KSTEPS = 2*Cp/16 (= Cp/8 = 16-B chunks per row), CW = Cout/32 column groups,
@@ -105,7 +106,7 @@ struct EcArgs {
 // them share a CU and drift out of phase: one workgroup's VALU epilogue overlaps the other's MFMAs.
 // The neighbour ids of tile t+2 are fetched while tile t computes, so the DMA issue of tile t+1 never
 // waits on a dependent global load.  RWT == 2 (128 < k <= 255) keeps the cross-wave LDS combine.
-template <int KSTEPS, int CW, int RWT, bool WITH_ARG>
+template <int KSTEPS, int CW, int RWT, bool WITH_ARG, bool ROUTED>
 __global__ __launch_bounds__(64 * RWT * CW, 2) void edgeconv_fwd_bf16_kernel(EcArgs a) {
   constexpr int NC = KSTEPS;               // chunks per x row
   constexpr int CP = KSTEPS * 8;           // padded channels
@@ -135,6 +136,9 @@ __global__ __launch_bounds__(64 * RWT * CW, 2) void edgeconv_fwd_bf16_kernel(EcA
 #pragma unroll
   for (int s = 0; s < KSTEPS; ++s)
     breg[s] = *reinterpret_cast<const bf16x8 *>(a.wp + (long)(cg * 32 + lr) * K + s * 16 + lh * 8);
+
+  // routed mode: sgn = +1 keeps the max, -1 turns the min into a max of the negated column
+  const float sgn = ROUTED ? (a.gamma_route[cg * 32 + lr] >= 0.f ? 1.f : -1.f) : 1.f;
 
   const int G = gridDim.x;
   const int t_begin = (int)((long)blockIdx.x * a.total_tiles / G);
@@ -279,12 +283,6 @@ __global__ __launch_bounds__(64 * RWT * CW, 2) void edgeconv_fwd_bf16_kernel(EcA
         if (blk * 32 >= rows_used) continue;          // wave-uniform: block beyond the tile's points
         if (n0 + (blk * 32) / kp >= a.N) continue;    // tail tile: point past the end of the cloud
         const int rbase = (blk * 32) % kp + 4 * lh;   // point-row of register 0 (kp % 32 == 0)
-        float mx = acc[rb][0], mn = acc[rb][0];
-#pragma unroll
-        for (int i = 1; i < 16; ++i) {
-          mx = fmaxf(mx, acc[rb][i]);
-          mn = fminf(mn, acc[rb][i]);
-        }
         float ps = 0.f, pq = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -295,6 +293,16 @@ __global__ __launch_bounds__(64 * RWT * CW, 2) void edgeconv_fwd_bf16_kernel(EcA
         }
         s1 += ps;
         s2 += pq;
+        if (ROUTED) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[rb][i] *= sgn;   // exact; min becomes max of the negated column
+        }
+        float mx = acc[rb][0], mn = acc[rb][0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) {
+          mx = fmaxf(mx, acc[rb][i]);
+          if (!ROUTED) mn = fminf(mn, acc[rb][i]);
+        }
         int ax = 0x7fffffff, an = 0x7fffffff;
         if (WITH_ARG) {
           // the point-row of register i grows with i, so the lowest row is the lowest i
@@ -302,17 +310,21 @@ __global__ __launch_bounds__(64 * RWT * CW, 2) void edgeconv_fwd_bf16_kernel(EcA
 #pragma unroll
           for (int i = 15; i >= 0; --i) {
             ix = acc[rb][i] == mx ? i : ix;
-            in_ = acc[rb][i] == mn ? i : in_;
+            if (!ROUTED) in_ = acc[rb][i] == mn ? i : in_;
           }
           ax = rbase + (ix & 3) + 8 * (ix >> 2);
           an = rbase + (in_ & 3) + 8 * (in_ >> 2);
         }
         // combine the two half-waves (rows 4h..)
-        const float mx2 = __shfl_xor(mx, 32), mn2 = __shfl_xor(mn, 32);
+        const float mx2 = __shfl_xor(mx, 32);
+        const float mn2 = ROUTED ? mn : __shfl_xor(mn, 32);
         if (WITH_ARG) {
-          const int ax2 = __shfl_xor(ax, 32), an2 = __shfl_xor(an, 32);
+          const int ax2 = __shfl_xor(ax, 32);
           ax = mx2 > mx ? ax2 : (mx2 == mx ? min(ax, ax2) : ax);
-          an = mn2 < mn ? an2 : (mn2 == mn ? min(an, an2) : an);
+          if (!ROUTED) {
+            const int an2 = __shfl_xor(an, 32);
+            an = mn2 < mn ? an2 : (mn2 == mn ? min(an, an2) : an);
+          }
         }
         mx = fmaxf(mx, mx2);
         mn = fminf(mn, mn2);
@@ -349,11 +361,11 @@ __global__ __launch_bounds__(64 * RWT * CW, 2) void edgeconv_fwd_bf16_kernel(EcA
               }
             }
             const long o = ((long)b * a.N + n0 + pt) * COUT + cg * 32 + lr;
-            a.ymax[o] = mx;
-            a.ymin[o] = mn;
+            a.ymax[o] = ROUTED ? mx * sgn : mx;
+            if (!ROUTED) a.ymin[o] = mn;
             if (WITH_ARG) {
               a.amax[o] = (unsigned char)ax;
-              a.amin[o] = (unsigned char)an;
+              if (!ROUTED) a.amin[o] = (unsigned char)an;
             }
           }
         }
@@ -393,11 +405,11 @@ __global__ __launch_bounds__(64 * RWT * CW, 2) void edgeconv_fwd_bf16_kernel(EcA
           mn = fminf(mn, v2);
         }
         const long o = ((long)b * a.N + n) * Cout + col;
-        a.ymax[o] = mx;
-        a.ymin[o] = mn;
+        a.ymax[o] = ROUTED ? mx * (a.gamma_route[col] >= 0.f ? 1.f : -1.f) : mx;
+        if (!ROUTED) a.ymin[o] = mn;
         if (WITH_ARG) {
           a.amax[o] = (unsigned char)ax;
-          a.amin[o] = (unsigned char)an;
+          if (!ROUTED) a.amin[o] = (unsigned char)an;
         }
       }
     }
@@ -415,7 +427,8 @@ __global__ __launch_bounds__(256) void edgeconv_fwd_f32_kernel(const float *__re
                                                                const int64_t *__restrict__ idx, int N, int NX, int C, int k,
                                                                int Cout, int G, float *__restrict__ ymax,
                                                                float *__restrict__ ymin, unsigned char *__restrict__ amax,
-                                                               unsigned char *__restrict__ amin, double *__restrict__ gsum) {
+                                                               unsigned char *__restrict__ amin, double *__restrict__ gsum,
+                                                               const float *__restrict__ gamma_route) {
   extern __shared__ float e[];  // [k][2C] edge rows, then [Cout] scratch for sums
   const int n = blockIdx.x, b = blockIdx.y;
   const float *xb = x + (long)b * NX * C;
@@ -443,8 +456,14 @@ __global__ __launch_bounds__(256) void edgeconv_fwd_f32_kernel(const float *__re
       s2 += (double)y * (double)y;
     }
     const long o = ((long)b * N + n) * Cout + co;
-    ymax[o] = mx; ymin[o] = mn;
-    if (amax) { amax[o] = (unsigned char)ax; amin[o] = (unsigned char)an; }
+    if (gamma_route) {  // routed mode: only the extreme that GroupNorm+LeakyReLU will select
+      const bool pos = gamma_route[co] >= 0.f;
+      ymax[o] = pos ? mx : mn;
+      if (amax) amax[o] = (unsigned char)(pos ? ax : an);
+    } else {
+      ymax[o] = mx; ymin[o] = mn;
+      if (amax) { amax[o] = (unsigned char)ax; amin[o] = (unsigned char)an; }
+    }
     gs[co * 2] = s1; gs[co * 2 + 1] = s2;
   }
   __syncthreads();
@@ -480,7 +499,7 @@ __global__ __launch_bounds__(256) void edgeconv_finish_kernel(const float *__res
       const float mean = (float)m, rstd = (float)(1.0 / sqrt(var + (double)eps));
       const float ga = gamma[c];
       const long o = ((long)b * N + n) * Cout + c;
-      const float y = ga >= 0.f ? ymax[o] : ymin[o];
+      const float y = (ga >= 0.f || ymin == nullptr) ? ymax[o] : ymin[o];   // ymin == NULL: ymax already holds the routed extreme
       const float z = (y - mean) * rstd * ga + beta[c];
       v = z > 0.f ? z : z * slope;
       if (out_pm) out_pm[o] = v;
@@ -689,7 +708,8 @@ static int launch_fwd_bf16(EcArgs &a, bool with_arg, hipStream_t st) {
   const int by_lds = (160 * 1024) / (lds_bytes > 0 ? lds_bytes : 1);
   const int resident = 256 * (wg_per_cu < by_lds ? wg_per_cu : by_lds);
   int grid = a.total_tiles < resident ? a.total_tiles : resident;
-  auto kern = with_arg ? edgeconv_fwd_bf16_kernel<KSTEPS, CW, RWT, true> : edgeconv_fwd_bf16_kernel<KSTEPS, CW, RWT, false>;
+  auto kern = a.gamma_route ? (with_arg ? edgeconv_fwd_bf16_kernel<KSTEPS, CW, RWT, true, true> : edgeconv_fwd_bf16_kernel<KSTEPS, CW, RWT, false, true>)
+                            : (with_arg ? edgeconv_fwd_bf16_kernel<KSTEPS, CW, RWT, true, false> : edgeconv_fwd_bf16_kernel<KSTEPS, CW, RWT, false, false>);
   GCN_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
   kern<<<grid, 64 * RWT * CW, lds_bytes, st>>>(a);
   return check_launch("edgeconv_fwd_bf16_kernel");
@@ -726,9 +746,10 @@ GCN_EXPORT int gcn_edgeconv_pack_w(const float *w, int Cout, int C, void *wp_bf1
 
 GCN_EXPORT int gcn_edgeconv_fwd(const void *x_pm, const void *w, const int64_t *idx, int dtype, int B, int N, int NX,
                                 int C, int k, int Cout, int G, float *ymax, float *ymin, uint8_t *amax, uint8_t *amin,
-                                double *gsum, void *stream) {
-  GCN_REQUIRE(x_pm && w && idx && ymax && ymin && gsum, "gcn_edgeconv_fwd: null pointer");
-  GCN_REQUIRE((amax == nullptr) == (amin == nullptr), "gcn_edgeconv_fwd: pass both amax and amin or neither");
+                                double *gsum, const float *gamma_route, void *stream) {
+  GCN_REQUIRE(x_pm && w && idx && ymax && gsum, "gcn_edgeconv_fwd: null pointer");
+  GCN_REQUIRE(gamma_route || ymin, "gcn_edgeconv_fwd: ymin may be NULL only in routed mode (gamma_route given)");
+  GCN_REQUIRE(gamma_route || (amax == nullptr) == (amin == nullptr), "gcn_edgeconv_fwd: pass both amax and amin or neither");
   GCN_REQUIRE(dtype == 0 || dtype == 1, "gcn_edgeconv_fwd: dtype must be 0 (f32) or 1 (bf16)");
   GCN_REQUIRE(B >= 0 && N >= 1 && NX >= N && C >= 1 && k >= 1 && k <= 255, "gcn_edgeconv_fwd: bad shape (need NX >= N, 1 <= k <= 255)");
   GCN_REQUIRE(G >= 1 && Cout % G == 0, "gcn_edgeconv_fwd: Cout=%d not divisible by G=%d", Cout, G);
@@ -740,7 +761,7 @@ GCN_EXPORT int gcn_edgeconv_fwd(const void *x_pm, const void *w, const int64_t *
     GCN_REQUIRE(lds <= 150 * 1024, "gcn_edgeconv_fwd(f32): k*2C too large for the exact path (%zu B LDS)", lds);
     GCN_HIP(hipFuncSetAttribute((const void *)edgeconv_fwd_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     edgeconv_fwd_f32_kernel<<<dim3(N, B), 256, lds, st>>>((const float *)x_pm, (const float *)w, idx, N, NX, C, k, Cout, G,
-                                                          ymax, ymin, amax, amin, gsum);
+                                                          ymax, ymin, amax, amin, gsum, gamma_route);
     return check_launch("edgeconv_fwd_f32_kernel");
   }
   GCN_REQUIRE(Cout == 64 || Cout == 128, "gcn_edgeconv_fwd(bf16): Cout must be 64 or 128, got %d", Cout);
@@ -750,7 +771,7 @@ GCN_EXPORT int gcn_edgeconv_fwd(const void *x_pm, const void *w, const int64_t *
   EcArgs a{};
   a.x = (const unsigned short *)x_pm; a.wp = (const unsigned short *)w; a.idx = idx;
   a.B = B; a.N = N; a.NX = NX; a.k = k; a.kp = (k + 31) / 32 * 32; a.Cout = Cout; a.G = G;
-  a.ymax = ymax; a.ymin = ymin; a.amax = amax; a.amin = amin; a.gsum = gsum;
+  a.ymax = ymax; a.ymin = ymin; a.amax = amax; a.amin = amin; a.gsum = gsum; a.gamma_route = gamma_route;
   const bool wa = amax != nullptr;
   const int ks = Cp / 8;
 #define EC_CASE(KS, CWV) \
@@ -765,7 +786,7 @@ GCN_EXPORT int gcn_edgeconv_fwd(const void *x_pm, const void *w, const int64_t *
 GCN_EXPORT int gcn_edgeconv_finish(const float *ymax, const float *ymin, const double *gsum, const float *gamma,
                                    const float *beta, int B, int N, int k, int Cout, int G, float eps, float slope,
                                    float *out_cm, float *out_pm, float *mean_rstd, void *stream) {
-  GCN_REQUIRE(ymax && ymin && gsum && gamma && beta && (out_cm || out_pm), "gcn_edgeconv_finish: null pointer");
+  GCN_REQUIRE(ymax && gsum && gamma && beta && (out_cm || out_pm), "gcn_edgeconv_finish: null pointer");
   GCN_REQUIRE(B >= 0 && N >= 1 && k >= 1 && G >= 1 && Cout % G == 0, "gcn_edgeconv_finish: bad shape");
   if (B == 0) return GCN_OK;
   edgeconv_finish_kernel<<<dim3(cdiv(N, 32), cdiv(Cout, 32), B), 256, 0, (hipStream_t)stream>>>(

@@ -39,8 +39,8 @@ __global__ __launch_bounds__(256) void route_bwd_kernel(const float *__restrict_
     float dg = 0.f, db = 0.f, s1 = 0.f, s2 = 0.f;
     for (int n = r0 + threadIdx.x / nct; n < r1; n += rstep) {
       const long o = ((long)b * N + n) * Cout + c;
-      const float ys = pos ? ymax[o] : ymin[o];
-      const int js = pos ? amax[o] : amin[o];
+      const float ys = (pos || ymin == nullptr) ? ymax[o] : ymin[o];   // ymin == NULL: routed forward
+      const int js = (pos || amin == nullptr) ? amax[o] : amin[o];
       const float yh = (ys - mean) * rstd;
       const float z = yh * ga + be;
       const float gz = dout[o] * (z > 0.f ? 1.f : slope);
@@ -165,7 +165,7 @@ GCN_EXPORT int gcn_route_bwd(const float *dout_pm, const float *ymax, const floa
                              const int64_t *idx, int B, int N, int k, int Cout, int G, float slope, float *coef,
                              int64_t *jsel, int64_t *msel, float *dsp, float *dgamma, float *dbeta, double *S,
                              void *stream) {
-  GCN_REQUIRE(dout_pm && ymax && ymin && amax && amin && gamma && beta && mean_rstd && coef && dgamma && dbeta && S,
+  GCN_REQUIRE(dout_pm && ymax && amax && gamma && beta && mean_rstd && coef && dgamma && dbeta && S,
               "gcn_route_bwd: null pointer");
   GCN_REQUIRE(B >= 0 && N >= 1 && Cout >= 1 && G >= 1 && Cout % G == 0, "gcn_route_bwd: bad shape");
   GCN_REQUIRE((Cout <= 256 && 256 % Cout == 0) || Cout % 256 == 0, "gcn_route_bwd: Cout=%d unsupported", Cout);

@@ -74,12 +74,12 @@ def edgeconv_forward_raw(x, idx, weight, gamma, beta, groups, dtype="bf16", eps=
         _run("gcn_edgeconv_pack_x", x, _lib.ptr(x), B, C, N, _lib.ptr(x_bf), _lib.ptr(x_pm))
         _run("gcn_edgeconv_pack_w", x, _lib.ptr(w), Cout, C, _lib.ptr(wp))
         _run("gcn_edgeconv_fwd", x, _lib.ptr(x_bf), _lib.ptr(wp), _lib.ptr(idx), 1, B, N, N, C, k, Cout, groups,
-             _lib.ptr(ymax), _lib.ptr(ymin), _lib.ptr(amax), _lib.ptr(amin), _lib.ptr(gsum),
+             _lib.ptr(ymax), _lib.ptr(ymin), _lib.ptr(amax), _lib.ptr(amin), _lib.ptr(gsum), None,
              tag="edgeconv_fwd[B=%d,N=%d,k=%d,C=%d,Cout=%d]" % (B, N, k, C, Cout))
     elif dtype == "f32":
         _run("gcn_edgeconv_pack_x", x, _lib.ptr(x), B, C, N, None, _lib.ptr(x_pm))
         _run("gcn_edgeconv_fwd", x, _lib.ptr(x_pm), _lib.ptr(w), _lib.ptr(idx), 0, B, N, N, C, k, Cout, groups,
-             _lib.ptr(ymax), _lib.ptr(ymin), _lib.ptr(amax), _lib.ptr(amin), _lib.ptr(gsum))
+             _lib.ptr(ymax), _lib.ptr(ymin), _lib.ptr(amax), _lib.ptr(amin), _lib.ptr(gsum), None)
     else:
         raise ValueError("dtype must be 'bf16' or 'f32'")
     out = torch.empty(B, Cout, N, **f32)
@@ -238,11 +238,11 @@ class GroupedBlockFunction(torch.autograd.Function):
             _run("gcn_edgeconv_pack_x", ef, _lib.ptr(rows), B, F, N * k, _lib.ptr(x_bf), None)
             _run("gcn_edgeconv_pack_w", ef, _lib.ptr(w2.contiguous()), Cout, F, _lib.ptr(wp))   # W' = [W | 0]
             _run("gcn_edgeconv_fwd", ef, _lib.ptr(x_bf), _lib.ptr(wp), _lib.ptr(ident), 1, B, N, N * k, F, k, Cout,
-                 groups, _lib.ptr(ymax), _lib.ptr(ymin), _lib.ptr(amax), _lib.ptr(amin), _lib.ptr(gsum))
+                 groups, _lib.ptr(ymax), _lib.ptr(ymin), _lib.ptr(amax), _lib.ptr(amin), _lib.ptr(gsum), None)
         else:   # exact path: W.(x_j - x_i) + W.x_i
             flat = ef.reshape(B, N * k, F)
             _run("gcn_edgeconv_fwd", ef, _lib.ptr(flat), _lib.ptr(w2.contiguous()), _lib.ptr(ident), 0, B, N, N * k, F,
-                 k, Cout, groups, _lib.ptr(ymax), _lib.ptr(ymin), _lib.ptr(amax), _lib.ptr(amin), _lib.ptr(gsum))
+                 k, Cout, groups, _lib.ptr(ymax), _lib.ptr(ymin), _lib.ptr(amax), _lib.ptr(amin), _lib.ptr(gsum), None)
         out_cm, out_pm, mean_rstd = _finish(ymax, ymin, gsum, gamma.float().contiguous(), beta.float().contiguous(),
                                             B, N, k, Cout, groups, eps, slope, not pm_out, pm_out)
         ctx.save_for_backward(ef, weight, gamma, beta, ymax, ymin, amax, amin, mean_rstd)
@@ -294,6 +294,8 @@ def _route_backward_fused(dout_pm, gamma, beta, ymax, ymin, amax, amin, mean_rst
     dgamma = torch.empty(Cout, dtype=torch.float32, device=dev)
     dbeta = torch.empty(Cout, dtype=torch.float32, device=dev)
     S = torch.empty(B, G, 2, dtype=torch.float64, device=dev)
+    ymin = ymin if (ymin is not None and ymin.numel()) else None
+    amin = amin if (amin is not None and amin.numel()) else None
     _run("gcn_route_bwd", ymax, _lib.ptr(dout_pm), _lib.ptr(ymax), _lib.ptr(ymin), _lib.ptr(amax), _lib.ptr(amin),
          _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(mean_rstd), _lib.ptr(idx), B, N, k, Cout, G, float(slope),
          _lib.ptr(coef), _lib.ptr(jsel), None, _lib.ptr(dsp), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(S))
@@ -654,9 +656,10 @@ class EdgeConvPMFunction(torch.autograd.Function):
         w = weight.float().contiguous()
         ga, be = gamma.float().contiguous(), beta.float().contiguous()
         f32 = dict(dtype=torch.float32, device=dev)
-        ymax, ymin = torch.empty(B, N, Cout, **f32), torch.empty(B, N, Cout, **f32)
+        # ROUTED forward: only the extreme GroupNorm+LeakyReLU will select is kept (ymin/amin not produced)
+        ymax = torch.empty(B, N, Cout, **f32)
         amax = torch.empty(B, N, Cout, dtype=torch.uint8, device=dev)
-        amin = torch.empty(B, N, Cout, dtype=torch.uint8, device=dev)
+        ymin = amin = None
         gsum = torch.empty(B, groups, 2, dtype=torch.float64, device=dev)
         if dtype == "bf16":
             Cp = _lib.lib().gcn_edgeconv_padded_channels(C)
@@ -665,13 +668,14 @@ class EdgeConvPMFunction(torch.autograd.Function):
             _run("gcn_cast_pad_bf16", x, _lib.ptr(x), B * N, C, _lib.ptr(x_bf))
             _run("gcn_edgeconv_pack_w", x, _lib.ptr(w), Cout, C, _lib.ptr(wp))
             _run("gcn_edgeconv_fwd", x, _lib.ptr(x_bf), _lib.ptr(wp), _lib.ptr(idx), 1, B, N, N, C, k, Cout, groups,
-                 _lib.ptr(ymax), _lib.ptr(ymin), _lib.ptr(amax), _lib.ptr(amin), _lib.ptr(gsum),
+                 _lib.ptr(ymax), None, _lib.ptr(amax), None, _lib.ptr(gsum), _lib.ptr(ga),
                  tag="edgeconv_fwd[B=%d,N=%d,k=%d,C=%d,Cout=%d]" % (B, N, k, C, Cout))
         else:
             _run("gcn_edgeconv_fwd", x, _lib.ptr(x), _lib.ptr(w), _lib.ptr(idx), 0, B, N, N, C, k, Cout, groups,
-                 _lib.ptr(ymax), _lib.ptr(ymin), _lib.ptr(amax), _lib.ptr(amin), _lib.ptr(gsum))
+                 _lib.ptr(ymax), None, _lib.ptr(amax), None, _lib.ptr(gsum), _lib.ptr(ga))
         out_cm, out_pm, mean_rstd = _finish(ymax, ymin, gsum, ga, be, B, N, k, Cout, groups, eps, slope, want_cm, True)
-        ctx.save_for_backward(x, idx, w, ga, be, ymax, ymin, amax, amin, mean_rstd)
+        empty = torch.empty(0, device=dev)
+        ctx.save_for_backward(x, idx, w, ga, be, ymax, empty, amax, empty, mean_rstd)
         ctx.cfg = (groups, slope)
         if out_cm is None:
             out_cm = torch.empty(0, device=dev)

@@ -206,14 +206,17 @@ int gcn_hierarchical_aggregation_host(const int32_t *semantic_label_host, const 
  *   gsum   (B,G,2) f64: per-(cloud, group) sum and sum of squares of the raw conv output over
  *          all N*k*(Cout/G) elements (zeroed by the call).
  * y -> LeakyReLU(gamma*(y-mu)*rstd+beta) is monotone, so max_k f(y_k) = f(max_k y_k) for
- * gamma >= 0 and f(min_k y_k) for gamma < 0, bitwise; gcn_edgeconv_finish applies it. */
+ * gamma >= 0 and f(min_k y_k) for gamma < 0, bitwise; gcn_edgeconv_finish applies it.
+ * ROUTED mode (gamma_route = the GroupNorm gain (Cout), non-NULL): only the extreme that will be
+ * routed is kept -- ymax/amax receive max for gamma_c >= 0 and min otherwise; ymin/amin may be NULL
+ * (halves the epilogue work and the output bytes; gcn_edgeconv_finish / gcn_route_bwd accept NULL ymin). */
 int gcn_edgeconv_padded_channels(int C);
 int gcn_edgeconv_pack_x(const float *x_cm, int B, int C, int N, void *x_pm_bf16, float *x_pm_f32,
                         void *stream);
 int gcn_edgeconv_pack_w(const float *w, int Cout, int C, void *wp_bf16, void *stream);
 int gcn_edgeconv_fwd(const void *x_pm, const void *w, const int64_t *idx, int dtype, int B, int N,
                      int NX, int C, int k, int Cout, int G, float *ymax, float *ymin, uint8_t *amax,
-                     uint8_t *amin, double *gsum, void *stream);
+                     uint8_t *amin, double *gsum, const float *gamma_route, void *stream);
 
 /* Point-major operand preparation when activations are already (rows, C) f32: cast to bf16 and zero-pad
  * the channel axis to gcn_edgeconv_padded_channels(C) (no transpose, unlike gcn_edgeconv_pack_x). */

@@ -28,9 +28,27 @@ ymin = torch.empty(B, N, Cout, device=dev)
 amax = torch.empty(B, N, Cout, dtype=torch.uint8, device=dev)
 amin = torch.empty(B, N, Cout, dtype=torch.uint8, device=dev)
 gsum = torch.empty(B, 2, 2, dtype=torch.float64, device=dev)
+ga = torch.randn(Cout, generator=g).to(dev)
+for routed in (False, True):
+  for with_arg in (True, False):
+    if routed:
+        args = (_lib.ptr(x_bf), _lib.ptr(wp), _lib.ptr(idx), 1, B, N, N, C, k, Cout, 2, _lib.ptr(ymax), None,
+                _lib.ptr(amax) if with_arg else None, None, _lib.ptr(gsum), _lib.ptr(ga), st)
+        for _ in range(2):
+            _lib.call("gcn_edgeconv_fwd", *args)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            _lib.call("gcn_edgeconv_fwd", *args)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        print("edgeconv_fwd ROUTED C=%d Cout=%d arg=%d: %.3f ms  %.1f TFLOP/s (%.1f%% of 2.5 PF)" % (
+            C, Cout, with_arg, ms, 2.0 * B * N * k * 2 * C * Cout / ms / 1e9, 2.0 * B * N * k * 2 * C * Cout / ms / 1e9 / 25))
 for with_arg in (True, False):
     args = (_lib.ptr(x_bf), _lib.ptr(wp), _lib.ptr(idx), 1, B, N, N, C, k, Cout, 2, _lib.ptr(ymax), _lib.ptr(ymin),
-            _lib.ptr(amax) if with_arg else None, _lib.ptr(amin) if with_arg else None, _lib.ptr(gsum), st)
+            _lib.ptr(amax) if with_arg else None, _lib.ptr(amin) if with_arg else None, _lib.ptr(gsum), None, st)
     for _ in range(2):
         _lib.call("gcn_edgeconv_fwd", *args)
     torch.cuda.synchronize()
