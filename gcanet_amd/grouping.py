@@ -1,0 +1,122 @@
+"""Callers on either side of the SoftGroup ops in the reference model (models/dgcnn-hais-concat-direct-4.py,
+"M4"): forward_grouping (M4:1123-1295), compute_batch_adjacency_matrix (M4:210-233), clusters_voxelization
+(M4:1300-1355), global_pool (M4:1358-1370), get_batch_offsets (M4:1372-1377) -- same argument meaning and
+results, built on the drop-in ops of gcanet_amd.softgroup.ops.
+
+Differences that do not change results:
+  * get_batch_offsets is one bincount + cumsum (the reference loops over the batch with a device sync per item);
+  * no torch.cuda.empty_cache() calls (M4:1189,1250);
+  * clusters_voxelization returns the sparse-tensor FIELDS (features, int32 (M,4) coords [cluster,x,y,z],
+    spatial_shape, batch_size) instead of an spconv.SparseConvTensor -- spconv is an un-vendored third-party
+    package; the tuple is the stable on-wire format for any sparse-conv backend.
+Reference quirk kept: proposals index points WITHIN their cloud (object_idxs are per-cloud positions,
+M4:1270), although the features they are applied to are flattened over the batch.
+"""
+import torch
+
+from .softgroup.ops import (ball_query, global_avg_pool, hierarchical_aggregation, sec_max, sec_min, voxelization,
+                            voxelization_idx)
+
+
+def compute_batch_adjacency_matrix(batch_point_clouds, radius=0, dist_state=True, sigma=1.0):
+    """M4:210-233: cdist -> zero diagonal -> GLOBAL min/max normalisation -> Gaussian -> zero diagonal."""
+    distances = torch.cdist(batch_point_clouds, batch_point_clouds)
+    adjacency = distances if dist_state else (distances <= radius).float()
+    adjacency = adjacency - torch.diag_embed(torch.diagonal(adjacency, dim1=-2, dim2=-1))
+    mn, mx = adjacency.min(), adjacency.max()
+    adjacency = (adjacency - mn) / (mx - mn)
+    adjacency = torch.exp(-adjacency ** 2 / (2 * sigma ** 2))
+    return adjacency - torch.diag_embed(torch.diagonal(adjacency, dim1=-2, dim2=-1))
+
+
+def get_batch_offsets(batch_idxs, bs):
+    """M4:1372-1377 -> int32 (bs+1) on the device of batch_idxs."""
+    counts = torch.bincount(batch_idxs.reshape(-1).long(), minlength=bs)[:bs]
+    return torch.cat([counts.new_zeros(1), torch.cumsum(counts, 0)]).int()
+
+
+def forward_grouping(semantic_scores, pt_offsets, batch_idxs, coords_float, type_per_point, param_per_point,
+                     feature_per_point, semantic_classes=10, training_mode='train', using_set_aggr=False,
+                     radius=0.03, similarity_threshold_inst=0.989, similarity_threshold_para=0.0, mean_active=300,
+                     min_npoint=50):
+    """M4:1123-1295.  semantic_scores (B*N,P), pt_offsets (B*N,3), batch_idxs (B*N), coords_float (B*N,3),
+    type_per_point (B,N,P) [shape donor], param_per_point (B,N,22), feature_per_point (B,N,emb).
+    Returns (proposals_idx (S,2) int32 CPU [cluster id, point index within its cloud], proposals_offset int32 CPU)."""
+    B, N = type_per_point.shape[0], type_per_point.shape[1]
+    batch_size = int(batch_idxs.max()) + 1
+    semantic_scores = semantic_scores.softmax(dim=-1).view(B, N, -1)
+    coords_float = coords_float.view(B, N, -1)
+    pt_offsets = pt_offsets.view(B, N, -1)
+    batch_idxs = batch_idxs.view(B, N, -1)
+    proposals_idx_list, proposals_offset_list = [], []
+    for b in range(batch_size):
+        labels = semantic_scores[b].argmax(dim=1)
+        for class_id in range(semantic_classes):
+            object_idxs = (labels == class_id).nonzero().view(-1)
+            if object_idxs.size(0) < min_npoint:
+                continue
+            batch_idxs_ = batch_idxs[b][object_idxs].reshape(-1).int().contiguous()
+            shifted = (coords_float[b][object_idxs] + pt_offsets[b][object_idxs]).float().contiguous()
+            batch_offsets_ = get_batch_offsets(batch_idxs_, batch_size)
+            adj_inst = compute_batch_adjacency_matrix(feature_per_point[b][object_idxs].float().unsqueeze(0)).squeeze(0)
+            adj_para = compute_batch_adjacency_matrix(param_per_point[b][object_idxs].float().unsqueeze(0)).squeeze(0)
+            neighbor_inds, start_len = ball_query(shifted, batch_idxs_, batch_offsets_, adj_inst.contiguous(),
+                                                  similarity_threshold_inst, adj_para.contiguous(),
+                                                  similarity_threshold_para, radius, mean_active)
+            semantic_preds_cpu = torch.full((object_idxs.numel(),), class_id, dtype=torch.int32)
+            proposals_idx, proposals_offset = hierarchical_aggregation(
+                semantic_preds_cpu, shifted.cpu(), neighbor_inds.cpu(), start_len.cpu(), batch_idxs_.cpu(),
+                training_mode, using_set_aggr if training_mode != 'train' else False)
+            proposals_idx[:, 1] = object_idxs.cpu()[proposals_idx[:, 1].long()].int()
+            if len(proposals_offset_list) > 0:          # merge proposals (M4:1273-1276)
+                proposals_idx[:, 0] += sum(x.size(0) for x in proposals_offset_list) - 1
+                proposals_offset = (proposals_offset + proposals_offset_list[-1][-1])[1:]
+            if proposals_idx.size(0) > 0:
+                proposals_idx_list.append(proposals_idx)
+                proposals_offset_list.append(proposals_offset)
+    if proposals_idx_list:
+        return torch.cat(proposals_idx_list, dim=0), torch.cat(proposals_offset_list)
+    return torch.zeros((0, 2), dtype=torch.int32), torch.zeros((0,), dtype=torch.int32)
+
+
+def clusters_voxelization(clusters_idx, clusters_offset, feats, coords, scale, spatial_shape, rand_quantize=False,
+                          rand=None):
+    """M4:1300-1355.  clusters_idx (S,2) int32 CPU, clusters_offset (P+1) int32 CPU, feats (M,C) cuda, coords (M,3)
+    cuda.  Returns (voxel_feats (V,C) cuda, voxel_coords (V,4) int32 cuda, [spatial_shape]*3, batch_size, inp_map).
+    `rand` (two (3,) tensors) replaces the reference's torch.rand(3) draws to make tests reproducible."""
+    dev = feats.device
+    if clusters_idx.size(0) == 0:
+        c = torch.tensor([[0, 0, 0, 0], [0, spatial_shape - 1, spatial_shape - 1, spatial_shape - 1]], dtype=torch.int,
+                         device=dev)
+        return feats[0:2], c, [spatial_shape] * 3, 1, feats.new_zeros((1,), dtype=torch.long)
+    batch_idx = clusters_idx[:, 0].to(dev).long()
+    c_idxs = clusters_idx[:, 1].to(dev).long()
+    feats = feats[c_idxs].float().contiguous()
+    coords = coords[c_idxs].float().contiguous()
+    offs = clusters_offset.to(dev).int().contiguous()
+    coords_min = sec_min(coords, offs)
+    coords_max = sec_max(coords, offs)
+    clusters_scale = 1 / ((coords_max - coords_min) / spatial_shape).max(1)[0] - 0.01
+    clusters_scale = torch.clamp(clusters_scale, min=None, max=scale)
+    coords_min = coords_min * clusters_scale[:, None]
+    coords_max = coords_max * clusters_scale[:, None]
+    coords = coords * clusters_scale[batch_idx][:, None]
+    if rand_quantize:
+        r1, r2 = rand if rand is not None else (torch.rand(3, device=dev), torch.rand(3, device=dev))
+        rng = coords_max - coords_min
+        coords_min = coords_min - torch.clamp(spatial_shape - rng - 0.001, min=0) * r1.to(dev)
+        coords_min = coords_min - torch.clamp(spatial_shape - rng + 0.001, max=0) * r2.to(dev)
+    coords = coords - coords_min[batch_idx]
+    assert coords.shape.numel() == int(((coords >= 0) * (coords < spatial_shape)).sum())
+    coords = torch.cat([clusters_idx[:, 0].view(-1, 1).long(), coords.long().cpu()], 1).contiguous()
+    nb = int(clusters_idx[-1, 0]) + 1
+    out_coords, inp_map, out_map = voxelization_idx(coords, nb)
+    out_feats = voxelization(feats, out_map.to(dev))
+    return out_feats, out_coords.int().to(dev), [spatial_shape] * 3, nb, inp_map
+
+
+def global_pool(features, indices):
+    """M4:1358-1370 (expand=False): per-sample mean of sparse-tensor features; indices = first coord column."""
+    batch_counts = torch.bincount(indices.long())
+    batch_offset = torch.cat([batch_counts.new_zeros(1), torch.cumsum(batch_counts, 0)]).int()
+    return global_avg_pool(features.float().contiguous(), batch_offset)

@@ -51,7 +51,7 @@ def main():
     print("grouping_operation bwd: %8.3f ms  %7.1f GB/s" % (ms, byt / ms / 1e6))
 
 
-if __name__ == "__main__" and "edgeconv" not in sys.argv:
+if __name__ == "__main__" and "edgeconv" not in sys.argv and "softgroup" not in sys.argv:
     main()
 
 
@@ -76,3 +76,33 @@ def bench_edgeconv():
 
 if __name__ == "__main__" and "edgeconv" in sys.argv:
     bench_edgeconv()
+
+
+def bench_softgroup():
+    """BASELINE config 4: one cloud N=100000, voxelize + ball query + aggregate."""
+    from gcanet_amd.softgroup import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(1234)
+    N = 100000
+    xyz = torch.rand(N, 3, generator=g)
+    coords = torch.cat([torch.zeros(N, 1, dtype=torch.int64), (xyz * 128).floor().long()], 1)
+    t0 = time.time(); oc, im, om = ops.voxelization_idx(coords, 1, 4); t_vi = (time.time() - t0) * 1e3
+    feats = torch.rand(N, 64, generator=g).to(dev)
+    omd = om.to(dev)
+    ms = timeit(lambda: ops.voxelization(feats, omd, 4))
+    byt = 4 * N * 64 + 4 * om.numel() + 4 * om.shape[0] * 64
+    print("voxelization_idx (host, N=100k): %.1f ms ; voxelization fwd: %.3f ms %.0f GB/s" % (t_vi, ms, byt / ms / 1e6))
+    xd = xyz.to(dev)
+    bidx = torch.zeros(N, dtype=torch.int32, device=dev)
+    offs = torch.tensor([0, N], dtype=torch.int32, device=dev)
+    ms = timeit(lambda: ops.ball_query_easy(xd, bidx, offs, 0.03, 32), n=3, warm=1)
+    idx, sl = ops.ball_query_easy(xd, bidx, offs, 0.03, 32)
+    print("ball_query_easy N=100k r=0.03: %.3f ms (%d pairs, %.2f G pair-tests/s)" % (ms, idx.numel(), N * N / ms / 1e6))
+    sem = torch.full((N,), 4, dtype=torch.int32)
+    t0 = time.time()
+    pi, po = ops.hierarchical_aggregation(sem, xyz, idx.cpu(), sl.cpu(), torch.zeros(N, dtype=torch.int32), "train", False)
+    print("hierarchical_aggregation (host BFS) N=100k: %.1f ms, %d clusters" % ((time.time() - t0) * 1e3, po.numel() - 1))
+
+
+if __name__ == "__main__" and "softgroup" in sys.argv:
+    bench_softgroup()
