@@ -443,24 +443,24 @@ __global__ __launch_bounds__(256) void knn_mfma_kernel(const float *__restrict__
         const float key = fresh ? -pd : KNN_INF;
         // serial list insertion here: the buffered-bitonic lists (4 VGPRs each x 32 lists) push this
         // kernel to 1 wave/SIMD and lose more than they gain (measured 3.1 vs 2.4 ms)
-        unsigned long long m = __ballot(key < thrv[r]);
-        while (m) {
-          const int l = __ffsll((long long)m) - 1;
-          m &= m - 1;
-          const float ck = readlane_f(key, l);
-          const float th = readlane_f(thrv[r], l);
-          if (ck < th) {
-            const int cj = jbase + cb * 32 + (l & 31);
-            if (l < 32) {
-              top[r][0].insert(ck, cj, lane);
-              const float nt = readlane_f(top[r][0].key[0], klane);
-              thrv[r] = lh == 0 ? nt : thrv[r];
-            } else {
-              top[r][1].insert(ck, cj, lane);
-              const float nt = readlane_f(top[r][1].key[0], klane);
-              thrv[r] = lh == 1 ? nt : thrv[r];
-            }
+        const unsigned long long m = __ballot(key < thrv[r]);
+        if (m) {
+          // every lane that beat the (possibly stale) threshold is inserted without a re-check: a key that no
+          // longer qualifies falls off the end of the 64-entry list by itself; thresholds refresh once per batch
+          unsigned int lo = (unsigned int)m, hi = (unsigned int)(m >> 32);
+          const int cb0 = jbase + cb * 32;
+          while (lo) {
+            const int l = __ffs((int)lo) - 1;
+            lo &= lo - 1;
+            top[r][0].insert(readlane_f(key, l), cb0 + l, lane);
           }
+          while (hi) {
+            const int l = __ffs((int)hi) - 1;
+            hi &= hi - 1;
+            top[r][1].insert(readlane_f(key, l + 32), cb0 + l, lane);
+          }
+          const float t0 = readlane_f(top[r][0].key[0], klane), t1 = readlane_f(top[r][1].key[0], klane);
+          thrv[r] = lh == 0 ? t0 : t1;
         }
       }
     }
