@@ -30,5 +30,8 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no GPU in this container")
     from gcanet_amd import _lib
+    if not os.path.exists(_lib.SO_PATH):      # a source-only checkout: compile the HIP library (a build step,
+        from gcanet_amd import build          # not a fallback -- there is no other implementation to fall back to)
+        build.build(verbose=False)
     _lib.lib()  # raises if libgcanet_hip.so is absent -> loud failure, no silent fallback
     return torch.device("cuda:0")
