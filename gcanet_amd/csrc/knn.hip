@@ -52,12 +52,27 @@ struct TopK {
     if (KPL == 1) {
       // all-VALU form: entries <= ckey stay; the rest take max(left neighbour, ckey) -- no
       // scalar round trip (ballot/popcount) on the critical path
-      const float sk = wave_shr1_f(-KNN_INF, key[0]);
-      const int si = wave_shr1_i(0, idx[0]);
-      const bool keep = key[0] <= ckey;
-      const bool shift = sk > ckey;
-      idx[0] = keep ? idx[0] : (shift ? si : cidx);
-      key[0] = keep ? key[0] : (shift ? sk : ckey);
+      // (the list is sorted, so "left neighbour > ckey" is the keep mask shifted by one lane: one
+      // compare + two scalar ops instead of a second compare on the DPP-shifted key)
+      // Seven VALU per insert: the DPP lane shift is folded into the select (v_cndmask_b32_dpp), which
+      // hipcc does not form by itself.  vcc = lanes whose left neighbour is kept (or lane 0): they take
+      // the candidate, the others the shifted entry; lanes with key <= ckey keep their own.
+      unsigned long long keep;
+      float tk;
+      int ti;
+      asm volatile(
+          "v_cmp_ge_f32_e64 %[keep], %[ck], %[key]\n\t"
+          "s_lshl_b64 vcc, %[keep], 1\n\t"
+          "s_or_b32 vcc_lo, vcc_lo, 1\n\t"
+          "v_mov_b32_e32 %[tk], %[ck]\n\t"
+          "v_mov_b32_e32 %[ti], %[ci]\n\t"
+          "v_cndmask_b32_dpp %[tk], %[key], %[tk], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+          "v_cndmask_b32_dpp %[ti], %[idx], %[ti], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+          "v_cndmask_b32_e64 %[key], %[tk], %[key], %[keep]\n\t"
+          "v_cndmask_b32_e64 %[idx], %[ti], %[idx], %[keep]\n\t"
+          : [key] "+v"(key[0]), [idx] "+v"(idx[0]), [keep] "=&s"(keep), [tk] "=&v"(tk), [ti] "=&v"(ti)
+          : [ck] "s"(ckey), [ci] "s"(cidx)
+          : "vcc", "scc");
       return;
     }
     int pos = 0;
