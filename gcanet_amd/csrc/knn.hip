@@ -363,52 +363,56 @@ static int launch_knn(const KnnArgs &a, int B, hipStream_t st) {
 
 
 // ------------------------------------------------------------------------------------------
-// Feature-space kNN (C >= 16) on the matrix cores.  v_mfma_f32_32x32x2_f32 is bit-for-bit a
-// k-ordered fmaf chain (cdna_hip_programming.md section 3), so dot(x_i, x_j) accumulated over
-// ascending channel pairs equals the oracle's scalar chain exactly and indices stay bit-exact,
-// while the VALU is left to the top-k bookkeeping.
-//   workgroup = 4 waves, each wave owns 32 queries (one MFMA row block); the query fragments stay
-//   in registers (CC/2 VGPRs).  Candidates stream through LDS in tiles of 64 ([channel][cand] f32,
+// Feature-space kNN (C in {32,64,128}) on the matrix cores.  v_mfma_f32_16x16x4_f32 is bit-for-bit
+// a k-ordered fmaf chain (cdna_hip_programming.md section 3), so dot(x_i, x_j) accumulated over
+// ascending channels equals the oracle's scalar chain exactly and indices stay bit-exact, while
+// the VALU is left to the top-k bookkeeping.
+//   workgroup = 4 waves, each wave owns 16 queries (one MFMA row block); the query fragments stay
+//   in registers (CC/4 VGPRs).  Candidates stream through LDS in tiles of TC ([channel][cand] f32,
 //   the global layout, fetched by LDS-DMA, double buffered) and are shared by the 4 waves.
-//   C/D layout: lane = candidate (l&31), register r = query row (r&3)+8(r>>2)+4(l>>5): every
-//   accumulator register carries TWO queries (one per half-wave), each with its own 64-entry sorted
-//   list spread across all 64 lanes -> 32 lists per wave, 64 VGPRs.
+//   C/D layout: lane = candidate (l&15), register r = query row 4(l>>4)+r: every accumulator
+//   register carries FOUR queries (one per 16-lane group), each with its own 64-entry sorted list
+//   spread across all 64 lanes -> 16 lists per wave, 32 VGPRs, four waves per SIMD.  (A 32x32x2
+//   version with 32 queries per wave ran two waves per SIMD and was 6 % slower: the kernel is bound
+//   by the dependent insert chains -- PMC: VALU 42 %, MFMA 31 % of SIMD time.)
 // k <= 64 only (one list entry per lane); larger k uses knn_select_kernel.
-typedef __attribute__((ext_vector_type(16))) float knn_f32x16;
+//   A[i=l&15][kk=l>>4] = x[4s+kk][q0+i];  B[kk=l>>4][j=l&15] = x[4s+kk][cand j]: the four channel rows a
+//   B fetch touches are one LDS row apart (TC=64: same banks), so the DMA writes row r with its
+//   16-candidate blocks XOR-permuted by (r&3) and the fetch undoes it (source-side swizzle).
+typedef __attribute__((ext_vector_type(4))) float knn_f32x4;
 
-template <int CC>
-__global__ __launch_bounds__(256) void knn_mfma_kernel(const float *__restrict__ x, const float *__restrict__ xxg,
-                                                       int N, int k, int step, int kout,
-                                                       int64_t *__restrict__ ind, float *__restrict__ val) {
-  constexpr int TC = 64;                 // candidates per tile
+template <int CC, int TC>
+__global__ __launch_bounds__(256, 4) void knn_mfma16_kernel(const float *__restrict__ x, const float *__restrict__ xxg,
+                                                            int N, int k, int step, int kout,
+                                                            int64_t *__restrict__ ind, float *__restrict__ val) {
   constexpr int ROWS = CC + 1;           // + one row of squared norms
-  constexpr int TILE_FLOATS = ROWS * TC;
-  constexpr int PIECES = (ROWS * TC * 4 + 1023) / 1024;  // 1-KiB DMA pieces (4 rows each)
+  constexpr int RPP = 256 / TC;          // rows per 1-KiB DMA piece
+  constexpr int PIECES = (ROWS + RPP - 1) / RPP;
+  constexpr int CPR = TC / 4;            // 16-B chunks per row
+  constexpr int NCB = TC / 16;           // 16-candidate column blocks per tile
   extern __shared__ __attribute__((aligned(1024))) float tile[];  // 2 buffers of PIECES KiB
 
   const int lane = lane_id(), wave = wave_id();
-  const int lr = lane & 31, lh = lane >> 5;
+  const int lc = lane & 15, lg = lane >> 4;
   const int b = blockIdx.y;
-  const int q0 = (blockIdx.x * 4 + wave) * 32;
+  const int q0 = (blockIdx.x * 4 + wave) * 16;
   const float *xb = x + (long)b * CC * N;
   const float *xxb = xxg + (long)b * N;
 
-  // query fragments: A[i = lane&31][kk = lane>>5] for channel pair s -> x[2s + lh][q0 + lr]
-  const int qa = min(q0 + lr, N - 1);
-  float afrag[CC / 2];
+  const int qa = min(q0 + lc, N - 1);
+  float afrag[CC / 4];
 #pragma unroll
-  for (int s = 0; s < CC / 2; ++s) afrag[s] = xb[(long)(2 * s + lh) * N + qa];
-  // per-register query norms (two queries per register: one per half-wave)
-  float xxq[16];
+  for (int s = 0; s < CC / 4; ++s) afrag[s] = xb[(long)(4 * s + lg) * N + qa];
+  float xxq[4];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) xxq[r] = xxb[min(q0 + (r & 3) + 8 * (r >> 2) + 4 * lh, N - 1)];
+  for (int r = 0; r < 4; ++r) xxq[r] = xxb[min(q0 + 4 * lg + r, N - 1)];
 
-  TopK<1> top[16][2];
-  float thrv[16];
+  TopK<1> top[4][4];                     // [r][g]: query q0 + 4g + r
+  float thrv[4];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    top[r][0].init();
-    top[r][1].init();
+  for (int r = 0; r < 4; ++r) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) top[r][g].init();
     thrv[r] = KNN_INF;
   }
   const int klane = k - 1;
@@ -416,17 +420,18 @@ __global__ __launch_bounds__(256) void knn_mfma_kernel(const float *__restrict__
   const int ntiles = (N + TC - 1) / TC;
   auto issue_tile = [&](int t, int buf) {
     int j0 = t * TC;
-    if (j0 + TC > N) j0 = N - TC;                   // tail tile: shifted back (N >= 64, N % 4 == 0 by dispatch)
+    if (j0 + TC > N) j0 = N - TC;                   // tail tile: shifted back (N >= TC, N % 4 == 0 by dispatch)
     for (int p = wave; p < PIECES; p += 4) {
-      const int row = p * 4 + (lane >> 4);          // 16 lanes x 16 B = one 256-B row of 64 candidates
-      const int j = j0 + (lane & 15) * 4;
+      const int row = p * RPP + lane / CPR;
+      const int chunk = lane % CPR;
+      const int sc = TC == 64 ? (chunk ^ ((row & 3) << 2)) : chunk;
+      const int j = j0 + sc * 4;
       const float *src = row < CC ? xb + (long)row * N + j : xxb + j;
       if (row < ROWS)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                          (__attribute__((address_space(3))) void *)(tile + buf * PIECES * 256 + p * 256), 16, 0, 0);
     }
   };
-  (void)TILE_FLOATS;
 
   issue_tile(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -437,45 +442,37 @@ __global__ __launch_bounds__(256) void knn_mfma_kernel(const float *__restrict__
     if (t + 1 < ntiles) issue_tile(t + 1, buf ^ 1);
     const float *tb = tile + buf * PIECES * 256;
     const int j0 = t * TC;
-    // a clamped tail tile holds candidates [N-64, N): shift so that lane ids still map to real indices
     const int jbase = (j0 + TC > N) ? N - TC : j0;
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-      knn_f32x16 acc;
+    for (int cb = 0; cb < NCB; ++cb) {
+      knn_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      const float *bcol = tb + lg * TC + (TC == 64 ? (((cb ^ lg) << 4) + lc) : (cb * 16 + lc));
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-      const float *bcol = tb + cb * 32 + lr;
+      for (int s = 0; s < CC / 4; ++s)
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[s], bcol[4 * s * TC], acc, 0, 0, 0);
+      const int j = jbase + cb * 16 + lc;
+      const float xxj = tb[CC * TC + cb * 16 + lc];
+      const bool fresh = j >= j0 && j < N;
 #pragma unroll
-      for (int s = 0; s < CC / 2; ++s)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[s], bcol[(2 * s + lh) * TC], acc, 0, 0, 0);
-      const int j = jbase + cb * 32 + lr;
-      const float xxj = tb[CC * TC + cb * 32 + lr];
-      const bool fresh = j >= j0 && j < N;          // not a re-visited (clamped) or out-of-range candidate
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
+      for (int r = 0; r < 4; ++r) {
         const float tt = 2.f * acc[r] - xxj;
         const float pd = tt - xxq[r];
         const float key = fresh ? -pd : KNN_INF;
-        // serial list insertion here: the buffered-bitonic lists (4 VGPRs each x 32 lists) push this
-        // kernel to 1 wave/SIMD and lose more than they gain (measured 3.1 vs 2.4 ms)
         const unsigned long long m = __ballot(key < thrv[r]);
         if (m) {
-          // every lane that beat the (possibly stale) threshold is inserted without a re-check: a key that no
-          // longer qualifies falls off the end of the 64-entry list by itself; thresholds refresh once per batch
-          unsigned int lo = (unsigned int)m, hi = (unsigned int)(m >> 32);
-          const int cb0 = jbase + cb * 32;
-          while (lo) {
-            const int l = __ffs((int)lo) - 1;
-            lo &= lo - 1;
-            top[r][0].insert(readlane_f(key, l), cb0 + l, lane);
-          }
-          while (hi) {
-            const int l = __ffs((int)hi) - 1;
-            hi &= hi - 1;
-            top[r][1].insert(readlane_f(key, l + 32), cb0 + l, lane);
+          const int cb0 = jbase + cb * 16;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            unsigned int mg = (unsigned int)(m >> (16 * g)) & 0xffffu;
+            while (mg) {
+              const int l = __ffs((int)mg) - 1;
+              mg &= mg - 1;
+              top[r][g].insert(readlane_f(key, l + 16 * g), cb0 + l, lane);
+            }
           }
           const float t0 = readlane_f(top[r][0].key[0], klane), t1 = readlane_f(top[r][1].key[0], klane);
-          thrv[r] = lh == 0 ? t0 : t1;
+          const float t2 = readlane_f(top[r][2].key[0], klane), t3 = readlane_f(top[r][3].key[0], klane);
+          thrv[r] = lg == 0 ? t0 : (lg == 1 ? t1 : (lg == 2 ? t2 : t3));
         }
       }
     }
@@ -484,26 +481,26 @@ __global__ __launch_bounds__(256) void knn_mfma_kernel(const float *__restrict__
   }
 
 #pragma unroll
-  for (int r = 0; r < 16; ++r)
+  for (int r = 0; r < 4; ++r)
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int q = q0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+    for (int g = 0; g < 4; ++g) {
+      const int q = q0 + 4 * g + r;
       if (q < N && lane < k && (lane % step) == 0) {
         const long o = ((long)b * N + q) * kout + lane / step;
-        ind[o] = (int64_t)top[r][h].idx[0];
-        if (val) val[o] = -top[r][h].key[0];
+        ind[o] = (int64_t)top[r][g].idx[0];
+        if (val) val[o] = -top[r][g].key[0];
       }
     }
 }
 
-template <int CC>
-static int launch_knn_mfma(const float *x, const float *xx, int B, int N, int k, int step, int kout, int64_t *ind,
-                           float *val, hipStream_t st) {
-  constexpr int PIECES = ((CC + 1) * 64 * 4 + 1023) / 1024;
+template <int CC, int TC>
+static int launch_knn_mfma16(const float *x, const float *xx, int B, int N, int k, int step, int kout, int64_t *ind,
+                             float *val, hipStream_t st) {
+  constexpr int PIECES = (CC + 1 + 256 / TC - 1) / (256 / TC);
   const int lds = 2 * PIECES * 1024;
-  GCN_HIP(hipFuncSetAttribute((const void *)knn_mfma_kernel<CC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  knn_mfma_kernel<CC><<<dim3(cdiv(N, 128), B), 256, lds, st>>>(x, xx, N, k, step, kout, ind, val);
-  return check_launch("knn_mfma_kernel");
+  GCN_HIP(hipFuncSetAttribute((const void *)knn_mfma16_kernel<CC, TC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  knn_mfma16_kernel<CC, TC><<<dim3(cdiv(N, 64), B), 256, lds, st>>>(x, xx, N, k, step, kout, ind, val);
+  return check_launch("knn_mfma16_kernel");
 }
 
 }  // namespace gcn
@@ -559,9 +556,9 @@ GCN_EXPORT int gcn_knn_model(const float *x, int B, int C, int N, int k1, int k2
   if (metric == 1) return launch_knn<2, 6>(a, B, st);
   if (C == 3) return launch_knn<1, 3>(a, B, st);
   if (k2 <= 64 && N >= 64 && (N % 4) == 0) {  // matrix-core path (bit-identical dot products)
-    if (C == 32) return launch_knn_mfma<32>(x, xx_ws, B, N, k2, step, kout, idx, val, st);
-    if (C == 64) return launch_knn_mfma<64>(x, xx_ws, B, N, k2, step, kout, idx, val, st);
-    if (C == 128) return launch_knn_mfma<128>(x, xx_ws, B, N, k2, step, kout, idx, val, st);
+    if (C == 32) return launch_knn_mfma16<32, 64>(x, xx_ws, B, N, k2, step, kout, idx, val, st);
+    if (C == 64) return launch_knn_mfma16<64, 64>(x, xx_ws, B, N, k2, step, kout, idx, val, st);
+    if (C == 128) return launch_knn_mfma16<128, 32>(x, xx_ws, B, N, k2, step, kout, idx, val, st);
   }
   return launch_knn<1, 0>(a, B, st);
 }
