@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "gcanet_hip.h")
 SO_PATH = os.path.join(_HERE, "lib", "libgcanet_hip.so")
 
-_PROTO = re.compile(r"^\s*(const\s+char\s*\*|int)\s*(gcn_\w+)\s*\(([^;]*?)\)\s*;", re.S | re.M)
+_PROTO = re.compile(r"^\s*(const\s+char\s*\*|int|long)\s*(gcn_\w+)\s*\(([^;]*?)\)\s*;", re.S | re.M)
 
 
 def parse_header(path=HEADER):
@@ -35,7 +35,7 @@ def parse_header(path=HEADER):
                 argtypes.append(C.c_int)
             else:
                 raise ValueError("unhandled parameter %r in %s" % (a, name))
-        protos[name] = (C.c_char_p if "char" in ret else C.c_int, argtypes)
+        protos[name] = (C.c_char_p if "char" in ret else (C.c_int64 if ret == "long" else C.c_int), argtypes)
     return protos
 
 

@@ -6,11 +6,18 @@ import torch
 from . import _lib
 
 
+def _workspace(BH, Lq, Lk, D, device):
+    n = _lib.lib().gcn_attention_ws_bytes(BH, Lq, Lk, D)
+    if n < 0:
+        raise RuntimeError("gcn_attention_ws_bytes: bad shape")
+    return torch.empty(n, dtype=torch.uint8, device=device)
+
+
 class SDPAFunction(torch.autograd.Function):
     """out = softmax(scale * q k^T [+ mask]) v  for q (BH,Lq,D), k/v (BH,Lk,D); mask: bool, True = masked out."""
 
     @staticmethod
-    def forward(ctx, q, k, v, mask, scale):
+    def forward(ctx, q, k, v, mask, scale, precision="f32"):
         _lib.require_cuda(q, k, v)
         q, k, v = q.float().contiguous(), k.float().contiguous(), v.float().contiguous()
         BH, Lq, D = q.shape
@@ -22,11 +29,18 @@ class SDPAFunction(torch.autograd.Function):
             m8 = mask.to(torch.uint8).contiguous()
             per_bh = 1 if m8.dim() == 3 else 0
         with torch.cuda.device_of(q):
-            _lib.call("gcn_attention_fwd", _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(m8), per_bh, BH, Lq, Lk, D,
-                      float(scale), _lib.ptr(out), _lib.ptr(lse), _lib.stream_of(q),
-                      tag="attention_fwd[BH=%d,Lq=%d,Lk=%d,D=%d]" % (BH, Lq, Lk, D))
+            if precision == "bf16":
+                ws = _workspace(BH, Lq, Lk, D, q.device)
+                _lib.call("gcn_attention_fwd_bf16", _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(m8), per_bh, BH, Lq,
+                          Lk, D, float(scale), _lib.ptr(out), _lib.ptr(lse), _lib.ptr(ws), _lib.stream_of(q),
+                          tag="attention_fwd_bf16[BH=%d,Lq=%d,Lk=%d,D=%d]" % (BH, Lq, Lk, D))
+            else:
+                _lib.call("gcn_attention_fwd", _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(m8), per_bh, BH, Lq, Lk,
+                          D, float(scale), _lib.ptr(out), _lib.ptr(lse), _lib.stream_of(q),
+                          tag="attention_fwd[BH=%d,Lq=%d,Lk=%d,D=%d]" % (BH, Lq, Lk, D))
         ctx.save_for_backward(q, k, v, out, lse, m8 if m8 is not None else torch.empty(0, device=q.device))
         ctx.scale = scale
+        ctx.precision = precision
         return out
 
     @staticmethod
@@ -40,10 +54,11 @@ class SDPAFunction(torch.autograd.Function):
         dp = torch.bmm(dout, v.transpose(1, 2))
         delta = (dout * out).sum(-1, keepdim=True)
         ds = p * (dp - delta) * ctx.scale
-        return torch.bmm(ds, k), torch.bmm(ds.transpose(1, 2), q), dv, None, None
+        return torch.bmm(ds, k), torch.bmm(ds.transpose(1, 2), q), dv, None, None, None
 
 
-def sdpa(q, k, v, mask=None, scale=None):
+def sdpa(q, k, v, mask=None, scale=None, precision="f32"):
+    """precision "f32": exact kernel (parity path, head dim 8..64); "bf16": matrix-core flash kernels (head dim 32/64)."""
     if scale is None:
         scale = q.shape[-1] ** -0.5
-    return SDPAFunction.apply(q, k, v, mask, scale)
+    return SDPAFunction.apply(q, k, v, mask, scale, precision)

@@ -1,0 +1,286 @@
+// attention_mfma.hip -- flash-style scaled-dot-product attention on the bf16 matrix cores
+// (v_mfma_f32_32x32x16_bf16, f32 accumulation) for the long-sequence attention stacks of the reference:
+// models/transformer.py:36-75 (self-attention over all n points, materialises (b,h,n,n) scores) and
+// models/query_decoder.py:5-72 (nn.MultiheadAttention, 100 queries x N points per cloud).
+// BASELINE config 5 (N = 16384, 8 heads) cannot afford the score matrix: nothing of size Lq x Lk ever
+// reaches HBM here, forward or backward.  The exact-f32 kernel of attention.hip stays the parity path.
+//
+// Common shape of the three kernels (forward, dQ, dK/dV): a workgroup of 4 waves owns 128 rows of ONE
+// side (32 per wave, operand fragments in registers for the whole kernel) and streams 64-row tiles of
+// the OTHER side through LDS by LDS-DMA (global_load_lds_dwordx4, double buffered, one barrier per
+// tile).  Scores are always computed TRANSPOSED to what the row softmax would suggest -- the streamed
+// side on the MFMA row index, the owned side on the lane -- so that
+//   * every per-row quantity of the owned side (running max, sum, LSE, delta) is one value per lane,
+//   * the accumulator tile is, register for register, the B operand of the next product
+//     (P^T for O^T = V^T.P^T;  dS^T for dQ^T = K^T.dS^T;  P, dS for dV^T = dO^T.P, dK^T = Q^T.dS).
+// The contraction index of that next product then runs over accumulator registers in C-layout order
+// (row = (r&3) + 8(r>>2) + 4(lane>>5)), so the "transposed" LDS images (V^T, K^T, Q^T, dO^T) are stored
+// with the rows of every 16-group permuted to that order (attn_pack_kernel) and one ds_read_b128
+// yields the matching A operand.  LDS images are lane-linear (DMA), the XOR swizzle that makes the
+// b128 reads conflict-free sits on the DMA source address.
+#include "common.h"
+
+namespace gcn {
+
+typedef __attribute__((ext_vector_type(8))) short a_bf16x8;
+typedef __attribute__((ext_vector_type(16))) float a_f32x16;
+typedef __attribute__((ext_vector_type(2))) float a_f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 a_bf16x2;
+
+__device__ __forceinline__ unsigned int pack_bf16x2(float a, float b) {
+  a_f32x2 v = {a, b};
+  a_bf16x2 h = __builtin_convertvector(v, a_bf16x2);   // v_cvt_pk_bf16_f32 (RNE)
+  return __builtin_bit_cast(unsigned int, h);
+}
+__device__ __forceinline__ unsigned short to_bf16(float f) {
+  __bf16 h = (__bf16)f;
+  return __builtin_bit_cast(unsigned short, h);
+}
+
+// position (within a group of 16) -> row of the group, in accumulator order: lane half h = p>>3 holds
+// rows 4h + (i&3) + 8(i>>2), i = p&7
+__device__ __host__ __forceinline__ int attn_row_of_pos(int p) {
+  const int h = p >> 3, i = p & 7;
+  return 4 * h + (i & 3) + 8 * (i >> 2);
+}
+
+// src (BH, L, D) f32 -> row-major image dst_rm (BH, Lp, D) bf16 (zero rows past L, values * mul)
+// and/or permuted transposed image dst_t (BH, D, Lp) bf16.  One block = 64 rows of one bh.
+template <int D>
+__global__ __launch_bounds__(256) void attn_pack_kernel(const float *__restrict__ src, int L, int Lp, float mul,
+                                                        unsigned short *__restrict__ dst_rm,
+                                                        unsigned short *__restrict__ dst_t) {
+  __shared__ float tile[64][D + 1];
+  const int bh = blockIdx.y, l0 = blockIdx.x * 64;
+  const float *s = src + (long)bh * L * D;
+  for (int e = threadIdx.x; e < 64 * D; e += 256) {
+    const int r = e / D, d = e % D;
+    const float v = (l0 + r < L) ? s[(long)(l0 + r) * D + d] * mul : 0.f;
+    tile[r][d] = v;
+    if (dst_rm) dst_rm[((long)bh * Lp + l0 + r) * D + d] = to_bf16(v);
+  }
+  if (!dst_t) return;
+  __syncthreads();
+  for (int e = threadIdx.x; e < 64 * D; e += 256) {
+    const int d = e / 64, p = e % 64;
+    const int r = (p & ~15) + attn_row_of_pos(p & 15);
+    dst_t[((long)bh * D + d) * Lp + l0 + p] = to_bf16(tile[r][d]);
+  }
+}
+
+// ---- LDS-DMA of one 64-row tile -----------------------------------------------------------------
+// Row-major image tile: 64 rows x D bf16 (RB = 2D bytes per row), 16-B chunks XOR-swizzled so that 16
+// consecutive rows reading the same logical chunk land on 16 different 16-B slots of the 256-B bank row.
+template <int D>
+__device__ __forceinline__ int rm_swz(int row) {
+  constexpr int RB = 2 * D, RPB = 256 / RB, CPR = RB / 16;
+  return (row / RPB) & (CPR - 1);
+}
+template <int D>
+__device__ __forceinline__ void dma_rm_tile(const unsigned short *__restrict__ img_row0, unsigned char *lds, int wave,
+                                            int lane) {
+  constexpr int RB = 2 * D, CPR = RB / 16, RPP = 1024 / RB, PIECES = 64 * RB / 1024;
+  for (int p = wave; p < PIECES; p += 4) {
+    const int row = p * RPP + lane / CPR, pos = lane % CPR;
+    const int chunk = pos ^ rm_swz<D>(row);
+    const unsigned char *src = reinterpret_cast<const unsigned char *>(img_row0) + (long)row * RB + chunk * 16;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                     (__attribute__((address_space(3))) void *)(lds + p * 1024), 16, 0, 0);
+  }
+}
+// Transposed image tile: D rows (channels) x 64 positions bf16 = 128-B rows, row stride Lp elements in global.
+template <int D>
+__device__ __forceinline__ void dma_t_tile(const unsigned short *__restrict__ img_col0, long Lp, unsigned char *lds,
+                                           int wave, int lane) {
+  constexpr int PIECES = D / 8;
+  for (int p = wave; p < PIECES; p += 4) {
+    const int row = p * 8 + lane / 8, pos = lane % 8;
+    const int chunk = pos ^ ((row >> 1) & 7);
+    const unsigned char *src = reinterpret_cast<const unsigned char *>(img_col0 + (long)row * Lp) + chunk * 16;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                     (__attribute__((address_space(3))) void *)(lds + p * 1024), 16, 0, 0);
+  }
+}
+// A operand from a row-major tile: row (0..63), logical 16-B chunk c (= k-step*2 + lane half)
+template <int D>
+__device__ __forceinline__ a_bf16x8 lds_rm_frag(const unsigned char *lds, int row, int c) {
+  return *reinterpret_cast<const a_bf16x8 *>(lds + row * (2 * D) + ((c ^ rm_swz<D>(row)) << 4));
+}
+// A operand from a transposed tile: row = channel, logical chunk c (8 positions)
+__device__ __forceinline__ a_bf16x8 lds_t_frag(const unsigned char *lds, int row, int c) {
+  return *reinterpret_cast<const a_bf16x8 *>(lds + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+}
+
+// ---- forward --------------------------------------------------------------------------------------
+// qb (BH,Lqp,D) bf16 pre-scaled by scale*log2(e); kb (BH,Lkp,D); vt (BH,D,Lkp) permuted; mask bytes
+// (1 = masked out) (Lq,Lk) [+ bh stride]; out (BH,Lq,D) f32; lse (BH,Lq) f32 natural-log units.
+template <int D, bool MASK>
+__global__ __launch_bounds__(256, 2) void attn_fwd_mfma_kernel(const unsigned short *__restrict__ qb,
+                                                               const unsigned short *__restrict__ kb,
+                                                               const unsigned short *__restrict__ vt,
+                                                               const unsigned char *__restrict__ mask, long mask_bh_stride,
+                                                               int Lq, int Lk, int Lqp, int Lkp,
+                                                               float *__restrict__ out, float *__restrict__ lse) {
+  constexpr int KS = D / 16;            // k-steps of S^T = K.Q^T
+  constexpr int DB = D / 32;            // 32-row blocks of O^T
+  constexpr int KT_BYTES = 64 * D * 2;  // K tile; the V^T tile is the same size
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];  // 2 x (K tile | V^T tile)
+
+  const int lane = lane_id(), wave = wave_id();
+  const int lr = lane & 31, lh = lane >> 5;
+  const int bh = blockIdx.y;
+  const int qrow = blockIdx.x * 128 + wave * 32 + lr;     // < Lqp by construction
+  const unsigned short *kimg = kb + (long)bh * Lkp * D;
+  const unsigned short *vimg = vt + (long)bh * D * Lkp;
+
+  a_bf16x8 qf[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s)
+    qf[s] = *reinterpret_cast<const a_bf16x8 *>(qb + ((long)bh * Lqp + qrow) * D + 16 * s + 8 * lh);
+
+  a_f32x16 o[DB];
+#pragma unroll
+  for (int d = 0; d < DB; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+  float m_run = -__builtin_inff(), l_run = 0.f;
+
+  const int ntiles = Lkp / 64;
+  auto issue = [&](int t, int buf) {
+    unsigned char *base = smem + buf * 2 * KT_BYTES;
+    dma_rm_tile<D>(kimg + (long)t * 64 * D, base, wave, lane);
+    dma_t_tile<D>(vimg + (long)t * 64, Lkp, base + KT_BYTES, wave, lane);
+  };
+  issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < ntiles) issue(t + 1, buf ^ 1);
+    const unsigned char *kt = smem + buf * 2 * KT_BYTES;
+    const unsigned char *vtile = kt + KT_BYTES;
+    const int key0 = t * 64;
+
+    a_f32x16 sc[2];
+#pragma unroll
+    for (int kb2 = 0; kb2 < 2; ++kb2) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[kb2][r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+        sc[kb2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_rm_frag<D>(kt, 32 * kb2 + lr, 2 * s + lh), qf[s], sc[kb2], 0, 0, 0);
+    }
+    // keys past Lk (zero padding of the last tile) and user mask -> -inf
+    if (MASK || key0 + 64 > Lk) {
+#pragma unroll
+      for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = key0 + 32 * kb2 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          bool dead = key >= Lk;
+          if (MASK && !dead && qrow < Lq) dead = mask[(long)bh * mask_bh_stride + (long)qrow * Lk + key] != 0;
+          if (dead) sc[kb2][r] = -__builtin_inff();
+        }
+    }
+    float mx = sc[0][0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[0][r]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[1][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    const float m_use = m_new == -__builtin_inff() ? 0.f : m_new;     // fully masked so far: p = 0 everywhere
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);        // m_run = -inf -> 0
+    m_run = m_new;
+    float ps = 0.f;
+    unsigned int pf[2][2][4];
+#pragma unroll
+    for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const float p0 = __builtin_amdgcn_exp2f(sc[kb2][r] - m_use);
+        const float p1 = __builtin_amdgcn_exp2f(sc[kb2][r + 1] - m_use);
+        ps += p0 + p1;
+        pf[kb2][r >> 3][(r & 7) >> 1] = pack_bf16x2(p0, p1);
+      }
+    l_run = l_run * alpha + ps;
+    if (__builtin_amdgcn_ballot_w64(alpha != 1.f)) {                 // wave-uniform skip once the maxima settle
+#pragma unroll
+      for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+    }
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+      for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          a_bf16x8 pb;
+          unsigned int *pw = reinterpret_cast<unsigned int *>(&pb);
+          pw[0] = pf[kb2][tt][0]; pw[1] = pf[kb2][tt][1]; pw[2] = pf[kb2][tt][2]; pw[3] = pf[kb2][tt][3];
+          o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_t_frag(vtile, 32 * d + lr, 4 * kb2 + 2 * tt + lh), pb, o[d], 0, 0, 0);
+        }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  if (qrow < Lq) {
+    const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+    float *orow = out + ((long)bh * Lq + qrow) * D;
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float4 v4 = make_float4(o[d][4 * g] * inv, o[d][4 * g + 1] * inv, o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv);
+        *reinterpret_cast<float4 *>(orow + 32 * d + 8 * g + 4 * lh) = v4;
+      }
+    if (lse && lh == 0) lse[(long)bh * Lq + qrow] = (m_run + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;
+  }
+}
+
+static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+template <int D>
+static int run_fwd(const float *q, const float *k, const float *v, const uint8_t *mask, int mask_per_bh, int BH, int Lq,
+                   int Lk, float scale, float *out, float *lse, unsigned short *ws, hipStream_t st) {
+  const int Lqp = round_up(Lq, 128), Lkp = round_up(Lk, 64);
+  unsigned short *qb = ws, *kb = qb + (size_t)BH * Lqp * D, *vt = kb + (size_t)BH * Lkp * D;
+  attn_pack_kernel<D><<<dim3(Lqp / 64, BH), 256, 0, st>>>(q, Lq, Lqp, scale * 1.4426950408889634f, qb, nullptr);
+  attn_pack_kernel<D><<<dim3(Lkp / 64, BH), 256, 0, st>>>(k, Lk, Lkp, 1.f, kb, nullptr);
+  attn_pack_kernel<D><<<dim3(Lkp / 64, BH), 256, 0, st>>>(v, Lk, Lkp, 1.f, nullptr, vt);
+  const int lds = 2 * 2 * 64 * D * 2;
+  const long ms = mask_per_bh ? (long)Lq * Lk : 0;
+  const dim3 grid(Lqp / 128, BH);
+  if (mask)
+    attn_fwd_mfma_kernel<D, true><<<grid, 256, lds, st>>>(qb, kb, vt, mask, ms, Lq, Lk, Lqp, Lkp, out, lse);
+  else
+    attn_fwd_mfma_kernel<D, false><<<grid, 256, lds, st>>>(qb, kb, vt, nullptr, 0, Lq, Lk, Lqp, Lkp, out, lse);
+  return check_launch("attn_fwd_mfma_kernel");
+}
+
+}  // namespace gcn
+
+using namespace gcn;
+
+GCN_EXPORT long gcn_attention_ws_bytes(int BH, int Lq, int Lk, int D) {
+  if (BH < 0 || Lq < 1 || Lk < 1 || D < 1) return -1;
+  const long Lqp = round_up(Lq, 128), Lkp = round_up(Lk, 128);
+  // forward: Q, K, V^T images; backward adds Q^T, K^T, V, dO, dO^T (all bf16) and delta (f32)
+  return 2L * BH * D * (3 * Lqp + 4 * Lkp) + 4L * BH * Lqp + 1024;
+}
+
+GCN_EXPORT int gcn_attention_fwd_bf16(const float *q, const float *k, const float *v, const uint8_t *mask, int mask_per_bh,
+                                      int BH, int Lq, int Lk, int D, float scale, float *out, float *lse, void *ws,
+                                      void *stream) {
+  GCN_REQUIRE(q && k && v && out && ws, "gcn_attention_fwd_bf16: null pointer");
+  GCN_REQUIRE(BH >= 0 && Lq >= 1 && Lk >= 1, "gcn_attention_fwd_bf16: bad shape");
+  GCN_REQUIRE(D == 32 || D == 64, "gcn_attention_fwd_bf16: head dim %d unsupported (32, 64)", D);
+  GCN_REQUIRE(((uintptr_t)ws & 15) == 0 && ((uintptr_t)out & 15) == 0, "gcn_attention_fwd_bf16: ws/out must be 16-B aligned");
+  if (BH == 0) return GCN_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (D == 32) return run_fwd<32>(q, k, v, mask, mask_per_bh, BH, Lq, Lk, scale, out, lse, (unsigned short *)ws, st);
+  return run_fwd<64>(q, k, v, mask, mask_per_bh, BH, Lq, Lk, scale, out, lse, (unsigned short *)ws, st);
+}

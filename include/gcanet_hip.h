@@ -313,6 +313,16 @@ int gcn_gn_bwd(const void *dy, const void *x, int dtype, const float *gamma, con
 int gcn_attention_fwd(const float *q, const float *k, const float *v, const uint8_t *mask, int mask_per_bh,
                       int BH, int Lq, int Lk, int D, float scale, float *out, float *lse, void *stream);
 
+/* The same contraction on the bf16 matrix cores (flash-style, f32 accumulation, f32 in/out) for the
+ * long sequences of BASELINE config 5 (transformer.py:52-69 over n = 16384 points; "fp16+MFMA").
+ * D in {32,64}.  ws: device workspace of gcn_attention_ws_bytes(BH,Lq,Lk,D) bytes, 16-B aligned (bf16
+ * operand images; contents are scratch).  Results agree with the f32 entry point to bf16 operand
+ * rounding (~1e-2 relative), not to 1e-4: the exact kernel above remains the parity path. */
+long gcn_attention_ws_bytes(int BH, int Lq, int Lk, int D);
+int gcn_attention_fwd_bf16(const float *q, const float *k, const float *v, const uint8_t *mask, int mask_per_bh,
+                           int BH, int Lq, int Lk, int D, float scale, float *out, float *lse, void *ws,
+                           void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,42 @@
+"""Attention kernels: accuracy of the bf16 matrix-core path vs the exact f32 kernel / torch, and timings.
+   python tools/attn_bench.py [BH] [L] [D]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gcanet_amd import attention  # noqa: E402
+
+BH = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+L = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+D = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+dev = torch.device("cuda:0")
+g = torch.Generator().manual_seed(0)
+q, k, v = (torch.randn(BH, L, D, generator=g).to(dev) for _ in range(3))
+scale = D ** -0.5
+
+
+def timeit(fn, iters=5):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+o_bf = attention.sdpa(q, k, v, None, scale, "bf16")
+if L <= 8192:
+    ref = torch.softmax(torch.bmm(q, k.transpose(1, 2)) * scale, -1) @ v
+    o_f32 = attention.sdpa(q, k, v, None, scale, "f32")
+    print("f32 kernel vs torch: max abs %.3e" % (o_f32 - ref).abs().max().item())
+    print("bf16 kernel vs torch: max abs %.3e  (ref max %.3f)" % ((o_bf - ref).abs().max().item(), ref.abs().max().item()))
+    t = timeit(lambda: attention.sdpa(q, k, v, None, scale, "f32"), 3)
+    print("f32  fwd: %.3f ms  %.1f TFLOP/s" % (t, 4.0 * BH * L * L * D / t / 1e9))
+t = timeit(lambda: attention.sdpa(q, k, v, None, scale, "bf16"))
+print("bf16 fwd: %.3f ms  %.1f TFLOP/s (incl. operand packing)" % (t, 4.0 * BH * L * L * D / t / 1e9))
