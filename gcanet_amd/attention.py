@@ -1,6 +1,7 @@
-"""Attention core shared by gcanet_amd.transformer and gcanet_amd.query_decoder: forward through the
-fused HIP kernel (csrc/attention.hip), backward by recomputing the probabilities from the saved
-log-sum-exp (flash-attention style, in torch ops this round)."""
+"""Attention core shared by gcanet_amd.transformer and gcanet_amd.query_decoder.
+precision "f32": exact fused forward (csrc/attention.hip, parity path); its backward recomputes the probabilities
+from the saved log-sum-exp in torch ops (small sequences only).  precision "bf16": matrix-core flash kernels,
+forward and backward (csrc/attention_mfma.hip) -- nothing of size Lq x Lk is ever materialised."""
 import torch
 
 from . import _lib
@@ -46,6 +47,19 @@ class SDPAFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         q, k, v, out, lse, m8 = ctx.saved_tensors
+        if ctx.precision == "bf16":
+            BH, Lq, D = q.shape
+            Lk = k.shape[1]
+            dout = dout.float().contiguous()
+            dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+            mm = m8 if m8.numel() else None
+            with torch.cuda.device_of(q):
+                ws = _workspace(BH, Lq, Lk, D, q.device)
+                _lib.call("gcn_attention_bwd_bf16", _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(out), _lib.ptr(dout),
+                          _lib.ptr(lse), _lib.ptr(mm), 1 if (mm is not None and mm.dim() == 3) else 0, BH, Lq, Lk, D,
+                          float(ctx.scale), _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), _lib.ptr(ws), _lib.stream_of(q),
+                          tag="attention_bwd_bf16[BH=%d,Lq=%d,Lk=%d,D=%d]" % (BH, Lq, Lk, D))
+            return dq, dk, dv, None, None, None
         s = torch.bmm(q, k.transpose(1, 2)) * ctx.scale
         if m8.numel():
             s = s.masked_fill(m8.bool() if m8.dim() == 3 else m8.bool().unsqueeze(0), float("-inf"))

@@ -241,7 +241,288 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma_kernel(const unsigned sh
   }
 }
 
+// ---- backward -------------------------------------------------------------------------------------
+// delta[q] = sum_d dO[q,d] * O[q,d]  and  lse2[q] = lse[q] * log2(e)  (padded rows and fully masked rows:
+// delta = 0, lse2 = +inf so that p = exp2(s - lse2) = 0).  8 lanes per row.
+template <int D>
+__global__ __launch_bounds__(256) void attn_delta_kernel(const float *__restrict__ dout, const float *__restrict__ out,
+                                                         const float *__restrict__ lse, int Lq, int Lqp,
+                                                         float *__restrict__ delta, float *__restrict__ lse2) {
+  const int bh = blockIdx.y;
+  const int row = blockIdx.x * 32 + (threadIdx.x >> 3), sub = threadIdx.x & 7;
+  float s = 0.f;
+  if (row < Lq) {
+    const float *a = dout + ((long)bh * Lq + row) * D, *b = out + ((long)bh * Lq + row) * D;
+#pragma unroll
+    for (int c = sub * 4; c < D; c += 32) {
+      const float4 x = *reinterpret_cast<const float4 *>(a + c), y = *reinterpret_cast<const float4 *>(b + c);
+      s += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+    }
+  }
+  s += __shfl_xor(s, 1);
+  s += __shfl_xor(s, 2);
+  s += __shfl_xor(s, 4);
+  if (sub == 0 && row < Lqp) {
+    float l2 = __builtin_inff();
+    if (row < Lq) {
+      const float l = lse[(long)bh * Lq + row];
+      if (l > -__builtin_inff()) l2 = l * 1.4426950408889634f;
+    }
+    delta[(long)bh * Lqp + row] = s;
+    lse2[(long)bh * Lqp + row] = l2;
+  }
+}
+
+__device__ __forceinline__ a_bf16x8 make_frag(const unsigned int *w) {
+  a_bf16x8 f;
+  unsigned int *pw = reinterpret_cast<unsigned int *>(&f);
+  pw[0] = w[0]; pw[1] = w[1]; pw[2] = w[2]; pw[3] = w[3];
+  return f;
+}
+
+// dQ: the workgroup owns 128 queries (lane = query) and streams key tiles: K, V (row-major) and K^T.
+//   S^T = K.Qs^T, dP^T = V.dO^T, dS^T = P^T o (dP^T - delta), dQ^T += K^T.dS^T;  dQ = scale * dQ^T.
+template <int D, bool MASK>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const unsigned short *__restrict__ qs,
+                                                             const unsigned short *__restrict__ kr,
+                                                             const unsigned short *__restrict__ vr,
+                                                             const unsigned short *__restrict__ ktr,
+                                                             const unsigned short *__restrict__ dor,
+                                                             const float *__restrict__ lse2, const float *__restrict__ delta,
+                                                             const unsigned char *__restrict__ mask, long mask_bh_stride,
+                                                             int Lq, int Lk, int Lqp, int Lkp, float scale,
+                                                             float *__restrict__ dq) {
+  constexpr int KS = D / 16, DB = D / 32, TB = 64 * D * 2;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];  // 2 x (K | V | K^T)
+  const int lane = lane_id(), wave = wave_id();
+  const int lr = lane & 31, lh = lane >> 5;
+  const int bh = blockIdx.y;
+  const int qrow = blockIdx.x * 128 + wave * 32 + lr;
+  const unsigned short *kimg = kr + (long)bh * Lkp * D, *vimg = vr + (long)bh * Lkp * D;
+  const unsigned short *ktimg = ktr + (long)bh * D * Lkp;
+
+  a_bf16x8 qf[KS], dof[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    qf[s] = *reinterpret_cast<const a_bf16x8 *>(qs + ((long)bh * Lqp + qrow) * D + 16 * s + 8 * lh);
+    dof[s] = *reinterpret_cast<const a_bf16x8 *>(dor + ((long)bh * Lqp + qrow) * D + 16 * s + 8 * lh);
+  }
+  const float my_lse2 = lse2[(long)bh * Lqp + qrow], my_delta = delta[(long)bh * Lqp + qrow];
+  a_f32x16 acc[DB];
+#pragma unroll
+  for (int d = 0; d < DB; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
+
+  const int ntiles = Lkp / 64;
+  auto issue = [&](int t, int buf) {
+    unsigned char *base = smem + buf * 3 * TB;
+    dma_rm_tile<D>(kimg + (long)t * 64 * D, base, wave, lane);
+    dma_rm_tile<D>(vimg + (long)t * 64 * D, base + TB, wave, lane);
+    dma_t_tile<D>(ktimg + (long)t * 64, Lkp, base + 2 * TB, wave, lane);
+  };
+  issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < ntiles) issue(t + 1, buf ^ 1);
+    const unsigned char *kt = smem + buf * 3 * TB, *vtile = kt + TB, *ktt = kt + 2 * TB;
+    const int key0 = t * 64;
+#pragma unroll
+    for (int kb2 = 0; kb2 < 2; ++kb2) {
+      a_f32x16 sc, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sc[r] = -my_lse2; dp[r] = -my_delta; }
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_rm_frag<D>(kt, 32 * kb2 + lr, 2 * s + lh), qf[s], sc, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_rm_frag<D>(vtile, 32 * kb2 + lr, 2 * s + lh), dof[s], dp, 0, 0, 0);
+      }
+      unsigned int dsw[2][4];
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        float ds2[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int key = key0 + 32 * kb2 + ((r + u) & 3) + 8 * ((r + u) >> 2) + 4 * lh;
+          bool dead = key >= Lk;
+          if (MASK && !dead && qrow < Lq) dead = mask[(long)bh * mask_bh_stride + (long)qrow * Lk + key] != 0;
+          const float p = dead ? 0.f : __builtin_amdgcn_exp2f(sc[r + u]);
+          ds2[u] = p * dp[r + u];
+        }
+        dsw[r >> 3][(r & 7) >> 1] = pack_bf16x2(ds2[0], ds2[1]);
+      }
+#pragma unroll
+      for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+          acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_t_frag(ktt, 32 * d + lr, 4 * kb2 + 2 * tt + lh),
+                                                           make_frag(dsw[tt]), acc[d], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  if (qrow < Lq) {
+    float *orow = dq + ((long)bh * Lq + qrow) * D;
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4 *>(orow + 32 * d + 8 * g + 4 * lh) =
+            make_float4(acc[d][4 * g] * scale, acc[d][4 * g + 1] * scale, acc[d][4 * g + 2] * scale, acc[d][4 * g + 3] * scale);
+  }
+}
+
+// dK, dV: the workgroup owns 128 keys (lane = key) and streams query tiles: Qs, dO (row-major), Qs^T, dO^T
+// and the tile's lse2 / delta.   S = Qs.K^T - lse2, dP = dO.V^T - delta (row constants enter as the initial
+// accumulator), P = exp2(S), dS = P o dP;  dV^T += dO^T.P,  dK^T += Qs^T.dS;  dK = ln2 * dK^T (Qs carries log2 e).
+template <int D, bool MASK>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const unsigned short *__restrict__ qs,
+                                                              const unsigned short *__restrict__ qst,
+                                                              const unsigned short *__restrict__ kr,
+                                                              const unsigned short *__restrict__ vr,
+                                                              const unsigned short *__restrict__ dor,
+                                                              const unsigned short *__restrict__ dot,
+                                                              const float *__restrict__ lse2, const float *__restrict__ delta,
+                                                              const unsigned char *__restrict__ mask, long mask_bh_stride,
+                                                              int Lq, int Lk, int Lqp, int Lkp,
+                                                              float *__restrict__ dk, float *__restrict__ dv) {
+  constexpr int KS = D / 16, DB = D / 32, TB = 64 * D * 2, BUF = 4 * TB + 1024;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];  // 2 x (Qs | dO | Qs^T | dO^T | lse2,delta)
+  const int lane = lane_id(), wave = wave_id();
+  const int lr = lane & 31, lh = lane >> 5;
+  const int bh = blockIdx.y;
+  const int krow = blockIdx.x * 128 + wave * 32 + lr;      // < Lkp
+  const unsigned short *qimg = qs + (long)bh * Lqp * D, *doimg = dor + (long)bh * Lqp * D;
+  const unsigned short *qtimg = qst + (long)bh * D * Lqp, *dotimg = dot + (long)bh * D * Lqp;
+  const float *l2 = lse2 + (long)bh * Lqp, *dl = delta + (long)bh * Lqp;
+
+  a_bf16x8 kf[KS], vf[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    kf[s] = *reinterpret_cast<const a_bf16x8 *>(kr + ((long)bh * Lkp + krow) * D + 16 * s + 8 * lh);
+    vf[s] = *reinterpret_cast<const a_bf16x8 *>(vr + ((long)bh * Lkp + krow) * D + 16 * s + 8 * lh);
+  }
+  a_f32x16 dkt[DB], dvt[DB];
+#pragma unroll
+  for (int d = 0; d < DB; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dkt[d][r] = 0.f; dvt[d][r] = 0.f; }
+
+  const int ntiles = Lqp / 64;
+  auto issue = [&](int t, int buf) {
+    unsigned char *base = smem + buf * BUF;
+    dma_rm_tile<D>(qimg + (long)t * 64 * D, base, wave, lane);
+    dma_rm_tile<D>(doimg + (long)t * 64 * D, base + TB, wave, lane);
+    dma_t_tile<D>(qtimg + (long)t * 64, Lqp, base + 2 * TB, wave, lane);
+    dma_t_tile<D>(dotimg + (long)t * 64, Lqp, base + 3 * TB, wave, lane);
+    if (wave == 0)       // 64 floats each: one dword per lane
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(l2 + t * 64 + lane),
+                                       (__attribute__((address_space(3))) void *)(base + 4 * TB), 4, 0, 0);
+    else if (wave == 1)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(dl + t * 64 + lane),
+                                       (__attribute__((address_space(3))) void *)(base + 4 * TB + 256), 4, 0, 0);
+  };
+  issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < ntiles) issue(t + 1, buf ^ 1);
+    const unsigned char *qt = smem + buf * BUF, *dot_rm = qt + TB, *qtt = qt + 2 * TB, *dott = qt + 3 * TB;
+    const float *lt = reinterpret_cast<const float *>(qt + 4 * TB), *dt = lt + 64;
+    const int q0 = t * 64;
+#pragma unroll
+    for (int qb2 = 0; qb2 < 2; ++qb2) {
+      a_f32x16 sc, dp;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 a = *reinterpret_cast<const float4 *>(lt + 32 * qb2 + 8 * g + 4 * lh);
+        const float4 b = *reinterpret_cast<const float4 *>(dt + 32 * qb2 + 8 * g + 4 * lh);
+        sc[4 * g] = -a.x; sc[4 * g + 1] = -a.y; sc[4 * g + 2] = -a.z; sc[4 * g + 3] = -a.w;
+        dp[4 * g] = -b.x; dp[4 * g + 1] = -b.y; dp[4 * g + 2] = -b.z; dp[4 * g + 3] = -b.w;
+      }
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_rm_frag<D>(qt, 32 * qb2 + lr, 2 * s + lh), kf[s], sc, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_rm_frag<D>(dot_rm, 32 * qb2 + lr, 2 * s + lh), vf[s], dp, 0, 0, 0);
+      }
+      unsigned int pw[2][4], dsw[2][4];
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        float p2[2], ds2[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          float p = __builtin_amdgcn_exp2f(sc[r + u]);          // padded / fully masked rows: lse2 = +inf -> 0
+          if (MASK) {
+            const int qq = q0 + 32 * qb2 + ((r + u) & 3) + 8 * ((r + u) >> 2) + 4 * lh;
+            if (qq < Lq && krow < Lk && mask[(long)bh * mask_bh_stride + (long)qq * Lk + krow] != 0) p = 0.f;
+          }
+          p2[u] = p;
+          ds2[u] = p * dp[r + u];
+        }
+        pw[r >> 3][(r & 7) >> 1] = pack_bf16x2(p2[0], p2[1]);
+        dsw[r >> 3][(r & 7) >> 1] = pack_bf16x2(ds2[0], ds2[1]);
+      }
+#pragma unroll
+      for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          dvt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_t_frag(dott, 32 * d + lr, 4 * qb2 + 2 * tt + lh),
+                                                           make_frag(pw[tt]), dvt[d], 0, 0, 0);
+          dkt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_t_frag(qtt, 32 * d + lr, 4 * qb2 + 2 * tt + lh),
+                                                           make_frag(dsw[tt]), dkt[d], 0, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  if (krow < Lk) {
+    float *krow_o = dk + ((long)bh * Lk + krow) * D, *vrow_o = dv + ((long)bh * Lk + krow) * D;
+    const float ln2 = 0.6931471805599453f;
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        *reinterpret_cast<float4 *>(krow_o + 32 * d + 8 * g + 4 * lh) =
+            make_float4(dkt[d][4 * g] * ln2, dkt[d][4 * g + 1] * ln2, dkt[d][4 * g + 2] * ln2, dkt[d][4 * g + 3] * ln2);
+        *reinterpret_cast<float4 *>(vrow_o + 32 * d + 8 * g + 4 * lh) =
+            make_float4(dvt[d][4 * g], dvt[d][4 * g + 1], dvt[d][4 * g + 2], dvt[d][4 * g + 3]);
+      }
+  }
+}
+
 static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+template <int D>
+static int run_bwd(const float *q, const float *k, const float *v, const float *out, const float *dout, const float *lse,
+                   const uint8_t *mask, int mask_per_bh, int BH, int Lq, int Lk, float scale, float *dq, float *dk,
+                   float *dv, unsigned char *wsb, hipStream_t st) {
+  const int Lqp = round_up(Lq, 128), Lkp = round_up(Lk, 128);
+  const size_t nq = (size_t)BH * Lqp * D, nk = (size_t)BH * Lkp * D;
+  unsigned short *qs = (unsigned short *)wsb, *qst = qs + nq, *dor = qst + nq, *dot = dor + nq;
+  unsigned short *kr = dot + nq, *ktr = kr + nk, *vr = ktr + nk;
+  float *delta = (float *)(vr + nk), *lse2 = delta + (size_t)BH * Lqp;
+  attn_pack_kernel<D><<<dim3(Lqp / 64, BH), 256, 0, st>>>(q, Lq, Lqp, scale * 1.4426950408889634f, qs, qst);
+  attn_pack_kernel<D><<<dim3(Lqp / 64, BH), 256, 0, st>>>(dout, Lq, Lqp, 1.f, dor, dot);
+  attn_pack_kernel<D><<<dim3(Lkp / 64, BH), 256, 0, st>>>(k, Lk, Lkp, 1.f, kr, ktr);
+  attn_pack_kernel<D><<<dim3(Lkp / 64, BH), 256, 0, st>>>(v, Lk, Lkp, 1.f, vr, nullptr);
+  attn_delta_kernel<D><<<dim3(Lqp / 32, BH), 256, 0, st>>>(dout, out, lse, Lq, Lqp, delta, lse2);
+  const long ms = mask_per_bh ? (long)Lq * Lk : 0;
+  const int lds_q = 2 * 3 * 64 * D * 2, lds_kv = 2 * (4 * 64 * D * 2 + 1024);
+  if (mask) {
+    GCN_HIP(hipFuncSetAttribute((const void *)attn_bwd_dkv_kernel<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv));
+    attn_bwd_dq_kernel<D, true><<<dim3(Lqp / 128, BH), 256, lds_q, st>>>(qs, kr, vr, ktr, dor, lse2, delta, mask, ms, Lq, Lk, Lqp, Lkp, scale, dq);
+    attn_bwd_dkv_kernel<D, true><<<dim3(Lkp / 128, BH), 256, lds_kv, st>>>(qs, qst, kr, vr, dor, dot, lse2, delta, mask, ms, Lq, Lk, Lqp, Lkp, dk, dv);
+  } else {
+    GCN_HIP(hipFuncSetAttribute((const void *)attn_bwd_dkv_kernel<D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv));
+    attn_bwd_dq_kernel<D, false><<<dim3(Lqp / 128, BH), 256, lds_q, st>>>(qs, kr, vr, ktr, dor, lse2, delta, nullptr, 0, Lq, Lk, Lqp, Lkp, scale, dq);
+    attn_bwd_dkv_kernel<D, false><<<dim3(Lkp / 128, BH), 256, lds_kv, st>>>(qs, qst, kr, vr, dor, dot, lse2, delta, nullptr, 0, Lq, Lk, Lqp, Lkp, dk, dv);
+  }
+  return check_launch("attn_bwd kernels");
+}
+
 
 template <int D>
 static int run_fwd(const float *q, const float *k, const float *v, const uint8_t *mask, int mask_per_bh, int BH, int Lq,
@@ -268,8 +549,8 @@ using namespace gcn;
 GCN_EXPORT long gcn_attention_ws_bytes(int BH, int Lq, int Lk, int D) {
   if (BH < 0 || Lq < 1 || Lk < 1 || D < 1) return -1;
   const long Lqp = round_up(Lq, 128), Lkp = round_up(Lk, 128);
-  // forward: Q, K, V^T images; backward adds Q^T, K^T, V, dO, dO^T (all bf16) and delta (f32)
-  return 2L * BH * D * (3 * Lqp + 4 * Lkp) + 4L * BH * Lqp + 1024;
+  // forward: Qs, K, V^T images; backward: Qs, Qs^T, dO, dO^T, K, K^T, V (all bf16), delta and lse2 (f32)
+  return 2L * BH * D * (4 * Lqp + 4 * Lkp) + 8L * BH * Lqp + 1024;
 }
 
 GCN_EXPORT int gcn_attention_fwd_bf16(const float *q, const float *k, const float *v, const uint8_t *mask, int mask_per_bh,
@@ -283,4 +564,18 @@ GCN_EXPORT int gcn_attention_fwd_bf16(const float *q, const float *k, const floa
   hipStream_t st = (hipStream_t)stream;
   if (D == 32) return run_fwd<32>(q, k, v, mask, mask_per_bh, BH, Lq, Lk, scale, out, lse, (unsigned short *)ws, st);
   return run_fwd<64>(q, k, v, mask, mask_per_bh, BH, Lq, Lk, scale, out, lse, (unsigned short *)ws, st);
+}
+
+GCN_EXPORT int gcn_attention_bwd_bf16(const float *q, const float *k, const float *v, const float *out, const float *dout,
+                                      const float *lse, const uint8_t *mask, int mask_per_bh, int BH, int Lq, int Lk, int D,
+                                      float scale, float *dq, float *dk, float *dv, void *ws, void *stream) {
+  GCN_REQUIRE(q && k && v && out && dout && lse && dq && dk && dv && ws, "gcn_attention_bwd_bf16: null pointer");
+  GCN_REQUIRE(BH >= 0 && Lq >= 1 && Lk >= 1, "gcn_attention_bwd_bf16: bad shape");
+  GCN_REQUIRE(D == 32 || D == 64, "gcn_attention_bwd_bf16: head dim %d unsupported (32, 64)", D);
+  GCN_REQUIRE(((uintptr_t)ws & 15) == 0 && (((uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv | (uintptr_t)out | (uintptr_t)dout) & 15) == 0,
+              "gcn_attention_bwd_bf16: buffers must be 16-B aligned");
+  if (BH == 0) return GCN_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (D == 32) return run_bwd<32>(q, k, v, out, dout, lse, mask, mask_per_bh, BH, Lq, Lk, scale, dq, dk, dv, (unsigned char *)ws, st);
+  return run_bwd<64>(q, k, v, out, dout, lse, mask, mask_per_bh, BH, Lq, Lk, scale, dq, dk, dv, (unsigned char *)ws, st);
 }

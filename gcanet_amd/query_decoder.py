@@ -9,7 +9,7 @@ import torch.nn.functional as F
 from .attention import sdpa
 
 
-def _mha(attn, q_in, k_in, v_in, attn_mask=None):
+def _mha(attn, q_in, k_in, v_in, attn_mask=None, precision="f32"):
     """nn.MultiheadAttention(batch_first=True).forward with the fused core (eval: no dropout)."""
     d, h = attn.embed_dim, attn.num_heads
     w, b = attn.in_proj_weight, attn.in_proj_bias
@@ -19,14 +19,15 @@ def _mha(attn, q_in, k_in, v_in, attn_mask=None):
     B, L, _ = q.shape
     S = k.shape[1]
     split = lambda t, n: t.view(B, n, h, d // h).transpose(1, 2).reshape(B * h, n, d // h)
-    o = sdpa(split(q, L), split(k, S), split(v, S), attn_mask, (d // h) ** -0.5)
+    o = sdpa(split(q, L), split(k, S), split(v, S), attn_mask, (d // h) ** -0.5, precision)
     o = o.view(B, h, L, d // h).transpose(1, 2).reshape(B, L, d)
     return F.linear(o, attn.out_proj.weight, attn.out_proj.bias)
 
 
 class CrossAttentionLayer(nn.Module):
-    def __init__(self, d_model=256, nhead=8, dropout=0.0):
+    def __init__(self, d_model=256, nhead=8, dropout=0.0, precision="f32"):
         super().__init__()
+        self.precision = precision
         self.attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout, batch_first=True)
         self.norm = nn.LayerNorm(d_model)
         self.dropout = nn.Dropout(dropout)
@@ -47,15 +48,16 @@ class CrossAttentionLayer(nn.Module):
         for i in range(B):
             kv = source[batch_offsets[i]:batch_offsets[i + 1]].unsqueeze(0)
             am = attn_masks[i] if attn_masks else None
-            output = _mha(self.attn, query[i].unsqueeze(0), kv, kv, am)
+            output = _mha(self.attn, query[i].unsqueeze(0), kv, kv, am, self.precision)
             # quirk kept: the results of self.dropout(output) and self.norm(output) are discarded (:40-42)
             outputs.append(output + query[i])
         return torch.cat(outputs, dim=0)
 
 
 class SelfAttentionLayer(nn.Module):
-    def __init__(self, d_model=256, nhead=8, dropout=0.0):
+    def __init__(self, d_model=256, nhead=8, dropout=0.0, precision="f32"):
         super().__init__()
+        self.precision = precision
         self.attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout, batch_first=True)
         self.norm = nn.LayerNorm(d_model)
         self.dropout = nn.Dropout(dropout)
@@ -65,7 +67,7 @@ class SelfAttentionLayer(nn.Module):
 
     def forward(self, x, pe=None):
         q = k = self.with_pos_embed(x, pe)
-        output = _mha(self.attn, q, k, x)
+        output = _mha(self.attn, q, k, x, None, self.precision)
         return self.norm(self.dropout(output) + x)
 
 
@@ -85,15 +87,16 @@ class QueryDecoder(nn.Module):
     """query_decoder.py:104-239."""
 
     def __init__(self, num_layer=6, num_query=100, num_class=18, in_channel=32, d_model=256, nhead=8,
-                 hidden_dim=1024, dropout=0.0, activation_fn='relu', iter_pred=False, attn_mask=False, pe=False):
+                 hidden_dim=1024, dropout=0.0, activation_fn='relu', iter_pred=False, attn_mask=False, pe=False,
+                 precision="f32"):
         super().__init__()
         self.num_layer, self.num_query = num_layer, num_query
         self.input_proj = nn.Sequential(nn.Linear(in_channel, d_model), nn.LayerNorm(d_model), nn.ReLU())
         self.query = nn.Embedding(num_query, d_model)
         if pe:
             self.pe = nn.Embedding(num_query, d_model)
-        self.cross_attn_layers = nn.ModuleList([CrossAttentionLayer(d_model, nhead, dropout) for _ in range(num_layer)])
-        self.self_attn_layers = nn.ModuleList([SelfAttentionLayer(d_model, nhead, dropout) for _ in range(num_layer)])
+        self.cross_attn_layers = nn.ModuleList([CrossAttentionLayer(d_model, nhead, dropout, precision) for _ in range(num_layer)])
+        self.self_attn_layers = nn.ModuleList([SelfAttentionLayer(d_model, nhead, dropout, precision) for _ in range(num_layer)])
         self.ffn_layers = nn.ModuleList([FFN(d_model, hidden_dim, dropout, activation_fn) for _ in range(num_layer)])
         self.out_norm = nn.LayerNorm(d_model)
         self.out_cls = nn.Sequential(nn.Linear(d_model, d_model), nn.ReLU(), nn.Linear(d_model, num_class))

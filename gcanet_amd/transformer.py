@@ -40,8 +40,9 @@ class FeedForward(nn.Module):
 class Attention(nn.Module):
     """transformer.py:36-75.  NOTE the reference scales by dim ** -0.5 (the MODEL width, not dim_head)."""
 
-    def __init__(self, dim, heads=8, dim_head=64, dropout=0.):
+    def __init__(self, dim, heads=8, dim_head=64, dropout=0., precision="f32"):
         super().__init__()
+        self.precision = precision      # "f32" exact kernel | "bf16" matrix-core flash kernels (dim_head 32/64)
         inner_dim = dim_head * heads
         self.heads = heads
         self.scale = dim ** -0.5
@@ -58,18 +59,18 @@ class Attention(nn.Module):
             assert mask.shape[-1] == n, 'mask has incorrect dimensions'
             keep = mask[:, None, :] * mask[:, :, None]                       # (b,n,n)
             am = (~keep).unsqueeze(1).expand(-1, h, -1, -1).reshape(b * h, n, n)
-        out = sdpa(q, k, v, am, self.scale)
+        out = sdpa(q, k, v, am, self.scale, self.precision)
         out = out.view(b, h, n, -1).transpose(1, 2).reshape(b, n, -1)
         return self.to_out(out)
 
 
 class Transformer(nn.Module):
-    def __init__(self, dim, depth, heads, dim_head, mlp_dim, dropout):
+    def __init__(self, dim, depth, heads, dim_head, mlp_dim, dropout, precision="f32"):
         super().__init__()
         self.layers = nn.ModuleList([])
         for _ in range(depth):
             self.layers.append(nn.ModuleList([
-                Residual(PreNorm(dim, Attention(dim, heads=heads, dim_head=dim_head, dropout=dropout))),
+                Residual(PreNorm(dim, Attention(dim, heads=heads, dim_head=dim_head, dropout=dropout, precision=precision))),
                 Residual(PreNorm(dim, FeedForward(dim, mlp_dim, dropout=dropout)))]))
 
     def forward(self, x, mask=None):

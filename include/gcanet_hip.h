@@ -323,6 +323,15 @@ int gcn_attention_fwd_bf16(const float *q, const float *k, const float *v, const
                            int BH, int Lq, int Lk, int D, float scale, float *out, float *lse, void *ws,
                            void *stream);
 
+/* Backward of gcn_attention_fwd_bf16 (what autograd derives from transformer.py:52-69 /
+ * nn.MultiheadAttention): recomputes the probabilities from lse, two kernels (dQ by query block, dK/dV by
+ * key block -- no atomics, deterministic), seven bf16 MFMA products per tile pair.  out/lse are the
+ * forward's results, dout (BH,Lq,D) the incoming gradient; dq (BH,Lq,D), dk/dv (BH,Lk,D) f32 are fully
+ * written.  Same ws contract. */
+int gcn_attention_bwd_bf16(const float *q, const float *k, const float *v, const float *out, const float *dout,
+                           const float *lse, const uint8_t *mask, int mask_per_bh, int BH, int Lq, int Lk, int D,
+                           float scale, float *dq, float *dk, float *dv, void *ws, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -40,3 +40,25 @@ if L <= 8192:
     print("f32  fwd: %.3f ms  %.1f TFLOP/s" % (t, 4.0 * BH * L * L * D / t / 1e9))
 t = timeit(lambda: attention.sdpa(q, k, v, None, scale, "bf16"))
 print("bf16 fwd: %.3f ms  %.1f TFLOP/s (incl. operand packing)" % (t, 4.0 * BH * L * L * D / t / 1e9))
+
+# backward: bf16 flash kernels vs torch autograd of the f32 reference
+qq, kk, vv = (t.clone().requires_grad_(True) for t in (q, k, v))
+do = torch.randn(BH, L, D, generator=g).to(dev)
+o = attention.sdpa(qq, kk, vv, None, scale, "bf16")
+o.backward(do)
+if L <= 8192 and BH * L * L * 4 < 8e9:
+    q2, k2, v2 = (t.clone().requires_grad_(True) for t in (q, k, v))
+    ref = torch.softmax(torch.bmm(q2, k2.transpose(1, 2)) * scale, -1) @ v2
+    ref.backward(do)
+    for n, a, b in (("dq", qq.grad, q2.grad), ("dk", kk.grad, k2.grad), ("dv", vv.grad, v2.grad)):
+        print("%s: max abs err %.3e  (ref max %.3e, rel fro %.3e)" % (n, (a - b).abs().max().item(), b.abs().max().item(),
+                                                                 ((a - b).norm() / b.norm()).item()))
+
+
+def fb():
+    o = attention.sdpa(qq, kk, vv, None, scale, "bf16")
+    o.backward(do)
+
+
+t = timeit(fb, 3)
+print("bf16 fwd+bwd: %.3f ms  %.1f TFLOP/s (4+14 = 18 B H L^2 D incl. packing)" % (t, 18.0 * BH * L * L * D / t / 1e9))
