@@ -186,7 +186,7 @@ def main():
                                "+Adam; stops before forward_grouping/spconv (third-party, SURVEY 8f)" % (B, N, args.k),
                    "global_batch": world * B, "points": N, "k": args.k, "parallelism": "dp%d" % world},
         "knn_mpts_per_s": round(3 * B * N / knn_ms / 1e3, 2) if knn_ms > 0 else None,
-        "roofline": roofline, "kernels": kernels, "loss": float(loss),
+        "roofline": roofline, "kernels": kernels, "loss": float(loss.detach()),
     }
     if world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(N, args.k)

@@ -29,6 +29,8 @@ def parse_header(path=HEADER):
                 argtypes.append(C.c_void_p)
             elif re.match(r"(const\s+)?float\b", a):
                 argtypes.append(C.c_float)
+            elif re.match(r"(const\s+)?double\b", a):
+                argtypes.append(C.c_double)
             elif re.match(r"(const\s+)?(long|int64_t)\b", a):
                 argtypes.append(C.c_int64)
             elif re.match(r"(const\s+)?(int|int32_t)\b", a):

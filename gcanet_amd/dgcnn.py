@@ -156,6 +156,12 @@ def _edgeconv_backward(saved, cfg, dout, pm):
              _lib.ptr(SW), _lib.ptr(XW), _lib.ptr(RW), B, N, k, Cout, _lib.ptr(D1), _lib.ptr(D2))
         dx_pm = D1 @ W1 + D2 @ Wd                                      # (B,N,C)
         # weight gradients
+        if (C <= 16 or C == 64) and Cout in (64, 128):                 # all row reductions in one MFMA pass
+            dW = torch.empty(Cout, 2 * C, dtype=torch.float32, device=x.device)
+            wsf = torch.empty(_lib.lib().gcn_edge_wgrad_ws_floats(B, C, Cout), dtype=torch.float32, device=x.device)
+            _run("gcn_edge_wgrad", x, _lib.ptr(x), _lib.ptr(s), _lib.ptr(Dsp), _lib.ptr(D2), _lib.ptr(indeg),
+                 _lib.ptr(W.contiguous()), _lib.ptr(Ac), _lib.ptr(Bc), B, N, C, Cout, _lib.ptr(dW), _lib.ptr(wsf))
+            return dx_pm, dW, dgamma, dbeta
         G11 = _tall_skinny_tn(x * indeg.unsqueeze(2), x)               # X^T diag(indeg) X   (B,C,C)
         G21 = _tall_skinny_tn(x, s)                                    # X^T S
         ssum = s.sum(1)                                                # (B,C)
@@ -261,12 +267,14 @@ class GroupedBlockFunction(torch.autograd.Function):
                                                                      float((Cout // G) * N * k), want_jsel=True)
         # sparse part: one selected edge row per (point, channel) -- never a (B,N,k,Cout) one-hot
         jx = jsel.unsqueeze(-1).expand(-1, -1, -1, F)                          # (B,N,Cout,F)
-        contrib = coef.unsqueeze(-1) * W.view(1, 1, Cout, F)                   # coef[n,c] * W[c,:]
-        d_ef = torch.zeros_like(ef).scatter_add_(2, jx, contrib)               # (B,N,k,F)
         dW = torch.einsum("bno,bnof->of", coef, torch.gather(ef, 2, jx))
-        # dense part: dy = A + B*y, y = ef.W^T
-        T = torch.einsum("of,bo,og->bfg", W, Bc, W)                            # (B,F,F)
-        d_ef = d_ef + (Ac @ W).view(B, 1, 1, F) + torch.einsum("bnkf,bfg->bnkg", ef, T)
+        d_ef = None
+        if ctx.needs_input_grad[0]:     # the normal-feature branch builds ef from the INPUT cloud: no gradient wanted
+            contrib = coef.unsqueeze(-1) * W.view(1, 1, Cout, F)               # coef[n,c] * W[c,:]
+            d_ef = torch.zeros_like(ef).scatter_add_(2, jx, contrib)           # (B,N,k,F)
+            # dense part: dy = A + B*y, y = ef.W^T
+            T = torch.einsum("of,bo,og->bfg", W, Bc, W)                        # (B,F,F)
+            d_ef = d_ef + (Ac @ W).view(B, 1, 1, F) + torch.einsum("bnkf,bfg->bnkg", ef, T)
         gram = torch.einsum("bnkf,bnkg->bfg", ef, ef)
         dW = dW + torch.einsum("bo,bf->of", Ac, ef.sum((1, 2))) + torch.einsum("bo,og,bgf->of", Bc, W, gram)
         return d_ef, dW, dgamma, dbeta, None, None, None, None, None
@@ -296,14 +304,12 @@ def _route_backward_fused(dout_pm, gamma, beta, ymax, ymin, amax, amin, mean_rst
     S = torch.empty(B, G, 2, dtype=torch.float64, device=dev)
     ymin = ymin if (ymin is not None and ymin.numel()) else None
     amin = amin if (amin is not None and amin.numel()) else None
+    Ac = torch.empty(B, Cout, dtype=torch.float32, device=dev)
+    Bc = torch.empty(B, Cout, dtype=torch.float32, device=dev)
     _run("gcn_route_bwd", ymax, _lib.ptr(dout_pm), _lib.ptr(ymax), _lib.ptr(ymin), _lib.ptr(amax), _lib.ptr(amin),
          _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(mean_rstd), _lib.ptr(idx), B, N, k, Cout, G, float(slope),
-         _lib.ptr(coef), _lib.ptr(jsel), None, _lib.ptr(dsp), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(S))
-    rs, mu = mean_rstd[:, :, 1].double(), mean_rstd[:, :, 0].double()
-    Bg = -(rs * rs) * S[:, :, 1] / count_per_group
-    Ag = -(rs * S[:, :, 0]) / count_per_group - Bg * mu
-    Ac = Ag.float().repeat_interleave(cpg, 1).contiguous()
-    Bc = Bg.float().repeat_interleave(cpg, 1).contiguous()
+         _lib.ptr(coef), _lib.ptr(jsel), None, _lib.ptr(dsp), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(S),
+         float(count_per_group), _lib.ptr(Ac), _lib.ptr(Bc))
     return jsel, coef, Ac, Bc, dgamma, dbeta, dsp
 
 
@@ -452,7 +458,7 @@ class DGCNNEncoderGn(nn.Module):
     def forward_pm(self, x_cm, x_pm=None):
         """Point-major core: x_cm (B,Cin,N) feeds the kNN, x_pm (B,N,Cin) the row gathers.
         Returns (x_features (B,N,256) f32, x4 (B,1024))."""
-        from .layers import conv1x1, group_norm_relu
+        from .layers import conv1x1, global_max_pool, group_norm_relu
         k = self.k
         if x_pm is None:
             x_pm = x_cm.transpose(1, 2).contiguous()
@@ -465,7 +471,7 @@ class DGCNNEncoderGn(nn.Module):
         self.last_idx = (idx1, idx2, idx3)
         x_features = torch.cat((x1, x2, x3), dim=2)                            # (B,N,256)
         h = group_norm_relu(conv1x1(x_features, self.mlp1), self.bnmlp1)      # (B,N,1024)
-        return x_features, h.amax(dim=1)
+        return x_features, global_max_pool(h)
 
     def forward(self, x):
         """Reference signature: x (B,Cin,N) -> (B,1280,N)  (M4:492-534)."""

@@ -95,3 +95,27 @@ def linear_pm(x, weight, bias=None):
 def conv1x1(x, conv):
     """Conv1d(kernel 1) applied to point-major x (B,N,Cin) as a GEMM with the SAME parameter tensor."""
     return linear_pm(x, conv.weight[:, :, 0], conv.bias)
+
+
+class GlobalMaxPoolFunction(torch.autograd.Function):
+    """x (B,N,C) -> max over points (B,C)  (M4:513 `x.max(dim=2)` on the channel-major tensor).  Backward routes the
+    gradient to the arg-max row only: one zero fill + a (B,C)-element scatter instead of torch's dense
+    `grad * (x == max) / count` passes over (B,N,C)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        vals, arg = x.max(dim=1)
+        ctx.save_for_backward(arg)
+        ctx.shape = x.shape
+        return vals
+
+    @staticmethod
+    def backward(ctx, dout):
+        (arg,) = ctx.saved_tensors
+        g = torch.zeros(ctx.shape, dtype=dout.dtype, device=dout.device)
+        g.scatter_(1, arg.unsqueeze(1), dout.unsqueeze(1))
+        return g
+
+
+def global_max_pool(x):
+    return GlobalMaxPoolFunction.apply(x)

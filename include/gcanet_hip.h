@@ -263,12 +263,24 @@ int gcn_keyedge_bwd(const float *att, const int64_t *kidx, const float *U, const
  * gradient gz = dout * LeakyReLU'(z).  Outputs: coef = rstd*gamma*gz (B,N,Cout); jsel (slot, may be
  * NULL), msel = idx[b,n,jsel] (may be NULL), dsp[b, msel, c] += coef (may be NULL; zeroed by the
  * call), dgamma/dbeta (Cout) and S (B,G,2) f64 = [sum gamma*gz, sum gamma*gz*yhat] (zeroed by the call).
- * idx (B,N,k) int64 may be NULL when neither msel nor dsp is wanted. */
+ * idx (B,N,k) int64 may be NULL when neither msel nor dsp is wanted.  Ac/Bc (B,Cout) f32 (both or
+ * neither): the affine GroupNorm terms of dy = coef*[j==jsel] + Ac + Bc*y for count_per_group =
+ * (Cout/G)*N*k conv outputs per group, evaluated in double from S and mean_rstd. */
 int gcn_route_bwd(const float *dout_pm, const float *ymax, const float *ymin, const uint8_t *amax,
                   const uint8_t *amin, const float *gamma, const float *beta, const float *mean_rstd,
                   const int64_t *idx, int B, int N, int k, int Cout, int G, float slope, float *coef,
                   int64_t *jsel, int64_t *msel, float *dsp, float *dgamma, float *dbeta, double *S,
-                  void *stream);
+                  double count_per_group, float *Ac, float *Bc, void *stream);
+
+/* Weight gradient of the fused EdgeConv block from the pieces above, all row reductions in one pass on the
+ * f32 matrix cores:  dW (Cout,2C) = [dW1 - dWd | dWd] with dWd = D2^T x and
+ *   dW1 = Dsp^T x + sum_b Ac_b (x) sum_n s_b + sum_b Bc_b o (W1 x_b^T diag(indeg_b) x_b + Wd x_b^T s_b),
+ * W = [W1 | W2] (Cout,2C) the conv weight (Wd = W2 - W1), x/s (B,N,C), dsp/d2 (B,N,Cout), indeg (B,N).
+ * ws: gcn_edge_wgrad_ws_floats(B,C,Cout) floats of scratch.  C <= 16 or C == 64; Cout in {64,128}. */
+long gcn_edge_wgrad_ws_floats(int B, int C, int Cout);
+int gcn_edge_wgrad(const float *x_pm, const float *s_pm, const float *dsp, const float *d2, const float *indeg,
+                   const float *W, const float *Ac, const float *Bc, int B, int N, int C, int Cout, float *dW,
+                   float *ws, void *stream);
 
 /* D2 = coef + k*A + B*(SW + k*XW);  D1 = dsp + indeg*(A + B*P1) + B*RW   (all (B,N,Cout) f32;
  * A, B (B,Cout); indeg (B,N)): per-point sums of dy over outgoing / incoming edges. */

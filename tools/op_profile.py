@@ -50,3 +50,15 @@ tot = sum(r[0] for r in rows)
 print("total self device time per step: %.3f ms" % tot)
 for t, c, k in rows[:70]:
     print("%8.3f ms  n=%6.1f  %s" % (t, c, k[:100]))
+
+print("\nautograd nodes (device time incl. nested ops, per step):")
+rows = []
+for e in ka:
+    if "Backward" in e.key or e.key.startswith("autograd::engine") or "Function" in e.key:
+        dt = getattr(e, "device_time_total", None)
+        if dt is None:
+            dt = e.cuda_time_total
+        rows.append((dt / steps / 1e3, e.count / steps, e.key))
+rows.sort(reverse=True)
+for t, c, k in rows[:40]:
+    print("%8.3f ms  n=%6.1f  %s" % (t, c, k[:90]))
