@@ -540,23 +540,114 @@ __global__ __launch_bounds__(256) void neighbor_sum_kernel(const float *__restri
 }
 
 // r[m] = sum_{(n,j): idx[n,j]=m} x[n]  and indeg[m]  (scatter; 256-B contiguous f32 atomics per row)
-__global__ __launch_bounds__(256) void reverse_sum_kernel(const float *__restrict__ x, const int64_t *__restrict__ idx,
-                                                          int N, int C, int k, float *__restrict__ r,
-                                                          float *__restrict__ indeg) {
-  const int lane = lane_id();
-  const int n = blockIdx.x * 4 + wave_id(), b = blockIdx.y;
-  if (n >= N) return;
-  const float *xr = x + ((long)b * N + n) * C;
-  const int64_t *ip = idx + ((long)b * N + n) * k;
-  for (int c0 = 0; c0 < C; c0 += 64) {
-    const int c = c0 + lane;
-    if (c < C) {
-      const float v = xr[c];
-      for (int j = 0; j < k; ++j) atomicAdd(r + ((long)b * N + ip[j]) * C + c, v);
+// r[m] = sum over incoming edges (n -> m) of x[n], indeg[m] = their number -- the transposed aggregation of
+// the closed-form backward.  Scattering 4 M rows with global f32 atomics is the slow way (they execute at the
+// memory side); building the inverted lists first costs two more passes of integer atomics.  Here the
+// destinations are PARTITIONED: a workgroup owns R consecutive destination rows of one cloud as an LDS
+// accumulator, scans the cloud's whole edge list (coalesced, L2-resident: every partition of the cloud reads
+// the same 4 MB) and adds x[n] for the edges that land in its range -- on average k*R/N per 64 edges.
+// The accumulator is 64-bit FIXED POINT: ds_add_f32 retires 0.33 lane-ops/clk/CU on gfx950 against 3 for
+// ds_add_u64 (tools/micro/lds_atomic_bench.hip), and integer sums are order-independent, so r is bitwise
+// reproducible.  Scale 2^S with S chosen from max|x| (absmax_kernel) and N*k so that no sum can overflow:
+// the quantisation step is <= 2^-43 * max|x| * N*k / 2^19, far below f32 rounding of the result.
+// neighbour ids as u16 (N <= 65536): the scan below re-reads the list once per partition, and at 2 bytes per
+// edge a cloud's list (1 MB) plus its rows stays inside the XCD's 4 MB L2
+__global__ __launch_bounds__(256) void idx_to_u16_kernel(const int64_t *__restrict__ idx, long n, unsigned short *__restrict__ out) {
+  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 2;
+  if (i + 1 < n) {
+    const longlong2 v = *reinterpret_cast<const longlong2 *>(idx + i);
+    *reinterpret_cast<unsigned int *>(out + i) = (unsigned int)(v.x & 0xffff) | ((unsigned int)(v.y & 0xffff) << 16);
+  } else if (i < n) {
+    out[i] = (unsigned short)idx[i];
+  }
+}
+
+__global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ x, long n, unsigned int *__restrict__ out) {
+  float m = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  if (lane_id() == 0) atomicMax(out, __float_as_uint(m));      // non-negative floats order like their bit patterns
+}
+
+template <typename IdxT>
+__global__ __launch_bounds__(1024) void reverse_sum_lds_kernel(const float *__restrict__ x, const IdxT *__restrict__ idx,
+                                                               const unsigned int *__restrict__ absmax_bits, int B, int N,
+                                                               int C, int k, int R, float *__restrict__ r,
+                                                               float *__restrict__ indeg) {
+  extern __shared__ unsigned long long qacc[];          // [R][C] fixed-point sums, then [R] u32 counts
+  unsigned int *cnt = reinterpret_cast<unsigned int *>(qacc + (long)R * C);
+  const int lane = lane_id(), wave = wave_id();
+  // workgroup id -> (cloud, partition) with the CLOUD fastest: ids are dealt round-robin to the 8 XCDs, so all
+  // partitions of a cloud run on one XCD and share its L2 copy of the cloud's edge list and rows (with the
+  // partition fastest every XCD streamed all clouds through a 4 MB L2: 880 us instead of ~100)
+  const int b = blockIdx.x % B, m0 = (blockIdx.x / B) * R;
+  for (int i = threadIdx.x; i < R * C; i += 1024) qacc[i] = 0ull;
+  for (int i = threadIdx.x; i < R; i += 1024) cnt[i] = 0u;
+  __syncthreads();
+  // S = 62 - ceil(log2(max|x|)) - ceil(log2(N*k)), clamped to [0, 40]
+  const float mx = __uint_as_float(*absmax_bits);
+  int ex = 0;
+  if (mx > 0.f) (void)frexpf(mx, &ex);                   // mx = f * 2^ex, f in [0.5,1)  => mx < 2^ex
+  int S = 62 - ex - (64 - __clzll((long long)N * k));
+  S = S < 0 ? 0 : (S > 40 ? 40 : S);
+  const float scale = ldexpf(1.f, S);
+  const double inv = ldexp(1.0, -S);
+  const IdxT *ib = idx + (long)b * N * k;
+  const float *xb = x + (long)b * N * C;
+  // A wave walks source points four at a time: their neighbour lists (lane = slot) and, unconditionally, their
+  // rows (lane = channel; P(some edge of a point lands in the range) = 1-(1-R/N)^k ~ 0.9) are fetched together,
+  // so the per-match work is a scalar read and ONE conflict-free ds_add_u64 per 64 channels.
+  // (loads are unconditional on clamped addresses and masked afterwards: a predicated load makes hipcc emit
+  //  branch + s_waitcnt vmcnt(0) per load, i.e. eight serialised round trips per iteration -- 880 us vs 90;
+  //  and the next four points are fetched before the current four are processed)
+  float xf_n[4];
+  int mraw_n[4];
+  auto fetch = [&](int n0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xf_n[i] = xb[(long)min(n0 + i, N - 1) * C + min(lane, C - 1)];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mraw_n[i] = (int)ib[(long)min(n0 + i, N - 1) * k + min(lane, k - 1)];
+  };
+  fetch(wave * 4);
+  for (int n0 = wave * 4; n0 < N; n0 += 16 * 4) {
+    float xf[4];
+    int mraw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { xf[i] = xf_n[i]; mraw[i] = mraw_n[i]; }
+    if (n0 + 64 < N) fetch(n0 + 64);                   // wave-uniform
+    unsigned long long xr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xr[i] = (unsigned long long)__float2ll_rn(xf[i] * scale);
+    for (int j0 = 0; j0 < k; j0 += 64) {
+      int mi[4];
+      if (j0 > 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mraw[i] = (int)ib[(long)min(n0 + i, N - 1) * k + min(j0 + lane, k - 1)];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) mi[i] = (n0 + i < N && j0 + lane < k) ? mraw[i] - m0 : -1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        unsigned long long hit = __ballot((unsigned)mi[i] < (unsigned)R);
+        while (hit) {
+          const int l = __ffsll((long long)hit) - 1;
+          hit &= hit - 1;
+          const int mm = readlane_i(mi[i], l);
+          if (lane < C) atomicAdd(&qacc[mm * C + lane], xr[i]);
+          for (int c = lane + 64; c < C; c += 64)
+            atomicAdd(&qacc[mm * C + c], (unsigned long long)__float2ll_rn(xb[(long)(n0 + i) * C + c] * scale));
+          if (lane == 0) atomicAdd(&cnt[mm], 1u);
+        }
+      }
     }
   }
+  __syncthreads();
+  const int rows = min(R, N - m0);
+  float *rb = r + ((long)b * N + m0) * C;
+  for (int i = threadIdx.x; i < rows * C; i += 1024) rb[i] = (float)((double)(long long)qacc[i] * inv);
   if (indeg)
-    for (int j = lane; j < k; j += 64) atomicAdd(indeg + (long)b * N + ip[j], 1.f);
+    for (int i = threadIdx.x; i < rows; i += 1024) indeg[(long)b * N + m0 + i] = (float)cnt[i];
 }
 
 
@@ -802,16 +893,39 @@ GCN_EXPORT int gcn_neighbor_sum(const float *x_pm, const int64_t *idx, int B, in
   return check_launch("neighbor_sum_kernel");
 }
 
+GCN_EXPORT long gcn_reverse_sum_ws_bytes(int B, int N, int k) {
+  if (B < 0 || N < 1 || k < 1) return -1;
+  return 16 + (N <= 65536 ? 2L * B * N * k : 0);
+}
+
 GCN_EXPORT int gcn_reverse_sum(const float *x_pm, const int64_t *idx, int B, int N, int C, int k, float *r, float *indeg,
-                               void *stream) {
-  GCN_REQUIRE(x_pm && idx && r, "gcn_reverse_sum: null pointer");
+                               void *ws, void *stream) {
+  GCN_REQUIRE(x_pm && idx && r && ws, "gcn_reverse_sum: null pointer");
   GCN_REQUIRE(B >= 0 && N >= 1 && C >= 1 && k >= 1, "gcn_reverse_sum: bad shape");
+  GCN_REQUIRE(C <= 2048, "gcn_reverse_sum: C=%d too wide for one LDS row block", C);
+  GCN_REQUIRE(((uintptr_t)ws & 15) == 0 && ((uintptr_t)idx & 15) == 0, "gcn_reverse_sum: ws/idx must be 16-B aligned");
   if (B == 0) return GCN_OK;
   hipStream_t st = (hipStream_t)stream;
-  GCN_HIP(hipMemsetAsync(r, 0, sizeof(float) * (size_t)B * N * C, st));
-  if (indeg) GCN_HIP(hipMemsetAsync(indeg, 0, sizeof(float) * (size_t)B * N, st));
-  reverse_sum_kernel<<<dim3(cdiv(N, 4), B), 256, 0, st>>>(x_pm, idx, N, C, k, r, indeg);
-  return check_launch("reverse_sum_kernel");
+  GCN_HIP(hipMemsetAsync(ws, 0, 4, st));
+  absmax_kernel<<<512, 256, 0, st>>>(x_pm, (long)B * N * C, (unsigned int *)ws);
+  // destination rows per workgroup: ~256 workgroups in total, bounded by 128 KB of LDS
+  int R = (int)(((long)N * B + 255) / 256);
+  const int rmax = (128 * 1024) / (8 * C + 4);
+  if (R > rmax) R = rmax;
+  if (R < 1) R = 1;
+  const size_t lds = (size_t)R * C * 8 + (size_t)R * 4;
+  const int grid = cdiv(N, R) * B;
+  if (N <= 65536) {
+    unsigned short *i16 = reinterpret_cast<unsigned short *>((char *)ws + 16);
+    const long E = (long)B * N * k;
+    idx_to_u16_kernel<<<cdiv((E + 1) / 2, 256), 256, 0, st>>>(idx, E, i16);
+    GCN_HIP(hipFuncSetAttribute((const void *)reverse_sum_lds_kernel<unsigned short>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    reverse_sum_lds_kernel<unsigned short><<<grid, 1024, lds, st>>>(x_pm, i16, (const unsigned int *)ws, B, N, C, k, R, r, indeg);
+  } else {
+    GCN_HIP(hipFuncSetAttribute((const void *)reverse_sum_lds_kernel<int64_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    reverse_sum_lds_kernel<int64_t><<<grid, 1024, lds, st>>>(x_pm, idx, (const unsigned int *)ws, B, N, C, k, R, r, indeg);
+  }
+  return check_launch("reverse_sum_lds_kernel");
 }
 
 GCN_EXPORT int gcn_keyedge_fwd(const float *att, const int64_t *kidx, const float *U, const float *V, int B, int N, int k,

@@ -4,8 +4,8 @@
 //                        per-channel dgamma/dbeta, per-(cloud,group) S1/S2, coef = rstd*gamma*g,
 //                        the selected neighbour slot / id and the sparse scatter Dsp[m_sel] += coef
 //   edge_combine_kernel  D1/D2 (the per-point sums of dy over incoming / outgoing edges)
-//   graph inversion      count -> scan -> fill of the reverse neighbour lists, and the gather form of
-//                        r[m] = sum_{n: m in idx[n]} x[n]  (replaces 2.1 GB of f32 atomics per call)
+//   edge_wgrad_kernel    every row reduction of the weight gradient in one f32-MFMA pass
+//   (the transposed aggregation r = Adj^T.x lives in edgeconv.hip: reverse_sum_lds_kernel)
 // The reference has no counterpart kernels: its autograd walks the materialised (B,Cout,N,k) tensor.
 #include "common.h"
 
@@ -104,72 +104,6 @@ __global__ __launch_bounds__(256) void edge_combine_kernel(const float *__restri
     D1[o] = dsp[o] + dg * (a + bb * P1[o]) + bb * RW[o];
   }
 }
-
-// ---------------------------------------------------------------- reverse neighbour lists
-__global__ void graph_count_kernel(const int64_t *__restrict__ idx, long E, int N, int k, int *__restrict__ cnt) {
-  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= E) return;
-  const long b = e / ((long)N * k);
-  atomicAdd(cnt + b * N + idx[e], 1);
-}
-
-// one workgroup per cloud: exclusive scan of cnt[b,0..N) -> start[b,0..N], start[b,N] = N*k; cursor := start
-__global__ __launch_bounds__(1024) void graph_scan_kernel(int N, const int *__restrict__ cnt, int *__restrict__ start,
-                                                          int *__restrict__ cursor) {
-  __shared__ int part[1024];
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const int chunk = (N + 1023) / 1024;
-  const int lo = min(tid * chunk, N), hi = min(lo + chunk, N);
-  int s = 0;
-  for (int i = lo; i < hi; ++i) s += cnt[(long)b * N + i];
-  part[tid] = s;
-  __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {
-    const int v = tid >= off ? part[tid - off] : 0;
-    __syncthreads();
-    part[tid] += v;
-    __syncthreads();
-  }
-  int run = part[tid] - s;
-  for (int i = lo; i < hi; ++i) {
-    start[(long)b * (N + 1) + i] = run;
-    cursor[(long)b * N + i] = run;
-    run += cnt[(long)b * N + i];
-  }
-  if (tid == 1023) start[(long)b * (N + 1) + N] = part[1023];
-}
-
-__global__ void graph_fill_kernel(const int64_t *__restrict__ idx, long E, int N, int k, int *__restrict__ cursor,
-                                  int *__restrict__ rev) {
-  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= E) return;
-  const long b = e / ((long)N * k);
-  const int n = (int)((e / k) % N);
-  const int pos = atomicAdd(cursor + b * N + idx[e], 1);
-  rev[b * (long)N * k + pos] = n;
-}
-
-// r[m] = sum over reverse neighbours; lists are first sorted in-wave... (order only affects f32 rounding)
-__global__ __launch_bounds__(256) void reverse_gather_kernel(const float *__restrict__ x, const int *__restrict__ start,
-                                                             const int *__restrict__ rev, int N, int C, int k,
-                                                             float *__restrict__ r, float *__restrict__ indeg) {
-  const int lane = lane_id();
-  const int m = blockIdx.x * 4 + wave_id(), b = blockIdx.y;
-  if (m >= N) return;
-  const int s0 = start[(long)b * (N + 1) + m], s1 = start[(long)b * (N + 1) + m + 1];
-  const int *lst = rev + (long)b * N * k;
-  const float *xb = x + (long)b * N * C;
-  for (int c0 = 0; c0 < C; c0 += 64) {
-    const int c = c0 + lane;
-    if (c < C) {
-      float acc = 0.f;
-      for (int t = s0; t < s1; ++t) acc += xb[(long)lst[t] * C + c];
-      r[((long)b * N + m) * C + c] = acc;
-    }
-  }
-  if (indeg && lane == 0) indeg[(long)b * N + m] = (float)(s1 - s0);
-}
-
 
 // ------------------------------------------------------------------ fused weight-gradient reductions
 // All row-reductions the closed-form EdgeConv backward needs, in ONE pass over the point rows, on the f32
@@ -359,30 +293,6 @@ GCN_EXPORT int gcn_edge_combine(const float *coef, const float *dsp, const float
   const int g = (int)((per + 255) / 256 > 1024 ? 1024 : (per + 255) / 256);
   edge_combine_kernel<<<dim3(g, B), 256, 0, (hipStream_t)stream>>>(coef, dsp, indeg, Ac, Bc, P1, SW, XW, RW, N, Cout, (float)k, D1, D2);
   return check_launch("edge_combine_kernel");
-}
-
-GCN_EXPORT int gcn_graph_invert(const int64_t *idx, int B, int N, int k, int32_t *rev_start, int32_t *rev_list,
-                                int32_t *ws, void *stream) {
-  GCN_REQUIRE(idx && rev_start && rev_list && ws, "gcn_graph_invert: null pointer");
-  GCN_REQUIRE(B >= 0 && N >= 1 && k >= 1, "gcn_graph_invert: bad shape");
-  if (B == 0) return GCN_OK;
-  hipStream_t st = (hipStream_t)stream;
-  int32_t *cnt = ws, *cursor = ws + (size_t)B * N;
-  GCN_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t) * (size_t)B * N, st));
-  const long E = (long)B * N * k;
-  graph_count_kernel<<<cdiv(E, 256), 256, 0, st>>>(idx, E, N, k, cnt);
-  graph_scan_kernel<<<B, 1024, 0, st>>>(N, cnt, rev_start, cursor);
-  graph_fill_kernel<<<cdiv(E, 256), 256, 0, st>>>(idx, E, N, k, cursor, rev_list);
-  return check_launch("graph_invert");
-}
-
-GCN_EXPORT int gcn_reverse_gather(const float *x_pm, const int32_t *rev_start, const int32_t *rev_list, int B, int N,
-                                  int C, int k, float *r, float *indeg, void *stream) {
-  GCN_REQUIRE(x_pm && rev_start && rev_list && r, "gcn_reverse_gather: null pointer");
-  GCN_REQUIRE(B >= 0 && N >= 1 && C >= 1 && k >= 1, "gcn_reverse_gather: bad shape");
-  if (B == 0) return GCN_OK;
-  reverse_gather_kernel<<<dim3(cdiv(N, 4), B), 256, 0, (hipStream_t)stream>>>(x_pm, rev_start, rev_list, N, C, k, r, indeg);
-  return check_launch("reverse_gather_kernel");
 }
 
 GCN_EXPORT long gcn_edge_wgrad_ws_floats(int B, int C, int Cout) {

@@ -139,17 +139,13 @@ def _edgeconv_backward(saved, cfg, dout, pm):
         dpm = dout if pm else dout.permute(0, 2, 1)
         _, coef, Ac, Bc, dgamma, dbeta, Dsp = _route_backward_fused(dpm, gamma, beta, ymax, ymin, amax, amin, mean_rstd,
                                                                     G, slope, Mg, idx=idx, want_dsp=True)
-        # graph aggregations: s = Adj.x (gather), r = Adj^T.x (gather over the inverted lists), in-degree
+        # graph aggregations: s = Adj.x (gather), r = Adj^T.x and the in-degree (destination-partitioned LDS scatter)
         s = torch.empty_like(x)
         r = torch.empty_like(x)
         indeg = torch.empty(B, N, dtype=torch.float32, device=x.device)
-        rev_start = torch.empty(B, N + 1, dtype=torch.int32, device=x.device)
-        rev_list = torch.empty(B, N * k, dtype=torch.int32, device=x.device)
-        ws = torch.empty(2 * B * N, dtype=torch.int32, device=x.device)
         _run("gcn_neighbor_sum", x, _lib.ptr(x), _lib.ptr(idx), B, N, C, k, _lib.ptr(s))
-        _run("gcn_graph_invert", x, _lib.ptr(idx), B, N, k, _lib.ptr(rev_start), _lib.ptr(rev_list), _lib.ptr(ws))
-        _run("gcn_reverse_gather", x, _lib.ptr(x), _lib.ptr(rev_start), _lib.ptr(rev_list), B, N, C, k, _lib.ptr(r),
-             _lib.ptr(indeg))
+        ws4 = torch.empty(_lib.lib().gcn_reverse_sum_ws_bytes(B, N, k), dtype=torch.uint8, device=x.device)
+        _run("gcn_reverse_sum", x, _lib.ptr(x), _lib.ptr(idx), B, N, C, k, _lib.ptr(r), _lib.ptr(indeg), _lib.ptr(ws4))
         P1, SW, XW, RW = x @ W1.t(), s @ W1.t(), x @ Wd.t(), r @ Wd.t()        # (B,N,Cout) each
         D1, D2 = torch.empty_like(coef), torch.empty_like(coef)
         _run("gcn_edge_combine", x, _lib.ptr(coef), _lib.ptr(Dsp), _lib.ptr(indeg), _lib.ptr(Ac), _lib.ptr(Bc), _lib.ptr(P1),

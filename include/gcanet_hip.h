@@ -233,12 +233,15 @@ int gcn_edgeconv_finish(const float *ymax, const float *ymin, const double *gsum
 /* Graph aggregations used by the EdgeConv backward (no counterpart kernel in the reference: its
  * autograd walks the materialised (B,2C,N,k) tensor).  x_pm (B,N,C) f32, idx (B,N,k) int64.
  *   gcn_neighbor_sum: s[b,n,:] = sum_j x[b, idx[b,n,j], :]                      (gather)
- *   gcn_reverse_sum : r[b,m,:] = sum_{(n,j): idx[b,n,j]==m} x[b,n,:], indeg[b,m] = #(n,j) (scatter;
- *                     both outputs zeroed by the call; indeg (B,N) f32 may be NULL). */
+ *   gcn_reverse_sum : r[b,m,:] = sum_{(n,j): idx[b,n,j]==m} x[b,n,:], indeg[b,m] = #(n,j) (destination-
+ *                     partitioned 64-bit fixed-point LDS accumulation: no global atomics, bitwise
+ *                     reproducible; both outputs fully written; indeg (B,N) f32 may be NULL;
+ *                     ws: gcn_reverse_sum_ws_bytes(B,N,k) bytes of device scratch, 16-B aligned). */
 int gcn_neighbor_sum(const float *x_pm, const int64_t *idx, int B, int N, int C, int k, float *s,
                      void *stream);
+long gcn_reverse_sum_ws_bytes(int B, int N, int k);
 int gcn_reverse_sum(const float *x_pm, const int64_t *idx, int B, int N, int C, int k, float *r,
-                    float *indeg, void *stream);
+                    float *indeg, void *ws, void *stream);
 
 /* Fused conv + extreme/statistics half of OFFSET_PRED_MODULE's grouped block (M4:425-446): every
  * point has k edges to a fixed set of NK key points; the KPAM-scaled Conv2d(131->128) output is
@@ -287,16 +290,6 @@ int gcn_edge_wgrad(const float *x_pm, const float *s_pm, const float *dsp, const
 int gcn_edge_combine(const float *coef, const float *dsp, const float *indeg, const float *Ac,
                      const float *Bc, const float *P1, const float *SW, const float *XW, const float *RW,
                      int B, int N, int k, int Cout, float *D1, float *D2, void *stream);
-
-/* Reverse neighbour lists of a kNN graph idx (B,N,k) int64: rev_start (B,N+1) i32, rev_list (B,N*k) i32
- * (order inside a list unspecified); ws: 2*B*N i32 workspace. */
-int gcn_graph_invert(const int64_t *idx, int B, int N, int k, int32_t *rev_start, int32_t *rev_list,
-                     int32_t *ws, void *stream);
-
-/* r[b,m,:] = sum over reverse neighbours n of x[b,n,:]; indeg[b,m] = list length (may be NULL).
- * Gather form of gcn_reverse_sum (no atomics). */
-int gcn_reverse_gather(const float *x_pm, const int32_t *rev_start, const int32_t *rev_list, int B, int N,
-                       int C, int k, float *r, float *indeg, void *stream);
 
 /* ------------------------------------------- GroupNorm(+ReLU), point-major (B,N,C) ------ */
 

@@ -13,7 +13,10 @@ Cout = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 B, N, k = 8, 8192, 64
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
-x = torch.randn(B, N, C, device=dev, requires_grad=True)
+# features that live near a 3-D manifold (like real layer activations): a geometric kNN graph without the extreme
+# hubs of i.i.d. 64-D gaussians
+xyz = torch.rand(B, N, 3, device=dev)
+x = (torch.tanh(xyz @ torch.randn(3, C, device=dev)) + 0.05 * torch.randn(B, N, C, device=dev)).requires_grad_(True)
 xc = x.detach().transpose(1, 2).contiguous()
 idx = dgcnn.knn(xc, k, k)
 w = (torch.randn(Cout, 2 * C, device=dev) * 0.1).requires_grad_(True)
