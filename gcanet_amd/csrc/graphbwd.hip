@@ -145,24 +145,43 @@ __global__ __launch_bounds__(256) void edge_wgrad_kernel(const float *__restrict
 #pragma unroll
   for (int t = 0; t < CT; ++t) ss[t] = 0.f;
 
-  for (int n0 = r0; n0 < r1; n0 += 4) {
-    const int n = n0 + lk;
-    const bool ok = n < r1;
-    float xv[CT], sv[CT], pa[OW], qa[OW];
+  // The loop is latency-bound (13 small loads, then 24 MFMAs): operands of the NEXT four rows are fetched before
+  // the current MFMAs issue.  Loads are unconditional on clamped addresses and masked afterwards (predicated
+  // loads serialise: one branch + s_waitcnt vmcnt(0) each).
+  float xn[CT], sn[CT], pn[OW], qn[OW], dgn;
+  auto fetch = [&](int n0) {
+    const int n = min(n0 + lk, r1 - 1);
 #pragma unroll
     for (int t = 0; t < CT; ++t) {
-      const int c = 16 * t + li;
-      const bool okc = ok && c < C;
-      xv[t] = okc ? xb[(long)n * C + c] : 0.f;
-      sv[t] = okc ? sb[(long)n * C + c] : 0.f;
+      const int c = min(16 * t + li, C - 1);
+      xn[t] = xb[(long)n * C + c];
+      sn[t] = sb[(long)n * C + c];
     }
 #pragma unroll
     for (int o = 0; o < OW; ++o) {
       const int oc = 16 * (wave * OW + o) + li;
-      pa[o] = ok ? pb[(long)n * Cout + oc] : 0.f;
-      qa[o] = ok ? qb[(long)n * Cout + oc] : 0.f;
+      pn[o] = pb[(long)n * Cout + oc];
+      qn[o] = qb[(long)n * Cout + oc];
     }
-    const float dg = ok ? ib[n] : 0.f;
+    dgn = ib[n];
+  };
+  if (r0 < r1) fetch(r0);
+  for (int n0 = r0; n0 < r1; n0 += 4) {
+    const bool ok = n0 + lk < r1;
+    float xv[CT], sv[CT], pa[OW], qa[OW];
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+      const bool okc = ok && 16 * t + li < C;
+      xv[t] = okc ? xn[t] : 0.f;
+      sv[t] = okc ? sn[t] : 0.f;
+    }
+#pragma unroll
+    for (int o = 0; o < OW; ++o) {
+      pa[o] = ok ? pn[o] : 0.f;
+      qa[o] = ok ? qn[o] : 0.f;
+    }
+    const float dg = ok ? dgn : 0.f;
+    if (n0 + 4 < r1) fetch(n0 + 4);
 #pragma unroll
     for (int t = 0; t < CT; ++t) {
 #pragma unroll
@@ -226,28 +245,42 @@ __global__ __launch_bounds__(256) void edge_wgrad_kernel(const float *__restrict
 
 // dW (Cout, 2C) = [dW1 - dWd | dWd],  dWd = M2,
 // dW1[o,d] = M1[o,d] + sum_b Ac[b,o] ssum[b,d] + sum_b Bc[b,o] sum_c (W1[o,c] G11[b,c,d] + Wd[o,c] G21[b,c,d])
+// One workgroup per output row o: W row in LDS, thread = (d, cloud slice); G reads coalesced over d.
 __global__ __launch_bounds__(256) void edge_wgrad_finish_kernel(const float *__restrict__ W, const float *__restrict__ Ac,
                                                                 const float *__restrict__ Bc, const float *__restrict__ M1,
                                                                 const float *__restrict__ M2, const float *__restrict__ G11,
                                                                 const float *__restrict__ G21, const float *__restrict__ ssum,
                                                                 int B, int C, int Cout, float *__restrict__ dW) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= Cout * C) return;
-  const int o = e / C, d = e % C;
-  float acc = M1[e];
-  for (int b = 0; b < B; ++b) {
-    float t = 0.f;
-    for (int c = 0; c < C; ++c) {
-      const float w1 = W[(long)o * 2 * C + c], wd = W[(long)o * 2 * C + C + c] - w1;
-      t = fmaf(w1, G11[((long)b * C + c) * C + d], t);
-      t = fmaf(wd, G21[((long)b * C + c) * C + d], t);
-    }
-    acc = fmaf(Bc[(long)b * Cout + o], t, acc);
-    acc = fmaf(Ac[(long)b * Cout + o], ssum[(long)b * C + d], acc);
+  __shared__ float w1[64], wd[64], part[256];
+  const int o = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    w1[c] = W[(long)o * 2 * C + c];
+    wd[c] = W[(long)o * 2 * C + C + c] - w1[c];
   }
-  const float dwd = M2[e];
-  dW[(long)o * 2 * C + d] = acc - dwd;
-  dW[(long)o * 2 * C + C + d] = dwd;
+  __syncthreads();
+  const int slices = 256 / C > 0 ? 256 / C : 1;          // C <= 64 here
+  const int d = threadIdx.x % C, sl = threadIdx.x / C;
+  float acc = 0.f;
+  if (sl < slices) {
+    for (int b = sl; b < B; b += slices) {
+      float t = 0.f;
+      for (int c = 0; c < C; ++c) {
+        t = fmaf(w1[c], G11[((long)b * C + c) * C + d], t);
+        t = fmaf(wd[c], G21[((long)b * C + c) * C + d], t);
+      }
+      acc = fmaf(Bc[(long)b * Cout + o], t, acc);
+      acc = fmaf(Ac[(long)b * Cout + o], ssum[(long)b * C + d], acc);
+    }
+  }
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  if (threadIdx.x < C) {
+    float tot = M1[(long)o * C + d];
+    for (int s2 = 0; s2 < slices; ++s2) tot += part[s2 * C + d];
+    const float dwd = M2[(long)o * C + d];
+    dW[(long)o * 2 * C + d] = tot - dwd;
+    dW[(long)o * 2 * C + C + d] = dwd;
+  }
 }
 
 }  // namespace gcn
@@ -271,6 +304,7 @@ GCN_EXPORT int gcn_route_bwd(const float *dout_pm, const float *ymax, const floa
   if (B == 0) return GCN_OK;
   GCN_HIP(hipMemsetAsync(S, 0, sizeof(double) * 2 * B * G, st));
   if (dsp) GCN_HIP(hipMemsetAsync(dsp, 0, sizeof(float) * (size_t)B * N * Cout, st));
+  // (more, shorter blocks are slower: the end-of-block dgamma/dbeta/S atomics all land on the same few lines)
   int blocks = (512 + B - 1) / B;
   int rows = (N + blocks - 1) / blocks;
   if (rows < 8) rows = 8;
@@ -312,7 +346,7 @@ GCN_EXPORT int gcn_edge_wgrad(const float *x_pm, const float *s_pm, const float 
   GCN_HIP(hipMemsetAsync(ws, 0, sizeof(float) * nws, st));
   float *M1 = ws, *M2 = M1 + (long)Cout * C, *G11 = M2 + (long)Cout * C, *G21 = G11 + (long)B * C * C,
         *ssum = G21 + (long)B * C * C;
-  int blocks = (256 + B - 1) / B;
+  int blocks = (512 + B - 1) / B;
   int rows = (N + blocks - 1) / blocks;
   rows = (rows + 3) & ~3;
   const dim3 grid(cdiv(N, rows), B);
@@ -324,6 +358,6 @@ GCN_EXPORT int gcn_edge_wgrad(const float *x_pm, const float *s_pm, const float 
 #undef GCN_WG
   int rc = check_launch("edge_wgrad_kernel");
   if (rc) return rc;
-  edge_wgrad_finish_kernel<<<cdiv((long)Cout * C, 256), 256, 0, st>>>(W, Ac, Bc, M1, M2, G11, G21, ssum, B, C, Cout, dW);
+  edge_wgrad_finish_kernel<<<Cout, 256, 0, st>>>(W, Ac, Bc, M1, M2, G11, G21, ssum, B, C, Cout, dW);
   return check_launch("edge_wgrad_finish_kernel");
 }
