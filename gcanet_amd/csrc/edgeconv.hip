@@ -712,68 +712,108 @@ __global__ __launch_bounds__(256) void keyedge_fwd_kernel(const float *__restric
 
 
 // Backward of the key-point edge block.  dy[n,j,c] = coef[n,c]*[j == jsel[n,c]] + A[b,c] + B[b,c]*y[n,j,c]
-// (sparse routed gradient + GroupNorm coupling, see gcanet_amd/dgcnn.py) with y = att*(U[m]-V):
-//   datt[n,j] = sum_c dy*(U[m,c]-V[n,c]);  dV[n,c] = -sum_j att*dy;  dU[m,c] = sum_{(n,j)->m} att*dy.
-// One wave per point, lanes across channels; U and the dU accumulator live in LDS (one flush of
-// contiguous f32 atomics per workgroup).
+// (sparse routed gradient + GroupNorm coupling, see gcanet_amd/dgcnn.py) with y = att*(U[m]-V).  Everything that
+// is affine in y collapses (y is linear in U, V, att), so the (n,j,c) triple loop carries no atomics:
+//   dV[n,c]   = -(cf*att_js + A_c*a1[n] + B_c*(sum_j att_j^2 U[m_j,c] - a2[n]*V[n,c]))           (complete here)
+//   datt[n,j] = sum_{c: js=j} cf*d_js + (UA[m_j] - VA[n]) + att_j*(UB2[m_j] - 2 X[n,m_j] + VB2[n])  (complete here;
+//               UA = U.A, UB2 = U^2.B per key point, VA/VB2 per point, X = (V o B).U^T from one GEMM outside)
+//   dU[m,c]   = dUsp[m,c] + A_c*T1[m] + B_c*(U[m,c]*T2[m] - (A2^T V)[m,c])   with A2[n,m] = sum_j att_j^2 [m_j = m]
+//               written here as a dense (N x NK) matrix for one tall-skinny GEMM; dUsp, T1, T2 accumulate in LDS
+//               (B*N*(Cout+2k) float atomics instead of B*N*k*Cout: ds_add_f32 retires 0.33 lane-ops/clk/CU).
+// One wave per point; U, the sparse dU accumulator and the per-key tables live in LDS.
 __global__ __launch_bounds__(1024) void keyedge_bwd_kernel(const float *__restrict__ att, const int64_t *__restrict__ kidx,
                                                           const float *__restrict__ U, const float *__restrict__ V,
                                                           const float *__restrict__ coef, const int64_t *__restrict__ jsel,
                                                           const float *__restrict__ Ac, const float *__restrict__ Bc,
-                                                          int N, int k, int NK, int Cout, int pts_per_block,
-                                                          float *__restrict__ datt, float *__restrict__ dV,
-                                                          float *__restrict__ dU) {
-  extern __shared__ float lds_f[];  // U table, then dU accumulator (NK*Cout each)
-  float *u_lds = lds_f, *du_lds = lds_f + NK * Cout;
+                                                          const float *__restrict__ X, int N, int k, int NK, int Cout,
+                                                          int pts_per_block, float *__restrict__ datt, float *__restrict__ dV,
+                                                          float *__restrict__ A2, float *__restrict__ dUsp,
+                                                          float *__restrict__ T12) {
+  extern __shared__ float lds_f[];  // U | dUsp | UA | UB2 | T1 | T2 | per-wave: att[64], kidx[64], datt_sp[64], row[NKp]
+  const int NKp = (NK + 63) & ~63;
+  float *u_lds = lds_f, *du_lds = u_lds + NK * Cout;
+  float *ua = du_lds + NK * Cout, *ub2 = ua + NKp, *t1 = ub2 + NKp, *t2 = t1 + NKp;
   const int lane = lane_id(), wave = wave_id();
+  float *wa = t2 + NKp + wave * (192 + NKp);
+  int *wm = reinterpret_cast<int *>(wa + 64);
+  float *wd = wa + 128, *wrow = wa + 192;
   const int b = blockIdx.y;
   for (int i = threadIdx.x; i < NK * Cout; i += blockDim.x) {
     u_lds[i] = U[(long)b * NK * Cout + i];
     du_lds[i] = 0.f;
+  }
+  for (int i = threadIdx.x; i < NKp; i += blockDim.x) { t1[i] = 0.f; t2[i] = 0.f; }
+  __syncthreads();
+  for (int m = threadIdx.x; m < NK; m += blockDim.x) {
+    float sa = 0.f, sb = 0.f;
+    for (int c = 0; c < Cout; ++c) {
+      const float u = u_lds[m * Cout + c];
+      sa = fmaf(Ac[(long)b * Cout + c], u, sa);
+      sb = fmaf(Bc[(long)b * Cout + c] * u, u, sb);
+    }
+    ua[m] = sa;
+    ub2[m] = sb;
   }
   __syncthreads();
   const int n_lo = blockIdx.x * pts_per_block;
   const int n_hi = min(n_lo + pts_per_block, N);
   for (int n = n_lo + wave; n < n_hi; n += (int)(blockDim.x >> 6)) {
     const long pn = (long)b * N + n;
-    float pj[32];  // per-lane partial of datt[n,j] (k <= 32)
+    const bool jv = lane < k;
+    const float a = jv ? att[pn * k + lane] : 0.f;
+    const int m = jv ? (int)kidx[pn * k + lane] : 0;
+    wa[lane] = a;
+    wm[lane] = m;
+    wd[lane] = 0.f;
+    for (int i = lane; i < NKp; i += 64) wrow[i] = 0.f;
+    __builtin_amdgcn_wave_barrier();
+    float a1 = a, a2 = a * a;
 #pragma unroll
-    for (int j = 0; j < 32; ++j) pj[j] = 0.f;
+    for (int o = 32; o >= 1; o >>= 1) { a1 += __shfl_xor(a1, o); a2 += __shfl_xor(a2, o); }
+    if (jv) {
+      wrow[m] = a * a;                       // top-k key ids of one point are distinct
+      atomicAdd(&t1[m], a);
+      atomicAdd(&t2[m], a * a);
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < NK; i += 64) A2[pn * NK + i] = wrow[i];
+    float va = 0.f, vb2 = 0.f;
     for (int c0 = 0; c0 < Cout; c0 += 64) {
-      const int c = c0 + lane;
-      const bool cv = c < Cout;
-      const float v = cv ? V[pn * Cout + c] : 0.f;
-      const float a_c = cv ? Ac[(long)b * Cout + c] : 0.f, b_c = cv ? Bc[(long)b * Cout + c] : 0.f;
-      const float cf = cv ? coef[pn * Cout + c] : 0.f;
-      const int js = cv ? (int)jsel[pn * Cout + c] : -1;
-      float dv = 0.f;
-#pragma unroll
-      for (int j = 0; j < 32; ++j) {
-        if (j < k) {
-          const float a = att[pn * k + j];
-          const int m = (int)kidx[pn * k + j];
-          const float d = (cv ? u_lds[m * Cout + c] : 0.f) - v;
-          const float dy = (j == js ? cf : 0.f) + a_c + b_c * (a * d);
-          const float ady = a * dy;
-          dv -= ady;
-          if (cv) atomicAdd(&du_lds[m * Cout + c], ady);
-          pj[j] = fmaf(dy, d, pj[j]);
-        }
+      const int c = min(c0 + lane, Cout - 1);
+      const bool cv = c0 + lane < Cout;
+      const float v = V[pn * Cout + c];
+      const float a_c = Ac[(long)b * Cout + c], b_c = Bc[(long)b * Cout + c];
+      const float cf = coef[pn * Cout + c];
+      const int js = (int)jsel[pn * Cout + c];
+      float wu2 = 0.f;
+      for (int j = 0; j < k; ++j) {
+        const float aj = readlane_f(a, j);
+        const int mj = readlane_i(m, j);
+        wu2 = fmaf(aj * aj, u_lds[mj * Cout + c], wu2);
       }
-      if (cv) dV[pn * Cout + c] = dv;
-    }
-#pragma unroll
-    for (int j = 0; j < 32; ++j) {
-      if (j < k) {
-        float t = pj[j];
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) t += __shfl_xor(t, o);
-        if (lane == 0) datt[pn * k + j] = t;
+      const float att_sel = wa[js];
+      const int m_sel = wm[js];
+      const float d_sel = u_lds[m_sel * Cout + c] - v;
+      if (cv) {
+        dV[pn * Cout + c] = -(cf * att_sel + a_c * a1 + b_c * (wu2 - a2 * v));
+        atomicAdd(&wd[js], cf * d_sel);
+        atomicAdd(&du_lds[m_sel * Cout + c], cf * att_sel);
+        va = fmaf(a_c, v, va);
+        vb2 = fmaf(b_c * v, v, vb2);
       }
     }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { va += __shfl_xor(va, o); vb2 += __shfl_xor(vb2, o); }
+    __builtin_amdgcn_wave_barrier();
+    if (jv) datt[pn * k + lane] = wd[lane] + (ua[m] - va) + a * (ub2[m] - 2.f * X[pn * NK + m] + vb2);
+    __builtin_amdgcn_wave_barrier();
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < NK * Cout; i += blockDim.x) atomicAdd(dU + (long)b * NK * Cout + i, du_lds[i]);
+  for (int i = threadIdx.x; i < NK * Cout; i += blockDim.x) atomicAdd(dUsp + (long)b * NK * Cout + i, du_lds[i]);
+  for (int i = threadIdx.x; i < NK; i += blockDim.x) {
+    atomicAdd(T12 + ((long)b * 2) * NK + i, t1[i]);
+    atomicAdd(T12 + ((long)b * 2 + 1) * NK + i, t2[i]);
+  }
 }
 
 template <int KSTEPS, int CW, int RWT>
@@ -957,19 +997,23 @@ GCN_EXPORT int gcn_cast_pad_bf16(const float *x_pm, long rows, int C, void *x_pm
 }
 
 GCN_EXPORT int gcn_keyedge_bwd(const float *att, const int64_t *kidx, const float *U, const float *V, const float *coef,
-                               const int64_t *jsel, const float *Ac, const float *Bc, int B, int N, int k, int NK,
-                               int Cout, float *datt, float *dV, float *dU, void *stream) {
-  GCN_REQUIRE(att && kidx && U && V && coef && jsel && Ac && Bc && datt && dV && dU, "gcn_keyedge_bwd: null pointer");
-  GCN_REQUIRE(B >= 0 && N >= 1 && k >= 1 && k <= 32 && NK >= 1 && Cout >= 1, "gcn_keyedge_bwd: bad shape (need k <= 32)");
-  const size_t lds = sizeof(float) * 2 * (size_t)NK * Cout;
-  GCN_REQUIRE(lds <= 150 * 1024, "gcn_keyedge_bwd: key tables %zu B exceed LDS", lds);
+                               const int64_t *jsel, const float *Ac, const float *Bc, const float *X, int B, int N, int k,
+                               int NK, int Cout, float *datt, float *dV, float *A2, float *dUsp, float *T12, void *stream) {
+  GCN_REQUIRE(att && kidx && U && V && coef && jsel && Ac && Bc && X && datt && dV && A2 && dUsp && T12,
+              "gcn_keyedge_bwd: null pointer");
+  GCN_REQUIRE(B >= 0 && N >= 1 && k >= 1 && k <= 64 && NK >= 1 && Cout >= 1, "gcn_keyedge_bwd: bad shape (need k <= 64)");
+  const int NKp = (NK + 63) & ~63;
+  const size_t lds = sizeof(float) * (2 * (size_t)NK * Cout + 4 * NKp + 16 * (192 + NKp));
+  GCN_REQUIRE(lds <= 158 * 1024, "gcn_keyedge_bwd: key tables %zu B exceed LDS", lds);
   if (B == 0) return GCN_OK;
   hipStream_t st = (hipStream_t)stream;
-  GCN_HIP(hipMemsetAsync(dU, 0, sizeof(float) * (size_t)B * NK * Cout, st));
+  GCN_HIP(hipMemsetAsync(dUsp, 0, sizeof(float) * (size_t)B * NK * Cout, st));
+  GCN_HIP(hipMemsetAsync(T12, 0, sizeof(float) * (size_t)B * 2 * NK, st));
   GCN_HIP(hipFuncSetAttribute((const void *)keyedge_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int blocks_per_cloud = (256 + B - 1) / B;
   if (blocks_per_cloud > (N + 3) / 4) blocks_per_cloud = (N + 3) / 4;
   const int ppb = (N + blocks_per_cloud - 1) / blocks_per_cloud;
-  keyedge_bwd_kernel<<<dim3(cdiv(N, ppb), B), 1024, lds, st>>>(att, kidx, U, V, coef, jsel, Ac, Bc, N, k, NK, Cout, ppb, datt, dV, dU);
+  keyedge_bwd_kernel<<<dim3(cdiv(N, ppb), B), 1024, lds, st>>>(att, kidx, U, V, coef, jsel, Ac, Bc, X, N, k, NK, Cout, ppb,
+                                                                datt, dV, A2, dUsp, T12);
   return check_launch("keyedge_bwd_kernel");
 }

@@ -380,11 +380,17 @@ class KeyEdgeBlockFunction(torch.autograd.Function):
         dpm = dout if pm_out else dout.permute(0, 2, 1)
         jsel, coef, Ac, Bc, dgamma, dbeta, _ = _route_backward_fused(dpm, gamma, beta, ymax, ymin, amax, amin, mean_rstd,
                                                                      G, slope, Mg, want_jsel=True)
-        if k <= 32:
-            datt, dV, dU = torch.empty_like(att), torch.empty_like(V), torch.empty_like(U)
+        if k <= 64:
+            X = (V * Bc.unsqueeze(1)) @ U.transpose(1, 2)                   # (B,N,NK)
+            datt, dV = torch.empty_like(att), torch.empty_like(V)
+            A2 = torch.empty(B, N, NK, dtype=torch.float32, device=att.device)
+            dUsp = torch.empty_like(U)
+            T12 = torch.empty(B, 2, NK, dtype=torch.float32, device=att.device)
             _run("gcn_keyedge_bwd", att, _lib.ptr(att), _lib.ptr(kidx), _lib.ptr(U), _lib.ptr(V), _lib.ptr(coef.contiguous()),
-                 _lib.ptr(jsel.contiguous()), _lib.ptr(Ac.contiguous()), _lib.ptr(Bc.contiguous()), B, N, k, NK, Cout,
-                 _lib.ptr(datt), _lib.ptr(dV), _lib.ptr(dU))
+                 _lib.ptr(jsel.contiguous()), _lib.ptr(Ac.contiguous()), _lib.ptr(Bc.contiguous()), _lib.ptr(X.contiguous()),
+                 B, N, k, NK, Cout, _lib.ptr(datt), _lib.ptr(dV), _lib.ptr(A2), _lib.ptr(dUsp), _lib.ptr(T12))
+            dU = dUsp + Ac.unsqueeze(1) * T12[:, 0].unsqueeze(-1) \
+                + Bc.unsqueeze(1) * (U * T12[:, 1].unsqueeze(-1) - _tall_skinny_tn(A2, V))
             return datt, None, dU, dV, dgamma, dbeta, None, None, None, None
         # generic-k fallback in torch ops (incidence matrices A1 = sum_j att [m_j=m], A2 = sum_j att^2 [m_j=m])
         A_, B_ = Ac.unsqueeze(1), Bc.unsqueeze(1)                       # (B,1,Cout)

@@ -254,11 +254,15 @@ int gcn_keyedge_fwd(const float *att, const int64_t *kidx, const float *U, const
 
 /* Backward of gcn_keyedge_fwd given the routed/affine decomposition of the conv-output gradient
  *   dy[b,n,j,c] = coef[b,n,c]*[j == jsel[b,n,c]] + Ac[b,c] + Bc[b,c]*y[b,n,j,c]
- * (coef (B,N,Cout) f32, jsel (B,N,Cout) int64 neighbour slot, Ac/Bc (B,Cout) f32).  Writes
- * datt (B,N,k), dV (B,N,Cout), dU (B,NK,Cout) (zeroed by the call).  k <= 32. */
+ * (coef (B,N,Cout) f32, jsel (B,N,Cout) int64 neighbour slot, Ac/Bc (B,Cout) f32) and the caller's
+ * X (B,N,NK) = (V o Bc) . U^T (one GEMM).  Writes datt (B,N,k) and dV (B,N,Cout) complete, and the pieces of
+ *   dU = dUsp + Ac (x) T1 + Bc o (U o T2 - A2^T V):
+ * A2 (B,N,NK) dense incidence sum_j att^2 [kidx = m], dUsp (B,NK,Cout), T12 (B,2,NK) = column sums of the
+ * att / att^2 incidences (dUsp, T12 zeroed by the call).  k <= 64. */
 int gcn_keyedge_bwd(const float *att, const int64_t *kidx, const float *U, const float *V,
-                    const float *coef, const int64_t *jsel, const float *Ac, const float *Bc, int B,
-                    int N, int k, int NK, int Cout, float *datt, float *dV, float *dU, void *stream);
+                    const float *coef, const int64_t *jsel, const float *Ac, const float *Bc, const float *X,
+                    int B, int N, int k, int NK, int Cout, float *datt, float *dV, float *A2, float *dUsp,
+                    float *T12, void *stream);
 
 /* ------------------------- fused pieces of the closed-form grouped-block backward ------ */
 
