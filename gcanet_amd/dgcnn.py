@@ -271,8 +271,9 @@ class GroupedBlockFunction(torch.autograd.Function):
             # dense part: dy = A + B*y, y = ef.W^T
             T = torch.einsum("of,bo,og->bfg", W, Bc, W)                        # (B,F,F)
             d_ef = d_ef + (Ac @ W).view(B, 1, 1, F) + torch.einsum("bnkf,bfg->bnkg", ef, T)
-        gram = torch.einsum("bnkf,bnkg->bfg", ef, ef)
-        dW = dW + torch.einsum("bo,bf->of", Ac, ef.sum((1, 2))) + torch.einsum("bo,og,bgf->of", Bc, W, gram)
+        rows = ef.reshape(B, N * k, F)
+        gram = _tall_skinny_tn(rows, rows)                                     # (B,F,F), split-K over the N*k rows
+        dW = dW + torch.einsum("bo,bf->of", Ac, rows.sum(1)) + torch.einsum("bo,og,bgf->of", Bc, W, gram)
         return d_ef, dW, dgamma, dbeta, None, None, None, None, None
 
 

@@ -84,7 +84,7 @@ class LinearPMFunction(torch.autograd.Function):
             dx = (dy @ wc).to(ctx.in_dtypes[0])
             rows = dy.reshape(-1, dy.shape[-1])
             dw = tall_skinny_tn(rows, xc.reshape(-1, xc.shape[-1])).to(ctx.in_dtypes[1])
-            db = rows.float().sum(0) if ctx.has_bias else None
+            db = rows.sum(0, dtype=torch.float32) if ctx.has_bias else None   # f32 accumulation, no f32 copy of dy
         return dx, dw, db
 
 
