@@ -1,0 +1,76 @@
+"""Direct C-ABI tests of the graph-aggregation / weight-gradient kernels behind the closed-form EdgeConv backward
+(edgeconv.hip: reverse_sum_lds_kernel, neighbor_sum_kernel; graphbwd.hip: edge_wgrad_kernel) against plain torch
+restatements.  The end-to-end gradient parity vs the reference's autograd lives in test_edgeconv_gpu.py."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _graph(B, N, k, C, dev, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, N, C, generator=g).to(dev)
+    idx = torch.stack([torch.stack([torch.randperm(N, generator=g)[:k] for _ in range(N)]) for _ in range(B)]).to(dev)
+    return x, idx
+
+
+@pytest.mark.parametrize("B,N,k,C", [(2, 256, 16, 64), (1, 1000, 30, 6), (3, 333, 7, 128), (2, 2048, 64, 64), (1, 64, 80, 13)])
+def test_reverse_and_neighbor_sum(dev, B, N, k, C):
+    from gcanet_amd import _lib
+    if k > N:
+        pytest.skip("k > N")
+    x, idx = _graph(B, N, k, C, dev, B * 100 + N + k + C)
+    x[0, 0] *= 1e3                                    # wide dynamic range inside one tensor
+    r = torch.empty_like(x)
+    s = torch.empty_like(x)
+    indeg = torch.empty(B, N, device=dev)
+    ws = torch.empty(_lib.lib().gcn_reverse_sum_ws_bytes(B, N, k), dtype=torch.uint8, device=dev)
+    _lib.call("gcn_reverse_sum", _lib.ptr(x), _lib.ptr(idx), B, N, C, k, _lib.ptr(r), _lib.ptr(indeg), _lib.ptr(ws),
+              _lib.stream_of(x))
+    _lib.call("gcn_neighbor_sum", _lib.ptr(x), _lib.ptr(idx), B, N, C, k, _lib.ptr(s), _lib.stream_of(x))
+    xd = x.double()
+    r_ref = torch.zeros_like(xd)
+    deg_ref = torch.zeros(B, N, dtype=torch.float64, device=dev)
+    for b in range(B):
+        r_ref[b].index_add_(0, idx[b].reshape(-1), xd[b].repeat_interleave(k, 0))
+        deg_ref[b].index_add_(0, idx[b].reshape(-1), torch.ones(N * k, dtype=torch.float64, device=dev))
+    s_ref = torch.stack([xd[b][idx[b]].sum(1) for b in range(B)])
+    assert torch.equal(indeg.double(), deg_ref)
+    # fixed-point accumulation is exact up to one final rounding: <= 1 ulp of the f64 reference rounded to f32
+    assert (r.double() - r_ref).abs().max().item() <= 2e-7 * r_ref.abs().max().item() + 1e-30
+    assert (s.double() - s_ref).abs().max().item() <= 1e-5 * s_ref.abs().max().item()
+    r2 = torch.empty_like(x)
+    _lib.call("gcn_reverse_sum", _lib.ptr(x), _lib.ptr(idx), B, N, C, k, _lib.ptr(r2), None, _lib.ptr(ws), _lib.stream_of(x))
+    assert torch.equal(r, r2)                         # bitwise reproducible (integer sums)
+
+
+@pytest.mark.parametrize("B,N,C,Cout", [(2, 512, 64, 128), (3, 300, 6, 64), (1, 1024, 64, 64), (2, 130, 16, 128)])
+def test_edge_wgrad(dev, B, N, C, Cout):
+    from gcanet_amd import _lib
+    g = torch.Generator().manual_seed(N + C + Cout)
+    x, s = (torch.randn(B, N, C, generator=g).to(dev) for _ in range(2))
+    dsp, d2 = (torch.randn(B, N, Cout, generator=g).to(dev) for _ in range(2))
+    indeg = torch.randint(0, 9, (B, N), generator=g).float().to(dev)
+    W = torch.randn(Cout, 2 * C, generator=g).to(dev)
+    Ac, Bc = (torch.randn(B, Cout, generator=g).to(dev) for _ in range(2))
+    dW = torch.empty(Cout, 2 * C, device=dev)
+    ws = torch.empty(_lib.lib().gcn_edge_wgrad_ws_floats(B, C, Cout), device=dev)
+    _lib.call("gcn_edge_wgrad", _lib.ptr(x), _lib.ptr(s), _lib.ptr(dsp), _lib.ptr(d2), _lib.ptr(indeg), _lib.ptr(W),
+              _lib.ptr(Ac), _lib.ptr(Bc), B, N, C, Cout, _lib.ptr(dW), _lib.ptr(ws), _lib.stream_of(x))
+    xd, sd, pd, qd, W_, A_, B_ = (t.double() for t in (x, s, dsp, d2, W, Ac, Bc))
+    W1, Wd = W_[:, :C], W_[:, C:] - W_[:, :C]
+    G11 = torch.einsum("bnc,bn,bnd->bcd", xd, indeg.double(), xd)
+    G21 = torch.einsum("bnc,bnd->bcd", xd, sd)
+    dW1 = torch.einsum("bno,bnc->oc", pd, xd) + torch.einsum("bo,bc->oc", A_, sd.sum(1)) \
+        + torch.einsum("bo,boc->oc", B_, torch.einsum("oc,bcd->bod", W1, G11) + torch.einsum("oc,bcd->bod", Wd, G21))
+    dWd = torch.einsum("bno,bnc->oc", qd, xd)
+    ref = torch.cat([dW1 - dWd, dWd], 1)
+    assert (dW.double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
+def test_edge_wgrad_rejects_unsupported(dev):
+    from gcanet_amd import _lib
+    t = torch.zeros(8, device=dev)
+    with pytest.raises(RuntimeError):
+        _lib.call("gcn_edge_wgrad", _lib.ptr(t), _lib.ptr(t), _lib.ptr(t), _lib.ptr(t), _lib.ptr(t), _lib.ptr(t), _lib.ptr(t),
+                  _lib.ptr(t), 1, 1, 32, 64, _lib.ptr(t), _lib.ptr(t), _lib.stream_of(t))
