@@ -28,9 +28,11 @@ def init_distributed(backend=None):
 
 
 class FlatGradDP:
-    """Keeps every parameter's .grad as a view into one flat fp32 buffer, so the gradient exchange
-    is a single bucket: all_reduce(SUM) then scale by 1/world (about 20 MB for GCANet: ~0.25 ms on a
-    7-link xGMI ring)."""
+    """One flat fp32 gradient bucket per replica: the gradient exchange is a single all_reduce(SUM) then a scale
+    by 1/world (about 20 MB for GCANet: ~0.25 ms on a 7-link xGMI ring).
+    During backward the parameters' .grad are None, so autograd hands over its gradient tensors instead of
+    launching one accumulate kernel per parameter into pre-zeroed views; `all_reduce_grads` packs them into the
+    bucket with one multi-tensor copy and re-points every .grad at its view (what the optimizer then reads)."""
 
     def __init__(self, module, world_size=None):
         self.params = [p for p in module.parameters() if p.requires_grad]
@@ -38,13 +40,17 @@ class FlatGradDP:
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.views = []
         off = 0
         for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
+        for p, v in zip(self.params, self.views):
+            p.grad = v
 
     def zero_grad(self):
-        self.flat.zero_()
+        for p in self.params:
+            p.grad = None
 
     def sync_params(self, src=0):
         """Make replicas identical at start (same seed already does; this is the belt-and-braces broadcast)."""
@@ -52,7 +58,20 @@ class FlatGradDP:
             for p in self.params:
                 dist.broadcast(p.data, src)
 
+    def pack_grads(self):
+        dst, src = [], []
+        for p, v in zip(self.params, self.views):
+            if p.grad is None:
+                v.zero_()                       # parameter unused this step
+            elif p.grad.data_ptr() != v.data_ptr():
+                dst.append(v)
+                src.append(p.grad.detach().to(torch.float32))
+            p.grad = v
+        if dst:
+            torch._foreach_copy_(dst, src)
+
     def all_reduce_grads(self):
+        self.pack_grads()
         if self.world > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             self.flat.mul_(1.0 / self.world)
