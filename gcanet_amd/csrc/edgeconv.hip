@@ -657,7 +657,7 @@ __global__ __launch_bounds__(1024) void reverse_sum_lds_kernel(const float *__re
 // LeakyReLU+max.  The conv is linear, so y[n,j,:] = att[n,j] * (U[m_j,:] - V[n,:]) with
 // U = Wf.f_key + Wp.p_key (NK rows per cloud) and V = Wp.p_n: the whole key table sits in LDS and the
 // (B,N,k,128) tensor (1 GB at B=8,N=8192,k=30) is never formed.  Same outputs as edgeconv_fwd.
-__global__ __launch_bounds__(256) void keyedge_fwd_kernel(const float *__restrict__ att, const int64_t *__restrict__ kidx,
+__global__ __launch_bounds__(1024) void keyedge_fwd_kernel(const float *__restrict__ att, const int64_t *__restrict__ kidx,
                                                           const float *__restrict__ U, const float *__restrict__ V,
                                                           int N, int k, int NK, int Cout, int G, int pts_per_block,
                                                           float *__restrict__ ymax, float *__restrict__ ymin,
@@ -667,7 +667,7 @@ __global__ __launch_bounds__(256) void keyedge_fwd_kernel(const float *__restric
   const int lane = lane_id(), wave = wave_id();
   const int b = blockIdx.y;
   const float *Ub = U + (long)b * NK * Cout;
-  for (int i = threadIdx.x; i < NK * Cout; i += 256) u_lds[i] = Ub[i];
+  for (int i = threadIdx.x; i < NK * Cout; i += blockDim.x) u_lds[i] = Ub[i];
   __syncthreads();
   const int n_lo = blockIdx.x * pts_per_block;
   const int n_hi = min(n_lo + pts_per_block, N);
@@ -676,15 +676,28 @@ __global__ __launch_bounds__(256) void keyedge_fwd_kernel(const float *__restric
     const int c = c0 + lane;
     const bool cv = c < Cout;
     float s1 = 0.f, s2 = 0.f;
-    for (int n = n_lo + wave; n < n_hi; n += 4) {
+    for (int n = n_lo + wave; n < n_hi; n += (int)(blockDim.x >> 6)) {
       const long pn = (long)b * N + n;
-      const float v = cv ? V[pn * Cout + c] : 0.f;
+      const float v = V[pn * Cout + min(c, Cout - 1)];
+      // the point's k weights / key ids: one lane-parallel load each (lane = slot), read back as scalars in the
+      // loop -- loading att[pn*k+j] inside it costs a dependent global round trip per iteration (347 -> ~100 us)
+      float a_l[4];
+      int m_l[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int jj = min(q * 64 + lane, k - 1);
+        a_l[q] = att[pn * k + jj];
+        m_l[q] = (int)kidx[pn * k + jj];
+      }
       float mx = -__builtin_inff(), mn = __builtin_inff();
       int ax = 0, an = 0;
       for (int j = 0; j < k; ++j) {
-        const float a = att[pn * k + j];
-        const int m = (int)kidx[pn * k + j];
-        const float y = a * ((cv ? u_lds[m * Cout + c] : 0.f) - v);
+        float a = 0.f;
+        int m = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if ((j >> 6) == q) { a = readlane_f(a_l[q], j & 63); m = readlane_i(m_l[q], j & 63); }
+        const float y = a * (u_lds[m * Cout + min(c, Cout - 1)] - v);
         if (y > mx) { mx = y; ax = j; }
         if (y < mn) { mn = y; an = j; }
         s1 += y;
@@ -980,10 +993,10 @@ GCN_EXPORT int gcn_keyedge_fwd(const float *att, const int64_t *kidx, const floa
   hipStream_t st = (hipStream_t)stream;
   GCN_HIP(hipMemsetAsync(gsum, 0, sizeof(double) * 2 * B * G, st));
   GCN_HIP(hipFuncSetAttribute((const void *)keyedge_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  int blocks_per_cloud = (512 + B - 1) / B;               // ~2 resident blocks per CU
-  if (blocks_per_cloud > (N + 3) / 4) blocks_per_cloud = (N + 3) / 4;
+  int blocks_per_cloud = (256 + B - 1) / B;               // one 16-wave block per CU (the key table is 61 KB)
+  if (blocks_per_cloud > (N + 15) / 16) blocks_per_cloud = (N + 15) / 16;
   const int ppb = (N + blocks_per_cloud - 1) / blocks_per_cloud;
-  keyedge_fwd_kernel<<<dim3(cdiv(N, ppb), B), 256, lds, st>>>(att, kidx, U, V, N, k, NK, Cout, G, ppb, ymax, ymin, amax, amin, gsum);
+  keyedge_fwd_kernel<<<dim3(cdiv(N, ppb), B), 1024, lds, st>>>(att, kidx, U, V, N, k, NK, Cout, G, ppb, ymax, ymin, amax, amin, gsum);
   return check_launch("keyedge_fwd_kernel");
 }
 
