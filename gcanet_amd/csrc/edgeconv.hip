@@ -708,13 +708,14 @@ __global__ __launch_bounds__(1024) void keyedge_fwd_kernel(const float *__restri
         if (amax) { amax[pn * Cout + c] = (unsigned char)ax; amin[pn * Cout + c] = (unsigned char)an; }
       }
     }
-    if ((cpg % 64) == 0) {  // the 64 channels of this chunk share one group
-      double d1 = (double)s1, d2 = (double)s2;
-#pragma unroll
-      for (int o = 32; o >= 1; o >>= 1) { d1 += __shfl_xor(d1, o); d2 += __shfl_xor(d2, o); }
-      if (lane == 0) {
-        atomicAdd(gsum + ((long)b * G + c0 / cpg) * 2, d1);
-        atomicAdd(gsum + ((long)b * G + c0 / cpg) * 2 + 1, d2);
+    // one f64 atomic pair per GroupNorm group and wave (per-lane same-address f64 atomics serialise)
+    const int seg = (cpg % 64) == 0 ? 64 : cpg;
+    if ((seg & (seg - 1)) == 0 && seg <= 64) {
+      double d1 = cv ? (double)s1 : 0.0, d2 = cv ? (double)s2 : 0.0;
+      for (int o = seg >> 1; o >= 1; o >>= 1) { d1 += __shfl_xor(d1, o); d2 += __shfl_xor(d2, o); }
+      if ((lane & (seg - 1)) == 0 && cv) {
+        atomicAdd(gsum + ((long)b * G + c / cpg) * 2, d1);
+        atomicAdd(gsum + ((long)b * G + c / cpg) * 2 + 1, d2);
       }
     } else if (cv) {
       atomicAdd(gsum + ((long)b * G + c / cpg) * 2, (double)s1);

@@ -277,6 +277,55 @@ class GroupedBlockFunction(torch.autograd.Function):
         return d_ef, dW, dgamma, dbeta, None, None, None, None, None
 
 
+class NormalEdgeBlockFunction(torch.autograd.Function):
+    """The normal-feature EdgeConv block  max_k LeakyReLU(GroupNorm(Conv2d_1x1(get_graph_feature_with_normals_g(x))))
+    (M4:164-205,575-577,691-693) on pts (B,N,6) point-major + idx (B,N,k), with the 7-channel edge feature rebuilt in
+    registers (csrc/normaledge.hip) -- no (B,7,N,k) tensor.  pts is the input cloud: no gradient flows to it."""
+
+    @staticmethod
+    def forward(ctx, pts, idx, weight, gamma, beta, groups, eps, slope, pm_out):
+        _lib.require_cuda(pts, idx)
+        B, N, _ = pts.shape
+        k = idx.shape[2]
+        Cout = weight.shape[0]
+        dev = pts.device
+        pts, idx = pts.float().contiguous(), idx.contiguous()
+        w = weight.float().reshape(Cout, 7).contiguous()
+        f32 = dict(dtype=torch.float32, device=dev)
+        ymax, ymin = torch.empty(B, N, Cout, **f32), torch.empty(B, N, Cout, **f32)
+        amax = torch.empty(B, N, Cout, dtype=torch.uint8, device=dev)
+        amin = torch.empty(B, N, Cout, dtype=torch.uint8, device=dev)
+        gsum = torch.empty(B, groups, 2, dtype=torch.float64, device=dev)
+        _run("gcn_normal_edge_fwd", pts, _lib.ptr(pts), _lib.ptr(idx), _lib.ptr(w), B, N, k, Cout, groups, _lib.ptr(ymax),
+             _lib.ptr(ymin), _lib.ptr(amax), _lib.ptr(amin), _lib.ptr(gsum))
+        ga, be = gamma.float().contiguous(), beta.float().contiguous()
+        out_cm, out_pm, mean_rstd = _finish(ymax, ymin, gsum, ga, be, B, N, k, Cout, groups, eps, slope, not pm_out, pm_out)
+        ctx.save_for_backward(pts, idx, w, ga, be, ymax, ymin, amax, amin, mean_rstd)
+        ctx.cfg = (groups, slope, pm_out, weight.shape)
+        return out_pm if pm_out else out_cm
+
+    @staticmethod
+    def backward(ctx, dout):
+        pts, idx, W, gamma, beta, ymax, ymin, amax, amin, mean_rstd = ctx.saved_tensors
+        G, slope, pm_out, wshape = ctx.cfg
+        B, N, k = idx.shape
+        Cout = W.shape[0]
+        dpm = dout if pm_out else dout.permute(0, 2, 1)
+        jsel, coef, Ac, Bc, dgamma, dbeta, _ = _route_backward_fused(dpm, gamma, beta, ymax, ymin, amax, amin, mean_rstd, G,
+                                                                     slope, float((Cout // G) * N * k), want_jsel=True)
+        f32 = dict(dtype=torch.float32, device=pts.device)
+        dWsp, esum, gram = torch.empty(Cout, 7, **f32), torch.empty(B, 7, **f32), torch.empty(B, 7, 7, **f32)
+        _run("gcn_normal_edge_bwd", pts, _lib.ptr(pts), _lib.ptr(idx), _lib.ptr(coef), _lib.ptr(jsel), B, N, k, Cout,
+             _lib.ptr(dWsp), _lib.ptr(esum), _lib.ptr(gram))
+        dW = dWsp + Ac.t() @ esum + torch.einsum("bo,og,bgf->of", Bc, W, gram)
+        return None, None, dW.reshape(wshape), dgamma, dbeta, None, None, None, None
+
+
+def normal_edge_block(pts, idx, weight, gamma, beta, groups=2, eps=1e-5, slope=0.2, pm_out=False):
+    """pts (B,N,6) [xyz, normal] point-major, idx (B,N,k) -> (B,Cout,N) or (B,N,Cout) with pm_out; f32 arithmetic."""
+    return NormalEdgeBlockFunction.apply(pts, idx, weight, gamma, beta, groups, eps, slope, pm_out)
+
+
 def grouped_block(ef, weight, gamma, beta, groups=2, eps=1e-5, slope=0.2, dtype="bf16", pm_out=False):
     """ef (B,N,k,F) point-major edge features -> (B,Cout,N), or (B,N,Cout) with pm_out."""
     if weight.dim() == 4:
@@ -617,13 +666,17 @@ class PrimitivesEmbeddingDGCNGn(nn.Module):
                                      p[:, :, 11:15], self._unit(p[:, :, 15:18]), p[:, :, 18:22]], dim=2)
         # normal-feature EdgeConv: same input as encoder layer 1 -> same neighbour list (M4:691 recomputes it)
         idx1 = self.encoder.last_idx[0]
-        bi = torch.arange(B, device=pts.device).view(B, 1, 1)
-        n_i = pts[:, :, 3:6].unsqueeze(2)
-        n_j = pts[bi, idx1][..., 3:6]                                                          # (B,N,k,3)
-        angle = (n_i * n_j).sum(-1, keepdim=True).clamp(-0.99, 0.99)
-        ef = torch.cat((angle, n_j - n_i, n_i.expand_as(n_j)), dim=3)                          # (B,N,k,7)
-        normal_feature = grouped_block(ef, self.conv_normal[0].weight, self.bn_normal.weight, self.bn_normal.bias, 2,
-                                       self.bn_normal.eps, 0.2, self.dtype, pm_out=True)       # (B,N,64)
+        if self.mode == 5 and not pts.requires_grad:      # fused: the (B,N,k,7) edge feature is never formed
+            normal_feature = normal_edge_block(pts, idx1, self.conv_normal[0].weight, self.bn_normal.weight,
+                                               self.bn_normal.bias, 2, self.bn_normal.eps, 0.2, pm_out=True)   # (B,N,64)
+        else:
+            bi = torch.arange(B, device=pts.device).view(B, 1, 1)
+            n_i = pts[:, :, 3:6].unsqueeze(2)
+            n_j = pts[bi, idx1][..., 3:6]                                                      # (B,N,k,3)
+            angle = (n_i * n_j).sum(-1, keepdim=True).clamp(-0.99, 0.99)
+            ef = torch.cat((angle, n_j - n_i, n_i.expand_as(n_j)), dim=3)                      # (B,N,k,7)
+            normal_feature = grouped_block(ef, self.conv_normal[0].weight, self.bn_normal.weight, self.bn_normal.bias, 2,
+                                           self.bn_normal.eps, 0.2, self.dtype, pm_out=True)   # (B,N,64)
         x = torch.cat([x_all, x_type, x_para, normal_feature.to(x_all.dtype)], dim=2)          # (B,N,832)
         x = group_norm_relu(conv1x1(x, self.mlp_seg_prob1), self.bn_seg_prob1)
         output_feats = conv1x1(x, self.mlp_seg_prob2).float()                                  # (B,N,emb)

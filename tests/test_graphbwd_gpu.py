@@ -74,3 +74,30 @@ def test_edge_wgrad_rejects_unsupported(dev):
     with pytest.raises(RuntimeError):
         _lib.call("gcn_edge_wgrad", _lib.ptr(t), _lib.ptr(t), _lib.ptr(t), _lib.ptr(t), _lib.ptr(t), _lib.ptr(t), _lib.ptr(t),
                   _lib.ptr(t), 1, 1, 32, 64, _lib.ptr(t), _lib.ptr(t), _lib.stream_of(t))
+
+
+@pytest.mark.parametrize("B,N,k", [(2, 300, 16), (1, 257, 80), (2, 64, 64)])
+def test_normal_edge_block_matches_materialised(dev, B, N, k):
+    """Fused normal-feature EdgeConv (csrc/normaledge.hip) vs the same block on the materialised (B,N,k,7) edge
+    feature of get_graph_feature_with_normals_g (M4:164-205) through torch autograd, f32."""
+    from gcanet_amd import dgcnn
+    g = torch.Generator().manual_seed(N + k)
+    xyz = torch.rand(B, N, 3, generator=g)
+    nrm = torch.nn.functional.normalize(torch.randn(B, N, 3, generator=g), dim=-1)
+    pts = torch.cat([xyz, nrm], -1).to(dev)
+    idx = dgcnn.knn_points_normals(pts.transpose(1, 2).contiguous(), k, k)
+    W = (0.3 * torch.randn(64, 7, 1, 1, generator=g)).to(dev).requires_grad_(True)
+    gn = torch.nn.GroupNorm(2, 64).to(dev)
+    with torch.no_grad():
+        gn.weight.copy_(torch.randn(64, generator=g))          # both signs: max- and min-routed channels
+        gn.bias.copy_(torch.randn(64, generator=g))
+    go = torch.randn(B, N, 64, generator=g).to(dev)
+    out = dgcnn.normal_edge_block(pts, idx, W, gn.weight, gn.bias, 2, gn.eps, 0.2, pm_out=True)
+    g1 = torch.autograd.grad(out, (W, gn.weight, gn.bias), go)
+    ef = dgcnn.get_graph_feature_with_normals_g(pts.transpose(1, 2).contiguous(), k, k, idx)      # (B,7,N,k)
+    y = torch.nn.functional.conv2d(ef, W)
+    y = torch.nn.functional.leaky_relu(gn(y), 0.2).max(dim=-1)[0].permute(0, 2, 1)
+    g2 = torch.autograd.grad(y, (W, gn.weight, gn.bias), go)
+    assert (out - y).abs().max().item() < 1e-4
+    for a, b in zip(g1, g2):
+        assert (a - b).abs().max().item() <= 2e-4 * max(b.abs().max().item(), 1.0)
