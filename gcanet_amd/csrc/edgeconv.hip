@@ -570,7 +570,7 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ x
   if (lane_id() == 0) atomicMax(out, __float_as_uint(m));      // non-negative floats order like their bit patterns
 }
 
-template <typename IdxT>
+template <typename IdxT, bool C64>
 __global__ __launch_bounds__(1024) void reverse_sum_lds_kernel(const float *__restrict__ x, const IdxT *__restrict__ idx,
                                                                const unsigned int *__restrict__ absmax_bits, int B, int N,
                                                                int C, int k, int R, float *__restrict__ r,
@@ -634,9 +634,13 @@ __global__ __launch_bounds__(1024) void reverse_sum_lds_kernel(const float *__re
           const int l = __ffsll((long long)hit) - 1;
           hit &= hit - 1;
           const int mm = readlane_i(mi[i], l);
-          if (lane < C) atomicAdd(&qacc[mm * C + lane], xr[i]);
-          for (int c = lane + 64; c < C; c += 64)
-            atomicAdd(&qacc[mm * C + c], (unsigned long long)__float2ll_rn(xb[(long)(n0 + i) * C + c] * scale));
+          if (C64) {                               // one full-wave add per match, no channel masks
+            atomicAdd(&qacc[mm * 64 + lane], xr[i]);
+          } else {
+            if (lane < C) atomicAdd(&qacc[mm * C + lane], xr[i]);
+            for (int c = lane + 64; c < C; c += 64)
+              atomicAdd(&qacc[mm * C + c], (unsigned long long)__float2ll_rn(xb[(long)(n0 + i) * C + c] * scale));
+          }
           if (lane == 0) atomicAdd(&cnt[mm], 1u);
         }
       }
@@ -973,11 +977,16 @@ GCN_EXPORT int gcn_reverse_sum(const float *x_pm, const int64_t *idx, int B, int
     unsigned short *i16 = reinterpret_cast<unsigned short *>((char *)ws + 16);
     const long E = (long)B * N * k;
     idx_to_u16_kernel<<<cdiv((E + 1) / 2, 256), 256, 0, st>>>(idx, E, i16);
-    GCN_HIP(hipFuncSetAttribute((const void *)reverse_sum_lds_kernel<unsigned short>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    reverse_sum_lds_kernel<unsigned short><<<grid, 1024, lds, st>>>(x_pm, i16, (const unsigned int *)ws, B, N, C, k, R, r, indeg);
+    if (C == 64) {
+      GCN_HIP(hipFuncSetAttribute((const void *)reverse_sum_lds_kernel<unsigned short, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      reverse_sum_lds_kernel<unsigned short, true><<<grid, 1024, lds, st>>>(x_pm, i16, (const unsigned int *)ws, B, N, C, k, R, r, indeg);
+    } else {
+      GCN_HIP(hipFuncSetAttribute((const void *)reverse_sum_lds_kernel<unsigned short, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      reverse_sum_lds_kernel<unsigned short, false><<<grid, 1024, lds, st>>>(x_pm, i16, (const unsigned int *)ws, B, N, C, k, R, r, indeg);
+    }
   } else {
-    GCN_HIP(hipFuncSetAttribute((const void *)reverse_sum_lds_kernel<int64_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    reverse_sum_lds_kernel<int64_t><<<grid, 1024, lds, st>>>(x_pm, idx, (const unsigned int *)ws, B, N, C, k, R, r, indeg);
+    GCN_HIP(hipFuncSetAttribute((const void *)reverse_sum_lds_kernel<int64_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    reverse_sum_lds_kernel<int64_t, false><<<grid, 1024, lds, st>>>(x_pm, idx, (const unsigned int *)ws, B, N, C, k, R, r, indeg);
   }
   return check_launch("reverse_sum_lds_kernel");
 }
