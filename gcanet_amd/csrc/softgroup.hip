@@ -138,6 +138,206 @@ __global__ __launch_bounds__(1024) void scan_counts_kernel(int n, int32_t *__res
   if (tid == 1023) counts[n] = part[1023];
 }
 
+// ---------------------------------------------------------------- ball query on a uniform grid
+// The easy form (no adjacency matrices) at BASELINE config 4 (n = 100 000) is 10^10 pair tests by brute force
+// (11 ms); with cells of edge >= radius only the 27 surrounding cells hold candidates (~75 instead of 100 000).
+//   grid_setup   bounding box -> cell edge (radius * 1.001, coarsened x1.26 until B*dx*dy*dz <= max_cells) and dims,
+//                all on the device: no host round trip
+//   cell_count / scan / cell_fill   counting sort of the points by (batch, z, y, x) cell (x fastest: the three
+//                x-neighbours of a (y,z) row are ONE contiguous range -> 9 ranges per point)
+//   ballquery_grid_kernel<FILL>     wave per point: candidates of the 9 ranges 64 at a time, same distance
+//                expression and comparison as the brute-force kernel; hits are compacted into an LDS buffer and
+//                sorted ascending (the reference's lists are in ascending index order and truncated at `cap` in
+//                that order).  A point whose 27 cells hold more than 1024 candidates takes the brute-force scan.
+// The 1.001 margin keeps |floor| differences of neighbours <= 1 under float rounding (dims <= 1024).
+struct BqGrid {            // lives at the head of the device workspace
+  float minx, miny, minz, inv;
+  int dx, dy, dz, ncell;   // per batch dims; ncell = B*dx*dy*dz
+  unsigned int bmin[3], bmax[3];   // ordered-uint bounding box accumulators
+};
+
+__device__ __forceinline__ unsigned int f2ord(float f) {
+  const unsigned int u = __float_as_uint(f);
+  return u ^ ((unsigned int)((int)u >> 31) | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned int u) {
+  return __uint_as_float(u ^ ((u >> 31) ? 0x80000000u : 0xFFFFFFFFu));
+}
+
+__global__ void bq_bbox_kernel(int n, const float *__restrict__ xyz, BqGrid *g) {
+  float mn[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, mx[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { const float v = xyz[i * 3 + a]; mn[a] = fminf(mn[a], v); mx[a] = fmaxf(mx[a], v); }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { mn[a] = fminf(mn[a], __shfl_xor(mn[a], o)); mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o)); }
+    if (lane_id() == 0) { atomicMin(&g->bmin[a], f2ord(mn[a])); atomicMax(&g->bmax[a], f2ord(mx[a])); }
+  }
+}
+
+__global__ void bq_setup_kernel(BqGrid *g, float radius, int B, int max_cells) {
+  const float mnx = ord2f(g->bmin[0]), mny = ord2f(g->bmin[1]), mnz = ord2f(g->bmin[2]);
+  const float ex = ord2f(g->bmax[0]) - mnx, ey = ord2f(g->bmax[1]) - mny, ez = ord2f(g->bmax[2]) - mnz;
+  float cell = radius * 1.001f;
+  int dx, dy, dz;
+  for (;;) {
+    dx = (int)fminf(ex / cell, 1.0e6f) + 1; dy = (int)fminf(ey / cell, 1.0e6f) + 1; dz = (int)fminf(ez / cell, 1.0e6f) + 1;
+    if (dx <= 1024 && dy <= 1024 && dz <= 1024 && (double)B * dx * dy * dz <= (double)max_cells) break;
+    cell *= 1.26f;
+  }
+  g->minx = mnx; g->miny = mny; g->minz = mnz; g->inv = 1.f / cell;
+  g->dx = dx; g->dy = dy; g->dz = dz; g->ncell = B * dx * dy * dz;
+}
+
+__device__ __forceinline__ void bq_cell_of(const BqGrid *g, float x, float y, float z, int &cx, int &cy, int &cz) {
+  cx = min(max((int)((x - g->minx) * g->inv), 0), g->dx - 1);
+  cy = min(max((int)((y - g->miny) * g->inv), 0), g->dy - 1);
+  cz = min(max((int)((z - g->minz) * g->inv), 0), g->dz - 1);
+}
+
+__global__ void bq_cell_count_kernel(int n, const float *__restrict__ xyz, const int32_t *__restrict__ batch_idxs,
+                                     const BqGrid *__restrict__ g, int32_t *__restrict__ cell_of_pt, int32_t *__restrict__ cell_cnt) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int cx, cy, cz;
+  bq_cell_of(g, xyz[i * 3], xyz[i * 3 + 1], xyz[i * 3 + 2], cx, cy, cz);
+  const int c = ((batch_idxs[i] * g->dz + cz) * g->dy + cy) * g->dx + cx;
+  cell_of_pt[i] = c;
+  atomicAdd(cell_cnt + c, 1);
+}
+
+// exclusive scan of cnt[0..m) in place -> start, cnt[m] = total; m read from the grid header (one workgroup)
+__global__ __launch_bounds__(1024) void bq_cell_scan_kernel(const BqGrid *__restrict__ g, int32_t *__restrict__ cnt,
+                                                            int32_t *__restrict__ cursor) {
+  __shared__ int part[1024];
+  const int m = g->ncell, tid = threadIdx.x;
+  const int chunk = (m + 1023) / 1024;
+  const int lo = min(tid * chunk, m), hi = min(lo + chunk, m);
+  int s = 0;
+  for (int i = lo; i < hi; ++i) s += cnt[i];
+  part[tid] = s;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const int v = tid >= off ? part[tid - off] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int run = part[tid] - s;
+  for (int i = lo; i < hi; ++i) {
+    const int c = cnt[i];
+    cnt[i] = run;
+    cursor[i] = run;
+    run += c;
+  }
+  if (tid == 1023) cnt[m] = part[1023];
+}
+
+__global__ void bq_cell_fill_kernel(int n, const int32_t *__restrict__ cell_of_pt, int32_t *__restrict__ cursor,
+                                    int32_t *__restrict__ sorted) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  sorted[atomicAdd(cursor + cell_of_pt[i], 1)] = i;
+}
+
+// ascending bitonic sort of `m` (<= 1024) ints held in a wave-private LDS buffer padded to a power of two
+__device__ __forceinline__ void bq_sort_lds(int *buf, int m, int lane) {
+  int p2 = 64;
+  while (p2 < m) p2 <<= 1;
+  for (int i = m + lane; i < p2; i += 64) buf[i] = 0x7fffffff;
+  __builtin_amdgcn_wave_barrier();
+  for (int sz = 2; sz <= p2; sz <<= 1)
+    for (int j = sz >> 1; j >= 1; j >>= 1) {
+      for (int t = lane; t < (p2 >> 1); t += 64) {
+        const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
+        const bool asc = (lo & sz) == 0;
+        const int a = buf[lo], c = buf[hi];
+        if ((a > c) == asc) { buf[lo] = c; buf[hi] = a; }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void ballquery_grid_kernel(int n, long thre, float radius2, int cap,
+                                                             const float *__restrict__ xyz,
+                                                             const int32_t *__restrict__ batch_idxs,
+                                                             const int32_t *__restrict__ batch_offsets,
+                                                             const BqGrid *__restrict__ g, const int32_t *__restrict__ cell_start,
+                                                             const int32_t *__restrict__ sorted, int32_t *__restrict__ idx,
+                                                             int32_t *__restrict__ start_len, int32_t *__restrict__ counts) {
+  __shared__ int hits[4][1024];
+  const int lane = lane_id(), wave = wave_id();
+  const int p = blockIdx.x * 4 + wave;
+  if (p >= n) return;
+  const float ox = xyz[p * 3], oy = xyz[p * 3 + 1], oz = xyz[p * 3 + 2];
+  const int bi = batch_idxs[p];
+  long s0 = 0;
+  int limit = cap;
+  if (FILL) {
+    s0 = start_len[p * 2];
+    if (s0 >= thre) return;
+    const int c0 = start_len[p * 2 + 1];
+    limit = (s0 + c0 >= thre) ? (int)(thre - s0) : c0;
+    if (limit <= 0) return;
+  }
+  int cx, cy, cz;
+  bq_cell_of(g, ox, oy, oz, cx, cy, cz);
+  // lanes 0..8: the (dy,dz) rows; each row is the contiguous range of cells x-1..x+1
+  int rlo = 0, rhi = 0;
+  if (lane < 9) {
+    const int yy = cy + lane % 3 - 1, zz = cz + lane / 3 - 1;
+    if (yy >= 0 && yy < g->dy && zz >= 0 && zz < g->dz) {
+      const int rowc = ((bi * g->dz + zz) * g->dy + yy) * g->dx;
+      rlo = cell_start[rowc + max(cx - 1, 0)];
+      rhi = cell_start[rowc + min(cx + 1, g->dx - 1) + 1];
+    }
+  }
+  int tot = rhi - rlo;
+#pragma unroll
+  for (int o = 8; o >= 1; o >>= 1) tot += __shfl_xor(tot, o);        // lanes 0..15 hold the 9-row total
+  tot = readlane_i(tot, 0);
+  int cnt = 0;
+  int *hb = hits[wave];
+  if (tot <= 1024) {
+    for (int rr = 0; rr < 9; ++rr) {
+      const int lo = readlane_i(rlo, rr), hi = readlane_i(rhi, rr);
+      for (int base = lo; base < hi; base += 64) {
+        const int t = base + lane;
+        bool hit = false;
+        int kk = 0;
+        if (t < hi) {
+          kk = sorted[t];
+          hit = sqdist3s(ox, oy, oz, xyz[kk * 3], xyz[kk * 3 + 1], xyz[kk * 3 + 2]) < radius2;
+        }
+        const unsigned long long mask = __ballot(hit);
+        if (FILL && hit) hb[cnt + __popcll(mask & ((1ull << lane) - 1ull))] = kk;
+        cnt += __popcll(mask);
+      }
+    }
+    if (!FILL) { if (lane == 0) counts[p] = cnt < cap ? cnt : cap; return; }
+    __builtin_amdgcn_wave_barrier();
+    bq_sort_lds(hb, cnt, lane);
+    for (int i = lane; i < min(cnt, limit); i += 64) idx[s0 + i] = hb[i];
+    return;
+  }
+  // crowded neighbourhood: the brute-force scan of the batch segment (ascending by construction)
+  const int start = batch_offsets[bi], end = batch_offsets[bi + 1];
+  for (int base = start; base < end && cnt < limit; base += 64) {
+    const int k = base + lane;
+    const bool hit = k < end && sqdist3s(ox, oy, oz, xyz[k * 3], xyz[k * 3 + 1], xyz[k * 3 + 2]) < radius2;
+    const unsigned long long mask = __ballot(hit);
+    if (FILL) {
+      const int slot = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+      if (hit && slot < limit) idx[s0 + slot] = k;
+    }
+    cnt += __popcll(mask);
+  }
+  if (!FILL && lane == 0) counts[p] = cnt < cap ? cnt : cap;
+}
+
 // ---------------------------------------------------------------- segment ops
 // sec_mean.cu:13-85, roipool.cu:12-32.  OP 0 sec_mean (sum of v/count), 1 min, 2 max,
 // 3 global_avg_pool (sum then divide).  Row order is kept sequential per plane -> bit-exact.
@@ -266,11 +466,17 @@ GCN_EXPORT int gcn_voxelize_bp(int M, int maxActive, int C, const float *d_outpu
   return check_launch("voxelize_bp_kernel");
 }
 
+GCN_EXPORT long gcn_ballquery_grid_ws_bytes(int n) {
+  if (n < 0) return -1;
+  const long max_cells = 4L * n + 4096;
+  return 64 + 4 * (2 * max_cells + 1 + 2L * n) + 64;
+}
+
 GCN_EXPORT int gcn_ballquery_batch_p(int n, int meanActive, float radius, const float *xyz,
                                      const int32_t *batch_idxs, const int32_t *batch_offsets,
                                      const float *adj_inst, float thr_inst, const float *adj_para,
                                      float thr_para, int32_t *idx, int32_t *start_len, int32_t *count_ws,
-                                     int *total_host, void *stream) {
+                                     int nbatch, void *grid_ws, int *total_host, void *stream) {
   GCN_REQUIRE(n >= 0 && meanActive >= 0, "gcn_ballquery_batch_p: bad shape");
   GCN_REQUIRE(total_host, "gcn_ballquery_batch_p: total_host is null");
   GCN_REQUIRE((adj_inst == nullptr) == (adj_para == nullptr), "gcn_ballquery_batch_p: adj_inst and adj_para must both be given or both be NULL");
@@ -282,12 +488,34 @@ GCN_EXPORT int gcn_ballquery_batch_p(int n, int meanActive, float radius, const 
   const int cap = adj_inst ? 3000 : 1000;  // bfs_cluster.cu:54 / bfs_cluster_easy.cu:43
   const float r2 = radius * radius;
   const long thre = (long)n * meanActive;
-  ballquery_kernel<false><<<cdiv(n, 4), 256, 0, st>>>(n, thre, r2, cap, xyz, batch_idxs, batch_offsets, adj_inst, thr_inst,
-                                                       adj_para, thr_para, idx, start_len, count_ws);
-  scan_counts_kernel<<<1, 1024, 0, st>>>(n, count_ws, start_len);
-  if (thre > 0)
-    ballquery_kernel<true><<<cdiv(n, 4), 256, 0, st>>>(n, thre, r2, cap, xyz, batch_idxs, batch_offsets, adj_inst, thr_inst,
-                                                        adj_para, thr_para, idx, start_len, count_ws);
+  if (!adj_inst && grid_ws && n >= 2048 && nbatch >= 1 && radius > 0.f) {
+    // uniform-grid path: [BqGrid | cell_cnt/start (max_cells+1) | cursor (max_cells) | cell_of_pt (n) | sorted (n)]
+    const int max_cells = 4 * n + 4096;
+    BqGrid *g = (BqGrid *)grid_ws;
+    int32_t *cell_start = (int32_t *)((char *)grid_ws + 64), *cursor = cell_start + max_cells + 1;
+    int32_t *cell_of_pt = cursor + max_cells, *sorted = cell_of_pt + n;
+    GCN_HIP(hipMemsetAsync(g, 0x00, 64, st));
+    GCN_HIP(hipMemsetAsync(&g->bmin[0], 0xff, 12, st));
+    GCN_HIP(hipMemsetAsync(cell_start, 0, sizeof(int32_t) * (size_t)(max_cells + 1), st));
+    bq_bbox_kernel<<<256, 256, 0, st>>>(n, xyz, g);
+    bq_setup_kernel<<<1, 1, 0, st>>>(g, radius, nbatch, max_cells);
+    bq_cell_count_kernel<<<cdiv(n, 256), 256, 0, st>>>(n, xyz, batch_idxs, g, cell_of_pt, cell_start);
+    bq_cell_scan_kernel<<<1, 1024, 0, st>>>(g, cell_start, cursor);
+    bq_cell_fill_kernel<<<cdiv(n, 256), 256, 0, st>>>(n, cell_of_pt, cursor, sorted);
+    ballquery_grid_kernel<false><<<cdiv(n, 4), 256, 0, st>>>(n, thre, r2, cap, xyz, batch_idxs, batch_offsets, g, cell_start,
+                                                              sorted, idx, start_len, count_ws);
+    scan_counts_kernel<<<1, 1024, 0, st>>>(n, count_ws, start_len);
+    if (thre > 0)
+      ballquery_grid_kernel<true><<<cdiv(n, 4), 256, 0, st>>>(n, thre, r2, cap, xyz, batch_idxs, batch_offsets, g, cell_start,
+                                                               sorted, idx, start_len, count_ws);
+  } else {
+    ballquery_kernel<false><<<cdiv(n, 4), 256, 0, st>>>(n, thre, r2, cap, xyz, batch_idxs, batch_offsets, adj_inst, thr_inst,
+                                                         adj_para, thr_para, idx, start_len, count_ws);
+    scan_counts_kernel<<<1, 1024, 0, st>>>(n, count_ws, start_len);
+    if (thre > 0)
+      ballquery_kernel<true><<<cdiv(n, 4), 256, 0, st>>>(n, thre, r2, cap, xyz, batch_idxs, batch_offsets, adj_inst, thr_inst,
+                                                          adj_para, thr_para, idx, start_len, count_ws);
+  }
   int rc = check_launch("ballquery_kernel");
   if (rc) return rc;
   GCN_HIP(hipMemcpyAsync(total_host, count_ws + n, sizeof(int), hipMemcpyDeviceToHost, st));

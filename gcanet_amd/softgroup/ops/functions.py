@@ -93,6 +93,10 @@ def _ballquery(coords, batch_idxs, batch_offsets, radius, meanActive, adj_inst=N
         assert t.is_contiguous() and t.is_cuda
     dev = coords.device
     count_ws = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    grid_ws = None
+    if adj_inst is None and n >= 2048:       # uniform-grid candidate search (easy form)
+        grid_ws = torch.empty(_lib.lib().gcn_ballquery_grid_ws_bytes(n), dtype=torch.uint8, device=dev)
+    nbatch = int(batch_offsets.numel()) - 1
     total = C.c_int(0)
     while True:  # functions.py:460-474 retry loop, kept verbatim in behaviour
         idx = torch.zeros(n * meanActive, dtype=torch.int32, device=dev)
@@ -100,7 +104,7 @@ def _ballquery(coords, batch_idxs, batch_offsets, radius, meanActive, adj_inst=N
         _run("gcn_ballquery_batch_p", coords, n, int(meanActive), float(radius), _lib.ptr(coords),
              _lib.ptr(batch_idxs), _lib.ptr(batch_offsets), _lib.ptr(adj_inst), float(thr_inst),
              _lib.ptr(adj_para), float(thr_para), _lib.ptr(idx), _lib.ptr(start_len), _lib.ptr(count_ws),
-             C.addressof(total))
+             nbatch, _lib.ptr(grid_ws), C.addressof(total))
         nActive = total.value
         if nActive <= n * meanActive:
             break

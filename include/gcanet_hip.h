@@ -126,12 +126,18 @@ int gcn_voxelize_bp(int M, int maxActive, int C, const float *d_output_feats, fl
  *   idx (n*meanActive) i32 (entries past the truncation point untouched),
  *   start_len (n,2) i32, count_ws (n+1) i32 workspace, total_host: pinned or pageable
  *   HOST int receiving the untruncated total (the call synchronises the stream for it,
- *   as the reference's blocking cudaMemcpy does, bfs_cluster.cu:118). */
+ *   as the reference's blocking cudaMemcpy does, bfs_cluster.cu:118).
+ * With grid_ws (easy form only) candidates come from a uniform grid of cells >= radius built on the device
+ * (counting sort by cell, 27-cell neighbourhood): same lists, ~75 distance tests per point instead of n. */
 int gcn_ballquery_batch_p(int n, int meanActive, float radius, const float *xyz,
                           const int32_t *batch_idxs, const int32_t *batch_offsets,
                           const float *adj_inst, float thr_inst, const float *adj_para,
                           float thr_para, int32_t *idx, int32_t *start_len, int32_t *count_ws,
-                          int *total_host, void *stream);
+                          int nbatch, void *grid_ws, int *total_host, void *stream);
+
+/* Device scratch for the uniform-grid path of gcn_ballquery_batch_p (easy form, n >= 2048): pass it as grid_ws
+ * (NULL selects the brute-force scan).  nbatch = number of batch segments (len(batch_offsets) - 1). */
+long gcn_ballquery_grid_ws_bytes(int n);
 
 /* SG/src/sec_mean/sec_mean.cpp `sec_mean/sec_min/sec_max` (kernels sec_mean.cu:13-85).
  * op 0 mean, 1 min, 2 max.  inp (N,C), offsets (P+1) i32 -> out (P,C). */

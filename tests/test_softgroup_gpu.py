@@ -149,3 +149,42 @@ def test_full_size_softgroup_path_properties(dev):
         assert p in nb and (np.diff(nb) > 0).all()
         q = int(nb[-1])
         assert p in ic[sl_c[q, 0]:sl_c[q, 0] + sl_c[q, 1]]
+
+
+@pytest.mark.parametrize("sizes,radius,mean_active", [((3000, 2500), 0.05, 40), ((4096,), 0.11, 20), ((2048, 1, 700), 0.02, 8),
+                                                      ((5000,), 0.4, 64)])
+def test_ball_query_grid_path_matches_oracle(dev, sizes, radius, mean_active):
+    """n >= 2048 takes the uniform-grid candidate search: same CSR, bit for bit, incl. the truncation at
+    n*meanActive (last case: ~1100 neighbours per point, over the 1000 cap and over the 1024-candidate grid limit)."""
+    rng = np.random.default_rng(sum(sizes) + 1)
+    xyz, bidx, offs = _cloud(rng, sizes)
+    xyz[: sizes[0] // 2] *= np.float32(0.5)                 # uneven density
+    idx, sl = _ops().ball_query_easy(torch.from_numpy(xyz).to(dev), torch.from_numpy(bidx).to(dev),
+                                     torch.from_numpy(offs).to(dev), radius, mean_active)
+    io, slo = oracle.ballquery_batch_p(xyz, bidx, offs, radius, mean_active)
+    np.testing.assert_array_equal(sl.cpu().numpy(), slo)
+    np.testing.assert_array_equal(idx.cpu().numpy(), io)
+
+
+def test_ball_query_grid_equals_bruteforce_full_size(dev):
+    """cfg4 (N = 100 000, radius 0.03): grid path vs the brute-force kernel through the C ABI (grid_ws = NULL)."""
+    import ctypes as C
+    from gcanet_amd import _lib
+    g = torch.Generator().manual_seed(7)
+    N, mean_active = 100000, 32
+    xyz = torch.rand(N, 3, generator=g).to(dev)
+    bidx = torch.cat([torch.zeros(60000), torch.ones(40000)]).to(torch.int32).to(dev)
+    offs = torch.tensor([0, 60000, N], dtype=torch.int32, device=dev)
+    res = []
+    for use_grid in (True, False):
+        idx = torch.zeros(N * mean_active, dtype=torch.int32, device=dev)
+        sl = torch.zeros(N, 2, dtype=torch.int32, device=dev)
+        cw = torch.empty(N + 1, dtype=torch.int32, device=dev)
+        ws = torch.empty(_lib.lib().gcn_ballquery_grid_ws_bytes(N), dtype=torch.uint8, device=dev) if use_grid else None
+        total = C.c_int(0)
+        _lib.call("gcn_ballquery_batch_p", N, mean_active, 0.03, _lib.ptr(xyz), _lib.ptr(bidx), _lib.ptr(offs), None, 0.0,
+                  None, 0.0, _lib.ptr(idx), _lib.ptr(sl), _lib.ptr(cw), 2, _lib.ptr(ws), C.addressof(total),
+                  _lib.stream_of(xyz))
+        res.append((idx[: total.value].clone(), sl.clone(), total.value))
+    assert res[0][2] == res[1][2] and res[0][2] > N
+    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][0], res[1][0])
