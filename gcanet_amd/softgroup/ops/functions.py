@@ -242,8 +242,20 @@ class Voxelization_Idx(Function):
         """functions.py:281-307: coords CPU int64 (N,3|4) -> (output_coords i64 (M,.), input_map i32 (N),
         output_map i32 (M, maxActive+1)), all CPU."""
         assert coords.is_contiguous()
-        assert not coords.is_cuda and coords.dtype == torch.int64
+        assert coords.dtype == torch.int64
         N, ncol = coords.shape
+        if coords.is_cuda:       # device path (extension: the reference only takes CPU tensors here); CUDA tensors out
+            dev = coords.device
+            input_map = torch.empty(N, dtype=torch.int32, device=dev)
+            ws = torch.empty(max(_lib.lib().gcn_voxelize_idx_ws_bytes(N), 64), dtype=torch.uint8, device=dev)
+            M, maxA = C.c_int(0), C.c_int(0)
+            args = (_lib.ptr(coords), N, ncol, int(mode), _lib.ptr(input_map), C.addressof(M), C.addressof(maxA))
+            _run("gcn_voxelize_idx", coords, *args, None, None, _lib.ptr(ws))
+            output_coords = torch.empty(M.value, ncol, dtype=torch.int64, device=dev)
+            output_map = torch.empty(M.value, maxA.value + 1, dtype=torch.int32, device=dev)
+            if N > 0:
+                _run("gcn_voxelize_idx", coords, *args, _lib.ptr(output_coords), _lib.ptr(output_map), _lib.ptr(ws))
+            return output_coords, input_map, output_map
         input_map = torch.zeros(N, dtype=torch.int32)
         M, maxA = C.c_int(0), C.c_int(0)
         args = (_lib.ptr(coords), N, ncol, int(mode), _lib.ptr(input_map), C.addressof(M), C.addressof(maxA))

@@ -167,6 +167,16 @@ int gcn_get_mask_label(int nInstance, int nProposal, float iou_thr, const int32_
                        const int64_t *instance_cls, const float *proposals_iou, float *mask_label,
                        void *stream);
 
+/* `voxelize_idx` (SG/src/voxelize/voxelize.cpp:11-165, a host hash table in the reference) on DEVICE buffers:
+ * sort-based, same numbering (voxels by first appearance, rule rows in input order), every coordinate must lie
+ * in [0, 65535].  Two-call protocol with the same ws (gcn_voxelize_idx_ws_bytes(N) bytes): call 1 with
+ * output_coords == NULL fills input_map (N) and returns M / maxActive through host ints (synchronises the
+ * stream); call 2 fills output_coords (M,ncol) i64 and output_map (M,maxActive+1) i32.  mode as the reference
+ * (0 unique, 1 front, 2 back, 3/4 full rule rows). */
+long gcn_voxelize_idx_ws_bytes(int N);
+int gcn_voxelize_idx(const int64_t *coords, int N, int ncol, int mode, int32_t *input_map, int *M_host,
+                     int *maxActive_host, int64_t *output_coords, int32_t *output_map, void *ws, void *stream);
+
 /* ---- host-side SoftGroup routines (the reference runs these on CPU tensors) ---- */
 
 /* SG/src/voxelize/voxelize.cpp:11-39 `voxelize_idx` (host C++ hash dedup).  HOST pointers.

@@ -188,3 +188,37 @@ def test_ball_query_grid_equals_bruteforce_full_size(dev):
         res.append((idx[: total.value].clone(), sl.clone(), total.value))
     assert res[0][2] == res[1][2] and res[0][2] > N
     assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][0], res[1][0])
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("ncol,N,span", [(4, 5000, 12), (3, 777, 4), (4, 1, 3), (4, 4096, 60000)])
+def test_voxelization_idx_device_matches_oracle(dev, mode, ncol, N, span):
+    """Device voxelize_idx (csrc/voxelize_dev.hip, sort based) vs the oracle's insertion-ordered hash
+    (voxelize.cpp:11-165): identical voxel numbering, rule rows and coordinates for every mode."""
+    rng = np.random.default_rng(N + span + mode)
+    coords = rng.integers(0, span, size=(N, ncol)).astype(np.int64)
+    if ncol == 4:
+        coords[:, 0] = rng.integers(0, 3, size=N)
+    oc, im, om = _ops().voxelization_idx(torch.from_numpy(coords).to(dev), 3, mode)
+    assert oc.is_cuda and im.is_cuda and om.is_cuda
+    oco, imo, omo = oracle.voxelization_idx(coords, 3, mode)
+    np.testing.assert_array_equal(im.cpu().numpy(), imo)
+    np.testing.assert_array_equal(om.cpu().numpy(), omo)
+    np.testing.assert_array_equal(oc.cpu().numpy(), oco)
+
+
+def test_voxelization_idx_device_full_size_equals_host(dev):
+    ops = _ops()
+    g = torch.Generator().manual_seed(99)
+    N = 100000
+    coords = torch.cat([torch.randint(0, 2, (N, 1), generator=g), (torch.rand(N, 3, generator=g) * 128).floor().long()], 1)
+    h = ops.voxelization_idx(coords, 2, 4)
+    d = ops.voxelization_idx(coords.to(dev), 2, 4)
+    for a, b in zip(h, d):
+        assert torch.equal(a, b.cpu())
+
+
+def test_voxelization_idx_device_rejects_out_of_range(dev):
+    coords = torch.tensor([[0, 1, 2, 70000]], dtype=torch.int64, device=dev)
+    with pytest.raises(RuntimeError):
+        _ops().voxelization_idx(coords, 1, 4)

@@ -91,7 +91,9 @@ def bench_softgroup():
     omd = om.to(dev)
     ms = timeit(lambda: ops.voxelization(feats, omd, 4))
     byt = 4 * N * 64 + 4 * om.numel() + 4 * om.shape[0] * 64
-    print("voxelization_idx (host, N=100k): %.1f ms ; voxelization fwd: %.3f ms %.0f GB/s" % (t_vi, ms, byt / ms / 1e6))
+    cd = coords.to(dev)
+    ms_vd = timeit(lambda: ops.voxelization_idx(cd, 1, 4), n=5, warm=2)
+    print("voxelization_idx N=100k: host %.1f ms, device %.3f ms ; voxelization fwd: %.3f ms %.0f GB/s" % (t_vi, ms_vd, ms, byt / ms / 1e6))
     xd = xyz.to(dev)
     bidx = torch.zeros(N, dtype=torch.int32, device=dev)
     offs = torch.tensor([0, N], dtype=torch.int32, device=dev)
