@@ -118,6 +118,70 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const void *__restrict__ 
   }
 }
 
+// apply + max over the points of each sample: out[b,c] = max_n ReLU(GN(x))[b,n,c] and its arg-max row, without
+// writing the (B,N,C) activation (M4:510-513: the 1024-channel global feature is only ever used through its max).
+// Thread = 4 channels of a row slab (as the backward reduction); best (value, lowest row) per channel goes to a
+// u64 atomicMax (value bits << 32 | ~row) -- values are >= 0 after ReLU, or order-mapped when relu == 0.
+template <bool BF16>
+__global__ __launch_bounds__(256) void gn_apply_max_kernel(const void *__restrict__ x, const double *__restrict__ gsum,
+                                                           const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                           int N, int C, int G, float eps, int relu, int rows_per_block,
+                                                           unsigned long long *__restrict__ best,
+                                                           float *__restrict__ mean_rstd) {
+  const int b = blockIdx.y;
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, N);
+  const Slab s = make_slab(C);
+  const int cpg = C / G;
+  const double cnt = (double)cpg * N;
+  for (int rep = 0; rep < s.reps; ++rep) {
+    const int c = s.c4 + rep * 1024;
+    const int g = c / cpg;
+    const double m = gsum[((long)b * G + g) * 2] / cnt;
+    double var = gsum[((long)b * G + g) * 2 + 1] / cnt - m * m;
+    if (var < 0.0) var = 0.0;
+    const float mean = (float)m, rstd = (float)(1.0 / sqrt(var + (double)eps));
+    if (mean_rstd && blockIdx.x == 0 && s.row0 == 0 && (c % cpg) == 0) {
+      mean_rstd[((long)b * G + g) * 2] = mean;
+      mean_rstd[((long)b * G + g) * 2 + 1] = rstd;
+    }
+    const float4 ga = *reinterpret_cast<const float4 *>(gamma + c);
+    const float4 be = *reinterpret_cast<const float4 *>(beta + c);
+    const float gg[4] = {ga.x, ga.y, ga.z, ga.w}, bb[4] = {be.x, be.y, be.z, be.w};
+    float bv[4] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    int br[4] = {0, 0, 0, 0};
+    for (int r = r0 + s.row0; r < r1; r += s.rstep) {
+      float v[4];
+      load4<BF16>(x, ((long)b * N + r) * C + c, v);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float z = (v[i] - mean) * rstd * gg[i] + bb[i];
+        z = (relu && !(z > 0.f)) ? 0.f : z;
+        if (BF16) z = bf2f(f2bf(z));                    // the value the (B,N,C) bf16 tensor would have held
+        if (z > bv[i]) { bv[i] = z; br[i] = r; }
+      }
+    }
+    if (r0 + s.row0 < r1) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        unsigned int u = __float_as_uint(bv[i] + 0.0f);
+        u ^= ((unsigned int)((int)u >> 31) | 0x80000000u);          // order-preserving for any sign
+        atomicMax(best + (long)b * C + c + i, ((unsigned long long)u << 32) | (unsigned int)(0xFFFFFFFFu - (unsigned)br[i]));
+      }
+    }
+  }
+}
+
+__global__ void gn_max_unpack_kernel(const unsigned long long *__restrict__ best, long n, float *__restrict__ vals,
+                                     int64_t *__restrict__ arg) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long k = best[i];
+  unsigned int u = (unsigned int)(k >> 32);
+  u ^= ((u >> 31) ? 0x80000000u : 0xFFFFFFFFu);
+  vals[i] = __uint_as_float(u);
+  arg[i] = (int64_t)(0xFFFFFFFFu - (unsigned int)k);
+}
+
 // backward pass 1: S (B,G,2) = [sum gamma*g, sum gamma*g*xhat], dgamma/dbeta (C) (accumulated, pre-zeroed)
 template <bool BF16>
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const void *__restrict__ dy, const void *__restrict__ x,
@@ -276,4 +340,28 @@ GCN_EXPORT int gcn_gn_bwd(const void *dy, const void *x, int dtype, const float 
     gn_bwd_apply_kernel<false><<<dim3(g2, B), 256, 0, st>>>(dy, x, gamma, beta, mean_rstd, s_ws, N, C, G, relu, dx);
   }
   return check_launch("gn_bwd");
+}
+
+GCN_EXPORT int gcn_gn_max_fwd(const void *x, int dtype, const float *gamma, const float *beta, int B, int N, int C, int G,
+                              float eps, int relu, float *out_max, int64_t *out_arg, float *mean_rstd, double *gsum_ws,
+                              void *best_ws, void *stream) {
+  int rc = gn_check("gcn_gn_max_fwd", B, N, C, G, dtype);
+  if (rc) return rc;
+  GCN_REQUIRE(x && gamma && beta && out_max && out_arg && gsum_ws && best_ws, "gcn_gn_max_fwd: null pointer");
+  if (B == 0) return GCN_OK;
+  hipStream_t st = (hipStream_t)stream;
+  GCN_HIP(hipMemsetAsync(gsum_ws, 0, sizeof(double) * 2 * B * G, st));
+  GCN_HIP(hipMemsetAsync(best_ws, 0, sizeof(unsigned long long) * (size_t)B * C, st));
+  const int rows = slab_rows(N, B);
+  const dim3 g1(cdiv(N, rows), B);
+  unsigned long long *best = (unsigned long long *)best_ws;
+  if (dtype == 1) {
+    gn_stats_kernel<true><<<g1, 256, sizeof(double) * 2 * G, st>>>(x, N, C, G, rows, gsum_ws);
+    gn_apply_max_kernel<true><<<g1, 256, 0, st>>>(x, gsum_ws, gamma, beta, N, C, G, eps, relu, rows, best, mean_rstd);
+  } else {
+    gn_stats_kernel<false><<<g1, 256, sizeof(double) * 2 * G, st>>>(x, N, C, G, rows, gsum_ws);
+    gn_apply_max_kernel<false><<<g1, 256, 0, st>>>(x, gsum_ws, gamma, beta, N, C, G, eps, relu, rows, best, mean_rstd);
+  }
+  gn_max_unpack_kernel<<<cdiv((long)B * C, 256), 256, 0, st>>>(best, (long)B * C, out_max, out_arg);
+  return check_launch("gn_max_fwd");
 }

@@ -510,7 +510,7 @@ class DGCNNEncoderGn(nn.Module):
     def forward_pm(self, x_cm, x_pm=None):
         """Point-major core: x_cm (B,Cin,N) feeds the kNN, x_pm (B,N,Cin) the row gathers.
         Returns (x_features (B,N,256) f32, x4 (B,1024))."""
-        from .layers import conv1x1, global_max_pool, group_norm_relu
+        from .layers import conv1x1, group_norm_relu_max
         k = self.k
         if x_pm is None:
             x_pm = x_cm.transpose(1, 2).contiguous()
@@ -522,8 +522,8 @@ class DGCNNEncoderGn(nn.Module):
         x3, _ = edge_conv_pm(x2, idx3, self.conv3._modules["0"].weight, self.bn3, self.dtype, want_cm=False)
         self.last_idx = (idx1, idx2, idx3)
         x_features = torch.cat((x1, x2, x3), dim=2)                            # (B,N,256)
-        h = group_norm_relu(conv1x1(x_features, self.mlp1), self.bnmlp1)      # (B,N,1024)
-        return x_features, global_max_pool(h)
+        x4 = group_norm_relu_max(conv1x1(x_features, self.mlp1), self.bnmlp1)  # (B,1024); (B,N,1024) never written
+        return x_features, x4
 
     def forward(self, x):
         """Reference signature: x (B,Cin,N) -> (B,1280,N)  (M4:492-534)."""

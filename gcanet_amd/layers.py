@@ -119,3 +119,48 @@ class GlobalMaxPoolFunction(torch.autograd.Function):
 
 def global_max_pool(x):
     return GlobalMaxPoolFunction.apply(x)
+
+
+class GroupNormReLUMaxFunction(torch.autograd.Function):
+    """max over points of [ReLU](GroupNorm(x)) for x (B,N,C) -> (B,C), the (B,N,C) activation never written
+    (csrc/gn.hip: gn_apply_max_kernel).  Backward routes the gradient to the arg-max rows and runs the ordinary
+    GroupNorm backward on that (B,N,C) gradient."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, groups, eps, relu):
+        _lib.require_cuda(x)
+        assert x.dim() == 3 and x.dtype in (torch.float32, torch.bfloat16)
+        x = x.contiguous()
+        B, N, C = x.shape
+        dt = 1 if x.dtype == torch.bfloat16 else 0
+        ga, be = gamma.float().contiguous(), beta.float().contiguous()
+        vals = torch.empty(B, C, dtype=torch.float32, device=x.device)
+        arg = torch.empty(B, C, dtype=torch.int64, device=x.device)
+        mean_rstd = torch.empty(B, groups, 2, dtype=torch.float32, device=x.device)
+        ws = torch.empty(B, groups, 2, dtype=torch.float64, device=x.device)
+        best = torch.empty(B, C, dtype=torch.int64, device=x.device)
+        _run("gcn_gn_max_fwd", x, _lib.ptr(x), dt, _lib.ptr(ga), _lib.ptr(be), B, N, C, groups, float(eps), int(relu),
+             _lib.ptr(vals), _lib.ptr(arg), _lib.ptr(mean_rstd), _lib.ptr(ws), _lib.ptr(best))
+        ctx.save_for_backward(x, ga, be, mean_rstd, arg)
+        ctx.cfg = (groups, relu, dt)
+        return vals.to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, ga, be, mean_rstd, arg = ctx.saved_tensors
+        groups, relu, dt = ctx.cfg
+        B, N, C = x.shape
+        dy = torch.zeros(B, N, C, dtype=x.dtype, device=x.device)
+        dy.scatter_(1, arg.unsqueeze(1), dout.to(x.dtype).unsqueeze(1))
+        dx = torch.empty_like(x)
+        dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+        ws = torch.empty(B, groups, 2, dtype=torch.float64, device=x.device)
+        _run("gcn_gn_bwd", x, _lib.ptr(dy), _lib.ptr(x), dt, _lib.ptr(ga), _lib.ptr(be), _lib.ptr(mean_rstd), B, N, C,
+             groups, int(relu), _lib.ptr(dx), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ws))
+        return dx, dgamma, dbeta, None, None, None
+
+
+def group_norm_relu_max(x, gn, relu=True):
+    """max over dim 1 of group_norm_relu(x, gn): (B,N,C) -> (B,C)."""
+    return GroupNormReLUMaxFunction.apply(x, gn.weight, gn.bias, gn.num_groups, gn.eps, relu)

@@ -342,6 +342,14 @@ int gcn_gn_bwd(const void *dy, const void *x, int dtype, const float *gamma, con
                const float *mean_rstd, int B, int N, int C, int G, int relu, void *dx, float *dgamma,
                float *dbeta, double *s_ws, void *stream);
 
+/* GroupNorm(+ReLU) followed by the max over the points of each sample (M4:510-513: the 1024-channel global
+ * feature), without writing the (B,N,C) activation: out_max (B,C) f32, out_arg (B,C) int64 = the row of the
+ * maximum (lowest row on ties); mean_rstd as gcn_gn_fwd; gsum_ws (B,G,2) f64 and best_ws (B,C) u64 scratch.
+ * With dtype 1 the maxima are rounded to bf16 exactly as the materialised tensor would have been. */
+int gcn_gn_max_fwd(const void *x, int dtype, const float *gamma, const float *beta, int B, int N, int C, int G,
+                   float eps, int relu, float *out_max, int64_t *out_arg, float *mean_rstd, double *gsum_ws,
+                   void *best_ws, void *stream);
+
 /* ------------------------------------------------------------- attention stacks ------ */
 
 /* Fused scaled-dot-product attention forward (online softmax; the (Lq x Lk) score matrix never

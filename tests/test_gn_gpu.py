@@ -31,3 +31,27 @@ def test_group_norm_relu_fwd_bwd(dev, B, N, C, G, relu, dtype):
         t2 = dict(rtol=1e-3, atol=1e-4 * max(1.0, np.abs(r).max())) if dtype == torch.float32 else \
             dict(rtol=5e-2, atol=2e-2 * max(1.0, np.abs(r).max()))
         np.testing.assert_allclose(a.grad.float().cpu().numpy(), r, err_msg=name, **t2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,N,C,G", [(2, 300, 64, 2), (3, 1000, 1024, 8), (1, 17, 256, 4)])
+def test_group_norm_relu_max_matches_two_step(dev, dtype, B, N, C, G):
+    """Fused GN+ReLU+max-over-points equals group_norm_relu followed by max(dim=1), values and gradients."""
+    from gcanet_amd import layers
+    g = torch.Generator().manual_seed(B * N + C)
+    x = torch.randn(B, N, C, generator=g).to(dev).to(dtype)
+    gn = torch.nn.GroupNorm(G, C).to(dev)
+    with torch.no_grad():
+        gn.weight.copy_(torch.randn(C, generator=g))
+        gn.bias.copy_(torch.randn(C, generator=g))
+    go = torch.randn(B, C, generator=g).to(dev).to(dtype)
+    xa = x.clone().requires_grad_(True)
+    a = layers.group_norm_relu_max(xa, gn)
+    ga = torch.autograd.grad(a, (xa, gn.weight, gn.bias), go)
+    xb = x.clone().requires_grad_(True)
+    b = layers.group_norm_relu(xb, gn).max(dim=1)[0]
+    gb = torch.autograd.grad(b, (xb, gn.weight, gn.bias), go)
+    assert torch.equal(a, b)
+    tol = 2e-2 if dtype == torch.bfloat16 else 1e-4
+    for u, v in zip(ga, gb):
+        assert (u.float() - v.float()).abs().max().item() <= tol * max(v.float().abs().max().item(), 1.0)
