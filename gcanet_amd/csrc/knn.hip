@@ -503,6 +503,46 @@ static int launch_knn_mfma16(const float *x, const float *xx, int B, int N, int 
   return check_launch("knn_mfma16_kernel");
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Row-wise top-k (largest, sorted descending) of short rows (NK <= 128, k <= 64): the `torch.topk(dist, 30)` over
+// the 120 key-point similarities of every point in OFFSET_PRED_MODULE (M4:421-422; torch's radix-select kernel
+// takes 0.42 ms at B*N = 65536).  One wave per row: lane l holds columns l and l+64 as u64 keys (order-preserving
+// value bits << 32 | ~column, so ties go to the LOWER column), two 64-wide bitonic sorts + one bitonic merge.
+template <bool BF16>
+__global__ __launch_bounds__(256) void topk_rows_kernel(const void *__restrict__ x, long R, int NK, int k,
+                                                        float *__restrict__ vals, int64_t *__restrict__ idx) {
+  const int lane = lane_id();
+  const long row = (long)blockIdx.x * 4 + wave_id();
+  if (row >= R) return;
+  auto load = [&](int c) -> u64 {
+    if (c >= NK) return 0ull;
+    float v;
+    if (BF16) v = __uint_as_float(((unsigned int)reinterpret_cast<const unsigned short *>(x)[row * NK + c]) << 16);
+    else v = reinterpret_cast<const float *>(x)[row * NK + c];
+    return ((u64)key_f2u(v) << 32) | (unsigned int)(0xFFFFFFFFu - (unsigned)c);
+  };
+  u64 a = load(lane), b = load(lane + 64);
+  // descending sorts == ascending sorts of the complemented keys
+  a = ~a; b = ~b;
+#pragma unroll
+  for (int sz = 2; sz <= 64; sz <<= 1)
+#pragma unroll
+    for (int j = sz >> 1; j >= 1; j >>= 1) {
+      a = TopB::cex(a, lane, j, (lane & sz) == 0);
+      b = TopB::cex(b, lane, j, (lane & sz) == 0);
+    }
+  const u64 br = shfl_u64(b, 63 - lane);
+  u64 m = br < a ? br : a;                     // the 64 smallest complemented keys, bitonic
+#pragma unroll
+  for (int j = 32; j >= 1; j >>= 1) m = TopB::cex(m, lane, j, true);
+  m = ~m;
+  if (lane < k) {
+    vals[row * k + lane] = key_u2f((unsigned int)(m >> 32));
+    idx[row * k + lane] = (int64_t)(0xFFFFFFFFu - (unsigned int)m);
+  }
+}
+
 }  // namespace gcn
 
 using namespace gcn;
@@ -561,4 +601,15 @@ GCN_EXPORT int gcn_knn_model(const float *x, int B, int C, int N, int k1, int k2
     if (C == 128) return launch_knn_mfma16<128, 32>(x, xx_ws, B, N, k2, step, kout, idx, val, st);
   }
   return launch_knn<1, 0>(a, B, st);
+}
+
+GCN_EXPORT int gcn_topk_rows(const void *x, int dtype, long R, int NK, int k, float *vals, int64_t *idx, void *stream) {
+  GCN_REQUIRE(x && vals && idx, "gcn_topk_rows: null pointer");
+  GCN_REQUIRE(dtype == 0 || dtype == 1, "gcn_topk_rows: dtype must be 0 (f32) or 1 (bf16)");
+  GCN_REQUIRE(R >= 0 && NK >= 1 && NK <= 128 && k >= 1 && k <= 64 && k <= NK, "gcn_topk_rows: need NK <= 128, k <= min(64, NK)");
+  if (R == 0) return GCN_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == 1) topk_rows_kernel<true><<<cdiv(R, 4), 256, 0, st>>>(x, R, NK, k, vals, idx);
+  else topk_rows_kernel<false><<<cdiv(R, 4), 256, 0, st>>>(x, R, NK, k, vals, idx);
+  return check_launch("topk_rows_kernel");
 }

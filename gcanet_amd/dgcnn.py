@@ -539,6 +539,42 @@ def cos_dist(instance_feature, global_instance_feature):
     return -(1 - torch.einsum("bnc,bkc->bnk", a, b))
 
 
+class TopKRowsFunction(torch.autograd.Function):
+    """torch.topk(x, k, dim=-1, largest=True) for short last dimensions (<= 128) through csrc/knn.hip:topk_rows_kernel;
+    gradient = scatter of the value gradients, as torch's."""
+
+    @staticmethod
+    def forward(ctx, x, k):
+        _lib.require_cuda(x)
+        shp = x.shape
+        NK = shp[-1]
+        xc = x.contiguous()
+        if xc.dtype not in (torch.float32, torch.bfloat16):
+            xc = xc.float()
+        R = xc.numel() // NK
+        vals = torch.empty(R, k, dtype=torch.float32, device=x.device)
+        idx = torch.empty(R, k, dtype=torch.int64, device=x.device)
+        _run("gcn_topk_rows", xc, _lib.ptr(xc), 1 if xc.dtype == torch.bfloat16 else 0, R, NK, k, _lib.ptr(vals), _lib.ptr(idx))
+        idx = idx.view(*shp[:-1], k)
+        ctx.save_for_backward(idx)
+        ctx.shape = shp
+        ctx.mark_non_differentiable(idx)
+        return vals.view(*shp[:-1], k).to(x.dtype), idx
+
+    @staticmethod
+    def backward(ctx, dvals, _):
+        (idx,) = ctx.saved_tensors
+        g = torch.zeros(ctx.shape, dtype=dvals.dtype, device=dvals.device)
+        g.scatter_(-1, idx, dvals)
+        return g, None
+
+
+def topk_rows(x, k):
+    if x.is_cuda and x.shape[-1] <= 128 and k <= 64:
+        return TopKRowsFunction.apply(x, k)
+    return torch.topk(x, k, dim=-1, largest=True)
+
+
 class KPAM(nn.Module):
     """M4:351-373 (softmax over the k axis -- see oracle/ref_model.py:kpam)."""
 
@@ -594,7 +630,7 @@ class OFFSET_PRED_MODULE(nn.Module):
         sub = key_point_indices(N, self.sampling_ratio, points.device)
         key_pts, key_feat, key_emb = points[:, sub], feature[:, sub], instance_feature[:, sub]
         dist = cos_dist(instance_feature, key_emb)                             # (B,N,120)
-        topk_dist, topk_idx = torch.topk(dist, self.k, dim=2, largest=True)    # once, not twice (M4:421-422)
+        topk_dist, topk_idx = topk_rows(dist, self.k)                          # once, not twice (M4:421-422)
         att = self.attention.weights(topk_dist)                                # (B,N,k)
         W = self.conv1[0].weight[:, :, 0, 0]                                   # (128,131)
         Wf, Wp = W[:, :128], W[:, 128:]

@@ -295,6 +295,11 @@ int gcn_normal_edge_fwd(const float *pts, const int64_t *idx, const float *W, in
 int gcn_normal_edge_bwd(const float *pts, const int64_t *idx, const float *coef, const int64_t *jsel, int B,
                         int N, int k, int Cout, float *dWsp, float *esum, float *gram, void *stream);
 
+/* Row-wise top-k, largest first, of R short rows: x (R,NK) f32 (dtype 0) or bf16 (dtype 1), NK <= 128,
+ * k <= min(64, NK) -> vals (R,k) f32, idx (R,k) int64; ties go to the lower column.  Replaces the
+ * `torch.topk(dist, k)` over the key-point similarities of OFFSET_PRED_MODULE (M4:421-422). */
+int gcn_topk_rows(const void *x, int dtype, long R, int NK, int k, float *vals, int64_t *idx, void *stream);
+
 /* ------------------------- fused pieces of the closed-form grouped-block backward ------ */
 
 /* One pass over (B,N,Cout): selected extreme (max for gamma >= 0, else min) -> yhat, z, routed

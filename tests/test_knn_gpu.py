@@ -149,3 +149,30 @@ def test_search_knn_known_answer_on_gpu(dev):
     sp._temperature.data = torch.tensor(0.1, device=dev)      # sigma := 0.1**2 (search_knn.py:279)
     proj = sp.project(qc, pc)[0].t().detach().cpu().numpy()
     np.testing.assert_allclose(proj, np.asarray(ka["expected_nn_cloud"]), atol=1.5e-3)
+
+
+@pytest.mark.parametrize("shape,k", [((3, 500, 120), 30), ((1000, 128), 64), ((7, 5), 3), ((2, 33, 64), 1)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_topk_rows_matches_torch(dev, shape, k, dtype):
+    """csrc/knn.hip:topk_rows_kernel vs torch.topk: identical sorted values; indices identical where values are
+    distinct, and always consistent (x[idx] == values, no duplicates); ties resolve to the lower column."""
+    from gcanet_amd import dgcnn
+    g = torch.Generator().manual_seed(sum(shape) + k)
+    x = torch.randn(*shape, generator=g).to(dev).to(dtype)          # bf16: plenty of exact ties
+    x.requires_grad_(True)
+    v, i = dgcnn.topk_rows(x, k)
+    tv, ti = torch.topk(x.detach(), k, dim=-1, largest=True)
+    assert v.dtype == x.dtype and i.dtype == torch.int64
+    assert torch.equal(v.detach(), tv)
+    assert torch.equal(torch.gather(x.detach(), -1, i), tv)
+    si = i.sort(-1)[0]
+    assert (si[..., 1:] != si[..., :-1]).all()
+    if dtype == torch.float32:
+        assert torch.equal(i, ti)
+    # ties: among equal values the lower column comes first
+    same = v.detach()[..., 1:] == v.detach()[..., :-1]
+    assert (i[..., 1:][same] > i[..., :-1][same]).all()
+    go = torch.randn(*v.shape, generator=g).to(dev).to(dtype)
+    (gx,) = torch.autograd.grad(v, x, go)
+    ref = torch.zeros_like(x).scatter_(-1, i, go)
+    assert torch.equal(gx, ref)
