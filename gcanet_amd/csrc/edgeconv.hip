@@ -605,7 +605,7 @@ __global__ __launch_bounds__(1024) void reverse_sum_lds_kernel(const float *__re
   int mraw_n[4];
   auto fetch = [&](int n0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) xf_n[i] = xb[(long)min(n0 + i, N - 1) * C + min(lane, C - 1)];
+    for (int i = 0; i < 4; ++i) xf_n[i] = C > 0 ? xb[(long)min(n0 + i, N - 1) * C + min(lane, C - 1)] : 0.f;   // C == 0: count only
 #pragma unroll
     for (int i = 0; i < 4; ++i) mraw_n[i] = (int)ib[(long)min(n0 + i, N - 1) * k + min(lane, k - 1)];
   };
@@ -648,8 +648,10 @@ __global__ __launch_bounds__(1024) void reverse_sum_lds_kernel(const float *__re
   }
   __syncthreads();
   const int rows = min(R, N - m0);
-  float *rb = r + ((long)b * N + m0) * C;
-  for (int i = threadIdx.x; i < rows * C; i += 1024) rb[i] = (float)((double)(long long)qacc[i] * inv);
+  if (C > 0) {
+    float *rb = r + ((long)b * N + m0) * C;
+    for (int i = threadIdx.x; i < rows * C; i += 1024) rb[i] = (float)((double)(long long)qacc[i] * inv);
+  }
   if (indeg)
     for (int i = threadIdx.x; i < rows; i += 1024) indeg[(long)b * N + m0 + i] = (float)cnt[i];
 }
@@ -958,14 +960,15 @@ GCN_EXPORT long gcn_reverse_sum_ws_bytes(int B, int N, int k) {
 
 GCN_EXPORT int gcn_reverse_sum(const float *x_pm, const int64_t *idx, int B, int N, int C, int k, float *r, float *indeg,
                                void *ws, void *stream) {
-  GCN_REQUIRE(x_pm && idx && r && ws, "gcn_reverse_sum: null pointer");
+  GCN_REQUIRE(x_pm && idx && ws && (r || indeg), "gcn_reverse_sum: null pointer");
   GCN_REQUIRE(B >= 0 && N >= 1 && C >= 1 && k >= 1, "gcn_reverse_sum: bad shape");
+  if (!r) C = 0;                                   // in-degrees only: no rows are read or accumulated
   GCN_REQUIRE(C <= 2048, "gcn_reverse_sum: C=%d too wide for one LDS row block", C);
   GCN_REQUIRE(((uintptr_t)ws & 15) == 0 && ((uintptr_t)idx & 15) == 0, "gcn_reverse_sum: ws/idx must be 16-B aligned");
   if (B == 0) return GCN_OK;
   hipStream_t st = (hipStream_t)stream;
   GCN_HIP(hipMemsetAsync(ws, 0, 4, st));
-  absmax_kernel<<<512, 256, 0, st>>>(x_pm, (long)B * N * C, (unsigned int *)ws);
+  if (C > 0) absmax_kernel<<<512, 256, 0, st>>>(x_pm, (long)B * N * C, (unsigned int *)ws);
   // destination rows per workgroup: ~256 workgroups in total, bounded by 128 KB of LDS
   int R = (int)(((long)N * B + 255) / 256);
   const int rmax = (128 * 1024) / (8 * C + 4);

@@ -126,8 +126,10 @@ def _ts2(a, b):
     return tall_skinny_tn(a, b)
 
 
-def _edgeconv_backward(saved, cfg, dout, pm):
-    """Closed-form EdgeConv backward; dout (B,Cout,N) (pm=False) or (B,N,Cout) (pm=True) -> dx (B,N,C), dW, dgamma, dbeta."""
+def _edgeconv_backward(saved, cfg, dout, pm, need_dx=True):
+    """Closed-form EdgeConv backward; dout (B,Cout,N) (pm=False) or (B,N,Cout) (pm=True) -> dx (B,N,C), dW, dgamma, dbeta.
+    need_dx=False (first layer: the cloud itself carries no gradient) skips the transposed aggregation r = Adj^T.x and
+    the GEMMs that only feed dx."""
     if True:
         x, idx, W, gamma, beta, ymax, ymin, amax, amin, mean_rstd = saved
         G, slope = cfg
@@ -141,16 +143,21 @@ def _edgeconv_backward(saved, cfg, dout, pm):
                                                                     G, slope, Mg, idx=idx, want_dsp=True)
         # graph aggregations: s = Adj.x (gather), r = Adj^T.x and the in-degree (destination-partitioned LDS scatter)
         s = torch.empty_like(x)
-        r = torch.empty_like(x)
+        r = torch.empty_like(x) if need_dx else None
         indeg = torch.empty(B, N, dtype=torch.float32, device=x.device)
         _run("gcn_neighbor_sum", x, _lib.ptr(x), _lib.ptr(idx), B, N, C, k, _lib.ptr(s))
         ws4 = torch.empty(_lib.lib().gcn_reverse_sum_ws_bytes(B, N, k), dtype=torch.uint8, device=x.device)
         _run("gcn_reverse_sum", x, _lib.ptr(x), _lib.ptr(idx), B, N, C, k, _lib.ptr(r), _lib.ptr(indeg), _lib.ptr(ws4))
-        P1, SW, XW, RW = x @ W1.t(), s @ W1.t(), x @ Wd.t(), r @ Wd.t()        # (B,N,Cout) each
-        D1, D2 = torch.empty_like(coef), torch.empty_like(coef)
-        _run("gcn_edge_combine", x, _lib.ptr(coef), _lib.ptr(Dsp), _lib.ptr(indeg), _lib.ptr(Ac), _lib.ptr(Bc), _lib.ptr(P1),
-             _lib.ptr(SW), _lib.ptr(XW), _lib.ptr(RW), B, N, k, Cout, _lib.ptr(D1), _lib.ptr(D2))
-        dx_pm = D1 @ W1 + D2 @ Wd                                      # (B,N,C)
+        SW, XW = s @ W1.t(), x @ Wd.t()                                  # (B,N,Cout) each
+        if need_dx:
+            P1, RW = x @ W1.t(), r @ Wd.t()
+            D1, D2 = torch.empty_like(coef), torch.empty_like(coef)
+            _run("gcn_edge_combine", x, _lib.ptr(coef), _lib.ptr(Dsp), _lib.ptr(indeg), _lib.ptr(Ac), _lib.ptr(Bc),
+                 _lib.ptr(P1), _lib.ptr(SW), _lib.ptr(XW), _lib.ptr(RW), B, N, k, Cout, _lib.ptr(D1), _lib.ptr(D2))
+            dx_pm = D1 @ W1 + D2 @ Wd                                  # (B,N,C)
+        else:
+            D2 = coef + Ac.unsqueeze(1) * float(k) + Bc.unsqueeze(1) * (SW + float(k) * XW)
+            dx_pm = None
         # weight gradients
         if (C <= 16 or C == 64) and Cout in (64, 128):                 # all row reductions in one MFMA pass
             dW = torch.empty(Cout, 2 * C, dtype=torch.float32, device=x.device)
@@ -782,7 +789,8 @@ class EdgeConvPMFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout_pm, _unused):
-        dx_pm, dW, dgamma, dbeta = _edgeconv_backward(ctx.saved_tensors, ctx.cfg, dout_pm.contiguous(), pm=True)
+        dx_pm, dW, dgamma, dbeta = _edgeconv_backward(ctx.saved_tensors, ctx.cfg, dout_pm.contiguous(), pm=True,
+                                                      need_dx=ctx.needs_input_grad[0])
         return dx_pm, None, dW, dgamma, dbeta, None, None, None, None, None
 
 

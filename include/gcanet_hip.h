@@ -251,7 +251,8 @@ int gcn_edgeconv_finish(const float *ymax, const float *ymin, const double *gsum
  *   gcn_neighbor_sum: s[b,n,:] = sum_j x[b, idx[b,n,j], :]                      (gather)
  *   gcn_reverse_sum : r[b,m,:] = sum_{(n,j): idx[b,n,j]==m} x[b,n,:], indeg[b,m] = #(n,j) (destination-
  *                     partitioned 64-bit fixed-point LDS accumulation: no global atomics, bitwise
- *                     reproducible; both outputs fully written; indeg (B,N) f32 may be NULL;
+ *                     reproducible; both outputs fully written; indeg (B,N) f32 may be NULL, or r may
+ *                     be NULL (in-degrees only: no rows are read);
  *                     ws: gcn_reverse_sum_ws_bytes(B,N,k) bytes of device scratch, 16-B aligned). */
 int gcn_neighbor_sum(const float *x_pm, const int64_t *idx, int B, int N, int C, int k, float *s,
                      void *stream);
