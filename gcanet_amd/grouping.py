@@ -108,8 +108,15 @@ def clusters_voxelization(clusters_idx, clusters_offset, feats, coords, scale, s
         coords_min = coords_min - torch.clamp(spatial_shape - rng + 0.001, max=0) * r2.to(dev)
     coords = coords - coords_min[batch_idx]
     assert coords.shape.numel() == int(((coords >= 0) * (coords < spatial_shape)).sum())
-    coords = torch.cat([clusters_idx[:, 0].view(-1, 1).long(), coords.long().cpu()], 1).contiguous()
     nb = int(clusters_idx[-1, 0]) + 1
+    if nb <= 65536 and spatial_shape <= 65536:
+        # device voxelize_idx (csrc/voxelize_dev.hip): no .cpu() round trip of the coordinates; inp_map is returned
+        # on the CPU as the reference does (M4:1352)
+        coords = torch.cat([batch_idx.view(-1, 1), coords.long()], 1).contiguous()
+        out_coords, inp_map, out_map = voxelization_idx(coords, nb)
+        out_feats = voxelization(feats, out_map)
+        return out_feats, out_coords.int(), [spatial_shape] * 3, nb, inp_map.cpu()
+    coords = torch.cat([clusters_idx[:, 0].view(-1, 1).long(), coords.long().cpu()], 1).contiguous()
     out_coords, inp_map, out_map = voxelization_idx(coords, nb)
     out_feats = voxelization(feats, out_map.to(dev))
     return out_feats, out_coords.int().to(dev), [spatial_shape] * 3, nb, inp_map
