@@ -106,21 +106,26 @@ __global__ __launch_bounds__(256) void group_points_kernel(int c, int n, long E,
 // group_points with the source rows staged in LDS: the random 4-B gathers hit LDS banks instead of
 // 64 different cache lines per wave-instruction (the texture-address path capped the first version at
 // ~1.6 TB/s); the (b, CT-channel) workgroup streams all E = npoints*nsample outputs with 16-B stores.
-template <int CT>
-__global__ __launch_bounds__(512) void group_points_lds_kernel(int c, int n, long E, const float *__restrict__ points,
-                                                               const int32_t *__restrict__ idx, float *__restrict__ out) {
+template <int CT, int BS>
+__global__ __launch_bounds__(BS) void group_points_lds_kernel(int c, int n, long E, const float *__restrict__ points,
+                                                              const int32_t *__restrict__ idx, float *__restrict__ out) {
   extern __shared__ float rows[];  // CT * n
   const int b = blockIdx.y;
   const int c0 = blockIdx.x * CT;
-  for (int i = threadIdx.x; i < CT * n; i += 512) {
+  for (int i = threadIdx.x; i < CT * n; i += BS) {
     const int ch = c0 + i / n;
     rows[i] = ch < c ? points[((long)b * c + ch) * n + (i % n)] : 0.f;
   }
   __syncthreads();
   const int32_t *ip = idx + (long)b * E;
   const long E4 = E >> 2;  // E % 4 == 0 (checked by the launcher)
-  for (long q = threadIdx.x; q < E4; q += 512) {
-    const int4 v = *reinterpret_cast<const int4 *>(ip + q * 4);
+  // the id vector of the NEXT iteration is fetched before the current one is consumed (the loop is otherwise one
+  // exposed L2 round trip per 16 output bytes and channel)
+  int4 vn = threadIdx.x < E4 ? *reinterpret_cast<const int4 *>(ip + (long)threadIdx.x * 4) : make_int4(0, 0, 0, 0);
+  for (long q = threadIdx.x; q < E4; q += BS) {
+    const int4 v = vn;
+    const long qn = q + BS < E4 ? q + BS : q;
+    vn = *reinterpret_cast<const int4 *>(ip + qn * 4);
 #pragma unroll
     for (int cc = 0; cc < CT; ++cc) {
       const int ch = c0 + cc;
@@ -439,8 +444,13 @@ GCN_EXPORT int gcn_group_points(int b, int c, int n, int npoints, int nsample, c
   if (b == 0 || c == 0 || E == 0) return GCN_OK;
   hipStream_t st = (hipStream_t)stream;
   const size_t row_bytes = (size_t)n * sizeof(float);
+  if ((E & 3) == 0 && E >= 4096 && row_bytes * 4 <= 128 * 1024 && c >= 4) {
+    GCN_HIP(hipFuncSetAttribute((const void *)group_points_lds_kernel<4, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(row_bytes * 4)));
+    group_points_lds_kernel<4, 1024><<<dim3(cdiv(c, 4), b), 1024, row_bytes * 4, st>>>(c, n, E, points, idx, out);
+    return check_launch("group_points_lds_kernel");
+  }
   if ((E & 3) == 0 && E >= 4096 && row_bytes * 2 <= 64 * 1024) {
-    group_points_lds_kernel<2><<<dim3(cdiv(c, 2), b), 512, row_bytes * 2, st>>>(c, n, E, points, idx, out);
+    group_points_lds_kernel<2, 512><<<dim3(cdiv(c, 2), b), 512, row_bytes * 2, st>>>(c, n, E, points, idx, out);
     return check_launch("group_points_lds_kernel");
   }
   constexpr int CT = 8;
