@@ -21,6 +21,11 @@
 //     (knn.cu:125-131) -- bit-exact indices vs oracle/gcanet_oracle.c.
 // Arithmetic follows the oracle's contraction convention (explicit fmaf chains; the file
 // is compiled with -ffp-contract=off).
+#include <cstring>
+#include <vector>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
 #include "common.h"
 
 namespace gcn {
@@ -543,12 +548,304 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const void *__restrict__
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Self kNN of 3-D clouds (C = 3, or xyz+normal with the knn_points_normals metric) with spatial pruning.
+// The brute-force kernel above evaluates all N candidates per query; in 3-D the k-th neighbour of a point lies
+// within a few percent of the cloud's extent.  Here every cloud is sorted along a Morton curve, cut into tiles of
+// 64 consecutive points with their bounding boxes, and a wave (8 queries, adjacent on the curve) walks the tiles
+// outward from its own: a tile is skipped when, for each of the 8 queries, a conservative lower bound of the
+// metric over the box exceeds that query's current k-th key.  Visited candidates get exactly the arithmetic of
+// knn_select_kernel and entries are ordered by (key, ORIGINAL index) in the buffered bitonic lists, so indices
+// and distances are bit-identical to the brute-force kernel -- only ~15-25 of the 128 tiles are evaluated at
+// N = 8192, k = 64.  Lower bound: box distance^2 * (1 - 1e-6) - 2e-6 (xx_q + max xx_tile)  (the expanded-form
+// distance can undershoot the true one by a few ulp of the squared norms), times the smallest possible normal
+// factor 3 - 2 max|n|^2 for the normal metric (pruning is disabled when that is not positive).
+struct TileKnnArgs {
+  const float *xs;     // (B, C, N) sorted along the curve
+  const float *xxs;    // (B, N)
+  const int *perm;     // (B, N) original index of sorted position
+  const float *bbox;   // (B, T, 8): lo xyz, hi xyz, max xx, pad
+  int N, T, k, step;
+  long o_sb, o_sk, o_sq;       // output element (b, t, q) at b*o_sb + t*o_sk + q*o_sq
+  const unsigned int *box;   // (B, 8) per-cloud boxes; slot 6 = max |n|^2 bits of the cloud (METRIC 2)
+  int64_t *ind;
+  float *val;
+};
+
+__device__ __forceinline__ unsigned int morton_expand10(unsigned int v) {
+  v &= 0x3ff;
+  v = (v | (v << 16)) & 0x030000FF;
+  v = (v | (v << 8)) & 0x0300F00F;
+  v = (v | (v << 4)) & 0x030C30C3;
+  v = (v | (v << 2)) & 0x09249249;
+  return v;
+}
+__device__ __forceinline__ unsigned int f2ord_u(float f) {
+  const unsigned int u = __float_as_uint(f);
+  return u ^ ((unsigned int)((int)u >> 31) | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f_u(unsigned int u) { return __uint_as_float(u ^ ((u >> 31) ? 0x80000000u : 0xFFFFFFFFu)); }
+
+__global__ void tile_box_init_kernel(unsigned int *box, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) box[i] = (i & 7) < 3 ? 0xFFFFFFFFu : 0u;      // lo = +max (ordered), hi = lowest, |n|^2 = 0
+}
+
+// per-cloud bounding box of the xyz channels (ordered-uint atomics), and the cloud's max |n|^2 (slot 6)
+__global__ void tile_bbox_kernel(const float *__restrict__ x, long sb, long sd, long sn, int N, int with_normals,
+                                 unsigned int *__restrict__ box) {
+  const int b = blockIdx.y;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  float v[3] = {0.f, 0.f, 0.f}, nn = 0.f;
+  const bool ok = j < N;
+  if (ok) {
+    for (int d = 0; d < 3; ++d) v[d] = x[b * sb + d * sd + j * sn];
+    if (with_normals) for (int d = 3; d < 6; ++d) { const float t = x[b * sb + d * sd + j * sn]; nn = fmaf(t, t, nn); }
+  }
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    float lo = ok ? v[d] : __builtin_inff(), hi = ok ? v[d] : -__builtin_inff();
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o)); hi = fmaxf(hi, __shfl_xor(hi, o)); }
+    if (lane_id() == 0) { atomicMin(box + b * 8 + d, f2ord_u(lo)); atomicMax(box + b * 8 + 3 + d, f2ord_u(hi)); }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) nn = fmaxf(nn, __shfl_xor(nn, o));
+  if (lane_id() == 0) atomicMax(box + b * 8 + 6, __float_as_uint(nn));
+}
+
+__global__ void tile_morton_kernel(const float *__restrict__ x, long sb, long sd, long sn, int N, const unsigned int *__restrict__ box,
+                                   unsigned long long *__restrict__ keys, int *__restrict__ vals) {
+  const int b = blockIdx.y;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= N) return;
+  unsigned int code = 0;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const float lo = ord2f_u(box[b * 8 + d]), hi = ord2f_u(box[b * 8 + 3 + d]);
+    const float ext = hi - lo;
+    const float t = ext > 0.f ? (x[b * sb + d * sd + j * sn] - lo) / ext : 0.f;
+    const unsigned int q = (unsigned int)fminf(fmaxf(t * 1023.f, 0.f), 1023.f);
+    code |= morton_expand10(q) << d;
+  }
+  keys[(long)b * N + j] = ((unsigned long long)b << 32) | code;
+  vals[(long)b * N + j] = j;
+}
+
+// one wave per tile: gather the sorted rows and reduce the tile's box
+__global__ __launch_bounds__(256) void tile_gather_kernel(const float *__restrict__ x, long sb, long sd, long sn,
+                                                          const float *__restrict__ xx, int C, int N, int T, const int *__restrict__ perm, float *__restrict__ xs,
+                                                          float *__restrict__ xxs, float *__restrict__ bbox) {
+  const int lane = lane_id();
+  const int t = blockIdx.x * 4 + wave_id(), b = blockIdx.y;
+  if (t >= T) return;
+  const int p = t * 64 + lane;
+  const bool ok = p < N;
+  const int j = perm[(long)b * N + min(p, N - 1)];
+  float v3[3];
+  for (int d = 0; d < C; ++d) {
+    const float v = x[b * sb + d * sd + j * sn];
+    if (ok) xs[((long)b * C + d) * N + p] = v;
+    if (d < 3) v3[d] = v;
+  }
+  const float xj = xx ? xx[(long)b * N + j] : 0.f;
+  if (ok) xxs[(long)b * N + p] = xj;
+  float red[7];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) { red[d] = ok ? v3[d] : __builtin_inff(); red[3 + d] = ok ? v3[d] : -__builtin_inff(); }
+  red[6] = ok ? xj : 0.f;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { red[d] = fminf(red[d], __shfl_xor(red[d], o)); red[3 + d] = fmaxf(red[3 + d], __shfl_xor(red[3 + d], o)); }
+    red[6] = fmaxf(red[6], __shfl_xor(red[6], o));
+  }
+  if (lane < 7) {
+    float out = red[0];
+#pragma unroll
+    for (int d = 1; d < 7; ++d) out = lane == d ? red[d] : out;
+    bbox[((long)b * T + t) * 8 + lane] = out;
+  }
+}
+
+template <int METRIC, int DIMC>   // METRIC 0: KNN_CUDA direct differences, 1: expanded form (DIMC = 3); 2: knn_points_normals (6)
+__global__ __launch_bounds__(256) void knn_tiles_kernel(TileKnnArgs a) {
+  constexpr int QW = 8;
+  const int lane = lane_id(), wave = wave_id();
+  const int b = blockIdx.y;
+  const int q0 = (blockIdx.x * 4 + wave) * QW;
+  if (q0 >= a.N) return;
+  const int N = a.N;
+  const float *xs = a.xs + (long)b * DIMC * N;
+  const float *xxs = a.xxs + (long)b * N;
+  const int *perm = a.perm + (long)b * N;
+  const float *bbox = a.bbox + (long)b * a.T * 8;
+  int qi[QW];
+#pragma unroll
+  for (int q = 0; q < QW; ++q) qi[q] = min(q0 + q, N - 1);
+  float qv[QW][DIMC], xxi[QW];
+#pragma unroll
+  for (int q = 0; q < QW; ++q) {
+#pragma unroll
+    for (int d = 0; d < DIMC; ++d) qv[q][d] = xs[(long)d * N + qi[q]];
+    xxi[q] = xxs[qi[q]];
+  }
+  // lane q (< 8) keeps query q's position / norm / threshold for the box test
+  const int ql = min(q0 + (lane & 7), N - 1);
+  const float vx = xs[ql], vy = xs[(long)N + ql], vz = xs[2L * N + ql], vxx = xxs[ql];
+  float thr_v = KNN_INF;
+  TopB topb[QW];
+  int cnt[QW];
+  u64 thr64[QW];
+#pragma unroll
+  for (int q = 0; q < QW; ++q) { topb[q].init(); cnt[q] = 0; thr64[q] = ~0ull; }
+  const int klane = a.k - 1;
+  const int home = q0 >> 6;
+  // METRIC 2: lower bound of the normal factor (1 + n_pd) = 3 - 2 n_i.n_j >= 3 - 2 max|n|^2; <= 0 disables pruning
+  float fac_lb = 1.f;
+  if (METRIC == 2) fac_lb = (3.f - 2.f * __uint_as_float(a.box[b * 8 + 6])) * (1.f - 1e-5f) - 1e-5f;
+  const bool prune = METRIC != 2 || fac_lb > 0.f;
+  const int span = max(home, a.T - 1 - home);
+  for (int i = 0; i <= 2 * span; ++i) {
+    const int off = (i + 1) >> 1;
+    const int t = (i & 1) ? home + off : home - off;
+    if (t < 0 || t >= a.T) continue;
+    if (prune) {
+      const float *bb = bbox + (long)t * 8;
+      const float dx = fmaxf(fmaxf(bb[0] - vx, vx - bb[3]), 0.f), dy = fmaxf(fmaxf(bb[1] - vy, vy - bb[4]), 0.f),
+                  dz = fmaxf(fmaxf(bb[2] - vz, vz - bb[5]), 0.f);
+      float lb = fmaf(dz, dz, fmaf(dy, dy, dx * dx)) * (1.f - 1e-6f) - 2e-6f * (vxx + bb[6]);
+      lb = fmaxf(lb, 0.f);
+      if (METRIC == 2) lb *= fac_lb;
+      const unsigned long long need = __ballot(lane < QW && q0 + lane < N && lb <= thr_v);
+      if (!need) continue;
+    }
+    const int j = t * 64 + lane;
+    const bool valid = j < N;
+    const int jc = valid ? j : N - 1;
+    float cv[DIMC];
+#pragma unroll
+    for (int d = 0; d < DIMC; ++d) cv[d] = xs[(long)d * N + jc];
+    const float xxj = xxs[jc];
+    const int oidx = perm[jc];
+    float key[QW];
+#pragma unroll
+    for (int q = 0; q < QW; ++q) {
+      if (METRIC == 0) {                        // KNN_CUDA: direct differences (knn.cu:73-77)
+        float acc = 0.f;
+#pragma unroll
+        for (int d = 0; d < DIMC; ++d) { const float t2 = cv[d] - qv[q][d]; acc = fmaf(t2, t2, acc); }
+        key[q] = acc;
+      } else if (METRIC == 1) {
+        float acc = 0.f;
+#pragma unroll
+        for (int d = 0; d < DIMC; ++d) acc = fmaf(qv[q][d], cv[d], acc);
+        const float tt = 2.f * acc - xxj;
+        key[q] = -(tt - xxi[q]);
+      } else {
+        float dp = 0.f, dn = 0.f;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) dp = fmaf(qv[q][d], cv[d], dp);
+#pragma unroll
+        for (int d = 3; d < 6; ++d) dn = fmaf(qv[q][d], cv[d], dn);
+        const float p_pd = (xxj - 2.f * dp) + xxi[q];
+        const float n_pd = 2.f - 2.f * dn;
+        key[q] = p_pd * (1.f + n_pd);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < QW; ++q) {
+      const u64 c64 = ((u64)key_f2u(key[q]) << 32) | (unsigned int)oidx;
+      const bool pass = valid && c64 < thr64[q];
+      const unsigned long long m = __ballot(pass);
+      if (m) {
+        if (cnt[q] + __popcll(m) > 64) {
+          topb[q].merge(cnt[q], lane);
+          cnt[q] = 0;
+          const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(topb[q].lst >> 32), klane);
+          const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)topb[q].lst, klane);
+          thr64[q] = ((u64)hi << 32) | lo;
+          const float tk = hi == 0xFFFFFFFFu ? KNN_INF : key_u2f(hi);   // list not full yet (short home tile): no bound
+          thr_v = (lane & 7) == q ? tk : thr_v;
+        }
+        cnt[q] = topb[q].append(m, pass, key[q], oidx, cnt[q], lane);
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < QW; ++q) {
+    if (q0 + q >= N) break;
+    topb[q].merge(cnt[q], lane);
+    const int oq = perm[q0 + q];
+    if (lane < a.k && (lane % a.step) == 0) {
+      const long o = (long)b * a.o_sb + (long)(lane / a.step) * a.o_sk + (long)oq * a.o_sq;
+      a.ind[o] = (int64_t)(unsigned int)topb[q].lst;
+      const float kv = key_u2f((unsigned int)(topb[q].lst >> 32));
+      if (a.val) a.val[o] = METRIC == 0 ? sqrtf(kv) : -kv;
+    }
+  }
+}
+
+struct TileWs {
+  unsigned int *box;            // (B, 8)
+  unsigned long long *keys_a, *keys_b;
+  int *vals_a, *perm;
+  float *xs, *xxs, *bbox;
+  void *tmp;
+  size_t tmp_bytes, total;
+};
+static TileWs tile_ws_layout(char *base, int B, int C, int N) {
+  TileWs L;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { char *p = base ? base + off : nullptr; off += (bytes + 255) & ~(size_t)255; return p; };
+  const size_t n = (size_t)B * N;
+  const int T = (N + 63) / 64;
+  L.box = (unsigned int *)take(32 * (size_t)B);
+  L.keys_a = (unsigned long long *)take(8 * n); L.keys_b = (unsigned long long *)take(8 * n);
+  L.vals_a = (int *)take(4 * n); L.perm = (int *)take(4 * n);
+  L.xs = (float *)take(4 * n * C); L.xxs = (float *)take(4 * n); L.bbox = (float *)take(32 * (size_t)B * T);
+  size_t tb = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, tb, (unsigned long long *)nullptr, (unsigned long long *)nullptr, (int *)nullptr,
+                                  (int *)nullptr, n > 0 ? n : 1, 0, 64);
+  L.tmp_bytes = tb;
+  L.tmp = take(tb + 256);
+  L.total = off;
+  return L;
+}
+
+// kernel_metric: 0 KNN_CUDA, 1 expanded form, 2 points+normals.  x element (b,d,j) at b*sb + d*sd + j*sn.
+static int run_knn_tiles(const float *x, long sb, long sd, long sn, const float *xx, int B, int C, int N, int k, int step,
+                         int kernel_metric, long o_sb, long o_sk, long o_sq, int64_t *ind, float *val, void *ws,
+                         hipStream_t st) {
+  TileWs L = tile_ws_layout((char *)ws, B, C, N);
+  const int T = (N + 63) / 64;
+  tile_box_init_kernel<<<cdiv(B * 8, 256), 256, 0, st>>>(L.box, B * 8);
+  const dim3 gp(cdiv(N, 256), B);
+  tile_bbox_kernel<<<gp, 256, 0, st>>>(x, sb, sd, sn, N, kernel_metric == 2 ? 1 : 0, L.box);
+  tile_morton_kernel<<<gp, 256, 0, st>>>(x, sb, sd, sn, N, L.box, L.keys_a, L.vals_a);
+  size_t tb = L.tmp_bytes;
+  int bits = 32;
+  for (int v = B - 1; v > 0; v >>= 1) ++bits;
+  GCN_HIP(rocprim::radix_sort_pairs(L.tmp, tb, L.keys_a, L.keys_b, L.vals_a, L.perm, (size_t)B * N, 0, bits, st));
+  tile_gather_kernel<<<dim3(cdiv(T, 4), B), 256, 0, st>>>(x, sb, sd, sn, xx, C, N, T, L.perm, L.xs, L.xxs, L.bbox);
+  TileKnnArgs a{};
+  a.xs = L.xs; a.xxs = L.xxs; a.perm = L.perm; a.bbox = L.bbox;
+  a.N = N; a.T = T; a.k = k; a.step = step; a.o_sb = o_sb; a.o_sk = o_sk; a.o_sq = o_sq; a.ind = ind; a.val = val;
+  a.box = L.box;
+  const dim3 grid(cdiv(N, 32), B);
+  if (kernel_metric == 2) knn_tiles_kernel<2, 6><<<grid, 256, 0, st>>>(a);
+  else if (kernel_metric == 1) knn_tiles_kernel<1, 3><<<grid, 256, 0, st>>>(a);
+  else knn_tiles_kernel<0, 3><<<grid, 256, 0, st>>>(a);
+  return check_launch("knn_tiles_kernel");
+}
+
 }  // namespace gcn
 
 using namespace gcn;
 
 GCN_EXPORT int gcn_knn_cuda(const float *ref, const float *query, int B, int dim, int nr, int nq, int k,
-                            int point_major, float *dist, int64_t *ind, void *stream) {
+                            int point_major, float *dist, int64_t *ind, void *tile_ws, void *stream) {
   GCN_REQUIRE(ref && query && dist && ind, "gcn_knn_cuda: null pointer");
   GCN_REQUIRE(B >= 0 && dim >= 1 && nr >= 1 && nq >= 0, "gcn_knn_cuda: bad shape B=%d dim=%d nr=%d nq=%d", B, dim, nr, nq);
   GCN_REQUIRE(k >= 1 && k <= nr && k <= 512, "gcn_knn_cuda: need 1 <= k <= min(nr,512), got k=%d nr=%d", k, nr);
@@ -567,12 +864,20 @@ GCN_EXPORT int gcn_knn_cuda(const float *ref, const float *query, int B, int dim
   a.o_sb = (long)k * nq;
   a.dist = dist; a.ind = ind;
   hipStream_t st = (hipStream_t)stream;
+  // a 3-D cloud searched against itself: the Morton-tiled kernel (same results, box pruning)
+  if (tile_ws && ref == query && nr == nq && dim == 3 && k <= 64 && nr >= 512)
+    return run_knn_tiles(ref, a.ref_sb, a.ref_sd, a.ref_sn, nullptr, B, 3, nr, k, 1, 0, a.o_sb, a.o_sk, a.o_sq, ind, dist, tile_ws, st);
   if (dim == 3) return launch_knn<0, 3>(a, B, st);
   return launch_knn<0, 0>(a, B, st);
 }
 
+GCN_EXPORT long gcn_knn_tiles_ws_bytes(int B, int C, int N) {
+  if (B < 0 || C < 1 || N < 1) return -1;
+  return (long)tile_ws_layout(nullptr, B, C, N).total;
+}
+
 GCN_EXPORT int gcn_knn_model(const float *x, int B, int C, int N, int k1, int k2, int metric,
-                             int64_t *idx, float *val, float *xx_ws, void *stream) {
+                             int64_t *idx, float *val, float *xx_ws, void *tile_ws, void *stream) {
   GCN_REQUIRE(x && idx && xx_ws, "gcn_knn_model: null pointer");
   GCN_REQUIRE(metric == 0 || metric == 1, "gcn_knn_model: metric must be 0 (knn) or 1 (knn_points_normals)");
   GCN_REQUIRE(B >= 0 && C >= 1 && N >= 1, "gcn_knn_model: bad shape B=%d C=%d N=%d", B, C, N);
@@ -593,6 +898,11 @@ GCN_EXPORT int gcn_knn_model(const float *x, int B, int C, int N, int k1, int k2
   a.ref_sd = a.q_sd = N; a.ref_sn = a.q_sn = 1;
   a.o_sb = (long)N * kout; a.o_sk = 1; a.o_sq = kout;
   a.dist = val; a.ind = idx;
+  // 3-D clouds: Morton-tiled kernel with bounding-box pruning (identical results, ~5x fewer candidates)
+  const bool tiled = tile_ws && k2 <= 64 && N >= 512 && ((metric == 1 && C == 6) || (metric == 0 && C == 3));
+  if (tiled)
+    return run_knn_tiles(x, (long)C * N, N, 1, xx_ws, B, C, N, k2, step, metric == 1 ? 2 : 1, (long)N * kout, 1, kout, idx, val,
+                         tile_ws, st);
   if (metric == 1) return launch_knn<2, 6>(a, B, st);
   if (C == 3) return launch_knn<1, 3>(a, B, st);
   if (k2 <= 64 && N >= 64 && (N % 4) == 0) {  // matrix-core path (bit-identical dot products)

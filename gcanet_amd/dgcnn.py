@@ -18,9 +18,15 @@ def _knn_model(x, k1, k2, metric):
     kout = len(range(0, k2, step))
     idx = torch.empty(B, N, kout, dtype=torch.int64, device=x.device)
     xx = torch.empty(B, N, dtype=torch.float32, device=x.device)
+    tile_ws = None
+    # 3-D clouds: Morton-tiled kernel with box pruning (identical results).  Not used for the normal metric: its
+    # factor (3 - 2 n_i.n_j) in [1,5] inflates the k-th key relative to the Euclidean bound, and with incoherent
+    # normals (the synthetic benchmark clouds) more than half of the tiles survive -- slower than the full scan.
+    if k2 <= 64 and N >= 512 and metric == 0 and C == 3:
+        tile_ws = torch.empty(_lib.lib().gcn_knn_tiles_ws_bytes(B, C, N), dtype=torch.uint8, device=x.device)
     with torch.cuda.device_of(x):
         _lib.call("gcn_knn_model", _lib.ptr(x), B, C, N, k1, k2, metric, _lib.ptr(idx), None, _lib.ptr(xx),
-                  _lib.stream_of(x), tag="knn_model[B=%d,C=%d,N=%d,k=%d]" % (B, C, N, k2))
+                  _lib.ptr(tile_ws), _lib.stream_of(x), tag="knn_model[B=%d,C=%d,N=%d,k=%d]" % (B, C, N, k2))
     return idx
 
 

@@ -35,9 +35,13 @@ def _knn_batched(ref, query, k, point_major):
         shape = (B, k, nq)
     D = torch.empty(shape, dtype=torch.float32, device=ref.device)
     I = torch.empty(shape, dtype=torch.int64, device=ref.device)
+    tile_ws = None
+    if dim == 3 and k <= 64 and nr >= 512 and nr == nq and ref.data_ptr() == query.data_ptr():
+        # a 3-D cloud against itself: Morton-tiled kernel with box pruning (identical results)
+        tile_ws = torch.empty(_lib.lib().gcn_knn_tiles_ws_bytes(B, 3, nr), dtype=torch.uint8, device=ref.device)
     with torch.cuda.device_of(ref):
         _lib.call("gcn_knn_cuda", _lib.ptr(ref), _lib.ptr(query), B, dim, nr, nq, k, int(point_major),
-                  _lib.ptr(D), _lib.ptr(I), _lib.stream_of(ref))
+                  _lib.ptr(D), _lib.ptr(I), _lib.ptr(tile_ws), _lib.stream_of(ref))
     return D, I
 
 

@@ -45,7 +45,7 @@ int gcn_version(void);
  *   ind   same shape as dist, int64, 0-based; ties -> lowest ref index (knn.cu:125-131)
  * 1 <= k <= min(nr, 512). */
 int gcn_knn_cuda(const float *ref, const float *query, int B, int dim, int nr, int nq, int k,
-                 int point_major, float *dist, int64_t *ind, void *stream);
+                 int point_major, float *dist, int64_t *ind, void *tile_ws, void *stream);
 
 /* Replaces the pure-torch `knn(x,k1,k2)` (M4:30-47, metric 0) and
  * `knn_points_normals(x,k1,k2)` (M4:50-90, metric 1): per-cloud N x N negative squared
@@ -56,7 +56,14 @@ int gcn_knn_cuda(const float *ref, const float *query, int B, int dim, int nr, i
  *   xx_ws workspace (B, N) f32 (squared norms; written by the call)
  * 1 <= k1 <= k2 <= min(N, 512). */
 int gcn_knn_model(const float *x, int B, int C, int N, int k1, int k2, int metric,
-                  int64_t *idx, float *val, float *xx_ws, void *stream);
+                  int64_t *idx, float *val, float *xx_ws, void *tile_ws, void *stream);
+
+/* Scratch for the spatially pruned path of gcn_knn_model (3-D clouds: C == 3, or C == 6 with metric 1; k2 <= 64,
+ * N >= 512): Morton sort + 64-point tiles with bounding boxes, tiles skipped by a conservative lower bound of the
+ * metric -- identical indices and values to the brute-force kernel.  tile_ws == NULL keeps the brute-force scan.
+ * gcn_knn_cuda takes the same workspace (gcn_knn_tiles_ws_bytes(B, 3, nr)) and uses it when a 3-D cloud is searched
+ * against itself (ref == query, k <= 64, nr >= 512). */
+long gcn_knn_tiles_ws_bytes(int B, int C, int N);
 
 /* ------------------------------------------------------------ pointnet2_ops ---- */
 

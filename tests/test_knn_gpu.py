@@ -176,3 +176,74 @@ def test_topk_rows_matches_torch(dev, shape, k, dtype):
     (gx,) = torch.autograd.grad(v, x, go)
     ref = torch.zeros_like(x).scatter_(-1, i, go)
     assert torch.equal(gx, ref)
+
+
+def _knn_both(x, k, metric):
+    """gcn_knn_model through the pruned (tile_ws) and the brute-force (tile_ws = NULL) paths: (idx, val) each."""
+    from gcanet_amd import _lib
+    B, C, N = x.shape
+    outs = []
+    for tiled in (True, False):
+        idx = torch.empty(B, N, k, dtype=torch.int64, device=x.device)
+        val = torch.empty(B, N, k, dtype=torch.float32, device=x.device)
+        xx = torch.empty(B, N, dtype=torch.float32, device=x.device)
+        ws = torch.empty(_lib.lib().gcn_knn_tiles_ws_bytes(B, C, N), dtype=torch.uint8, device=x.device) if tiled else None
+        _lib.call("gcn_knn_model", _lib.ptr(x), B, C, N, k, k, metric, _lib.ptr(idx), _lib.ptr(val), _lib.ptr(xx), _lib.ptr(ws),
+                  _lib.stream_of(x))
+        outs.append((idx, val))
+    return outs
+
+
+@pytest.mark.parametrize("kind", ["uniform", "clustered", "grid_ties", "plane", "duplicates"])
+@pytest.mark.parametrize("B,N,k,metric", [(2, 2048, 64, 0), (3, 1000, 20, 0), (2, 4096, 64, 1), (1, 777, 33, 1)])
+def test_knn_tiles_bitexact_vs_bruteforce(dev, kind, B, N, k, metric):
+    """Morton-tiled pruned kNN == brute-force kernel, indices AND distances, on benign and adversarial clouds:
+    clusters (uneven density), an integer grid (masses of exact ties), a plane (degenerate boxes), duplicated points."""
+    g = torch.Generator().manual_seed(N * 7 + k + metric)
+    if kind == "uniform":
+        p = torch.rand(B, N, 3, generator=g)
+    elif kind == "clustered":
+        c = torch.rand(B, 8, 3, generator=g)
+        p = c[:, torch.randint(0, 8, (N,), generator=g)] + 0.02 * torch.randn(B, N, 3, generator=g)
+        p[:, : N // 10] = torch.rand(B, N // 10, 3, generator=g) * 5.0
+    elif kind == "grid_ties":
+        p = torch.randint(0, 12, (B, N, 3), generator=g).float() / 4.0
+    elif kind == "plane":
+        p = torch.rand(B, N, 3, generator=g)
+        p[..., 2] = 0.25
+    else:
+        p = torch.rand(B, N // 4 + 1, 3, generator=g).repeat(1, 4, 1)[:, :N]
+    if metric == 1:
+        nrm = torch.nn.functional.normalize(torch.randn(B, N, 3, generator=g), dim=-1)
+        if kind == "grid_ties":
+            nrm = torch.nn.functional.normalize(torch.randint(-1, 2, (B, N, 3), generator=g).float() + 0.001, dim=-1)
+        p = torch.cat([p, nrm], -1)
+    x = p.transpose(1, 2).contiguous().to(dev)
+    (i1, v1), (i0, v0) = _knn_both(x, k, metric)
+    assert torch.equal(i1, i0)
+    assert torch.equal(v1, v0)
+
+
+def test_knn_tiles_unnormalised_normals_fall_back_to_full_scan(dev):
+    """|n| > 1.22 makes the normal factor's lower bound non-positive: pruning must switch itself off, results unchanged."""
+    g = torch.Generator().manual_seed(3)
+    p = torch.cat([torch.rand(1, 1024, 3, generator=g), 3.0 * torch.randn(1, 1024, 3, generator=g)], -1)
+    x = p.transpose(1, 2).contiguous().to(dev)
+    (i1, v1), (i0, v0) = _knn_both(x, 32, 1)
+    assert torch.equal(i1, i0) and torch.equal(v1, v0)
+
+
+@pytest.mark.parametrize("transpose_mode", [False, True])
+@pytest.mark.parametrize("kind", ["uniform", "grid_ties"])
+def test_knn_cuda_self_query_tiles_equals_bruteforce(dev, transpose_mode, kind):
+    """KNN_CUDA module on a cloud against itself takes the pruned kernel; a clone of the query (different pointer)
+    takes the brute-force one: identical D and I in both layouts."""
+    from gcanet_amd.knn_cuda import KNN
+    g = torch.Generator().manual_seed(21)
+    B, N, k = 2, 3000, 40
+    p = torch.rand(B, N, 3, generator=g) if kind == "uniform" else torch.randint(0, 10, (B, N, 3), generator=g).float() / 3.0
+    x = (p if transpose_mode else p.transpose(1, 2)).contiguous().to(dev)
+    m = KNN(k, transpose_mode=transpose_mode)
+    d1, i1 = m(x, x)
+    d0, i0 = m(x, x.clone())
+    assert torch.equal(i1, i0) and torch.equal(d1, d0)
