@@ -106,7 +106,7 @@ struct EcArgs {
 // them share a CU and drift out of phase: one workgroup's VALU epilogue overlaps the other's MFMAs.
 // The neighbour ids of tile t+2 are fetched while tile t computes, so the DMA issue of tile t+1 never
 // waits on a dependent global load.  RWT == 2 (128 < k <= 255) keeps the cross-wave LDS combine.
-template <int KSTEPS, int CW, int RWT, bool WITH_ARG, bool ROUTED>
+template <int KSTEPS, int CW, int RWT, bool WITH_ARG, bool ROUTED, int KP>   // KP: compile-time padded k (0 = runtime)
 __global__ __launch_bounds__(64 * RWT * CW, 2) void edgeconv_fwd_bf16_kernel(EcArgs a) {
   constexpr int NC = KSTEPS;               // chunks per x row
   constexpr int CP = KSTEPS * 8;           // padded channels
@@ -137,15 +137,24 @@ __global__ __launch_bounds__(64 * RWT * CW, 2) void edgeconv_fwd_bf16_kernel(EcA
   for (int s = 0; s < KSTEPS; ++s)
     breg[s] = *reinterpret_cast<const bf16x8 *>(a.wp + (long)(cg * 32 + lr) * K + s * 16 + lh * 8);
 
-  // routed mode: sgn = +1 keeps the max, -1 turns the min into a max of the negated column
+  // routed mode: sgn = +1 keeps the max, -1 turns the min into a max of the NEGATED column: the sign is folded
+  // into this lane's W' column once (bf16 sign bits; products and sums negate exactly), not into every output
   const float sgn = ROUTED ? (a.gamma_route[cg * 32 + lr] >= 0.f ? 1.f : -1.f) : 1.f;
+  if (ROUTED && sgn < 0.f) {
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) {
+      unsigned int *w4 = reinterpret_cast<unsigned int *>(&breg[s]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) w4[i] ^= 0x80008000u;
+    }
+  }
 
   const int G = gridDim.x;
   const int t_begin = (int)((long)blockIdx.x * a.total_tiles / G);
   const int t_end = (int)((long)(blockIdx.x + 1) * a.total_tiles / G);
   if (t_begin >= t_end) return;
 
-  const int kp = a.kp, k = a.k, TP = a.TP;
+  const int kp = KP ? KP : a.kp, k = a.k, TP = a.TP;      // a constant kp turns the row -> (point, slot) divisions into shifts
   const int rows_used = TP * kp;
 
   // neighbour row ids of this lane's DMA pieces for one tile (always PPW loads, clamped, so that the
@@ -165,7 +174,7 @@ __global__ __launch_bounds__(64 * RWT * CW, 2) void edgeconv_fwd_bf16_kernel(EcA
       if (j >= k) j = 0;
       int n = n0 + pt;
       if (n >= a.N) n = a.N - 1;
-      grow[i] = (int)a.idx[((long)b * a.N + n) * k + j];
+      grow[i] = reinterpret_cast<const int *>(a.idx)[2 * (((long)b * a.N + n) * k + j)];   // low dword of the int64 id
     }
   };
   // issue the LDS-DMA gather of tile t into buffer `buf` from the ids in grow[]
@@ -181,7 +190,9 @@ __global__ __launch_bounds__(64 * RWT * CW, 2) void edgeconv_fwd_bf16_kernel(EcA
         const int row = p * RPP + lane / NC;
         const int cs = lane % NC;                       // physical chunk slot
         const int c = cs ^ ((row / RPB) & (NC - 1));    // logical chunk (swizzle on the source side)
-        const unsigned short *src = xb + (long)grow[i] * CP + c * 8;
+        // 32-bit byte offset from the cloud's (wave-uniform) base: scalar base + VGPR offset addressing
+        const unsigned char *src = reinterpret_cast<const unsigned char *>(xb) +
+                                   ((unsigned int)grow[i] * (unsigned int)ROW_BYTES + (unsigned int)(c * 16));
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                          (__attribute__((address_space(3))) void *)(abuf + p * 1024), 16, 0, 0);
       }
@@ -245,22 +256,26 @@ __global__ __launch_bounds__(64 * RWT * CW, 2) void edgeconv_fwd_bf16_kernel(EcA
       for (int i = 0; i < 16; ++i) acc[rb][i] = 0.f;
 
     if (active) {
-      int arow[4], aswz[4], cpt[4];
+      // neighbour half (k-steps 0..NC/2-1): chunk (2s + lh) ^ swz = (2s) ^ (lh ^ swz) since 2s and lh share no
+      // bit, and rows are ROW_BYTES-aligned, so the address is base ^ (2s << 4) with base = row start ^ ((lh ^ swz)
+      // << 4): ONE xor with a literal per fragment.  Centre half: purely additive (immediate offsets).
+      int abase[4], cbase[4];
 #pragma unroll
       for (int rb = 0; rb < 4; ++rb) {
         const int row = rg * 128 + rb * 32 + lr;
-        arow[rb] = row * ROW_BYTES;
-        aswz[rb] = (row / RPB) & (NC - 1);
-        cpt[rb] = (row / kp) * ROW_BYTES;
+        abase[rb] = (row * ROW_BYTES) ^ ((lh ^ ((row / RPB) & (NC - 1))) << 4);
+        cbase[rb] = (row / kp) * ROW_BYTES + (lh << 4);
       }
 #pragma unroll
       for (int s = 0; s < KSTEPS; ++s) {
-        const int gc = 2 * s + lh;  // global 16-B chunk of the [x_j ; x_i] row
         bf16x8 af[4];
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) {
-          const unsigned char *p = gc < NC ? abuf + arow[rb] + ((gc ^ aswz[rb]) << 4)
-                                           : cbuf + cpt[rb] + ((gc - NC) << 4);
+          const unsigned char *p;
+          if (NC == 1)        // one 16-B chunk per row: the half-wave decides (lh = 0 neighbour row, 1 centre row)
+            p = lh == 0 ? abuf + (abase[rb] ^ (lh << 4)) : cbuf + cbase[rb] - (lh << 4);
+          else
+            p = s < NC / 2 ? abuf + (abase[rb] ^ ((2 * s) << 4)) : cbuf + cbase[rb] + ((2 * s - NC) << 4);
           af[rb] = *reinterpret_cast<const bf16x8 *>(p);
         }
 #pragma unroll
@@ -291,12 +306,8 @@ __global__ __launch_bounds__(64 * RWT * CW, 2) void edgeconv_fwd_bf16_kernel(EcA
           ps += v;
           pq = fmaf(v, v, pq);
         }
-        s1 += ps;
+        s1 += ROUTED ? ps * sgn : ps;                   // acc holds sgn * y in routed mode
         s2 += pq;
-        if (ROUTED) {
-#pragma unroll
-          for (int i = 0; i < 16; ++i) acc[rb][i] *= sgn;   // exact; min becomes max of the negated column
-        }
         float mx = acc[rb][0], mn = acc[rb][0];
 #pragma unroll
         for (int i = 1; i < 16; ++i) {
@@ -859,8 +870,16 @@ static int launch_fwd_bf16(EcArgs &a, bool with_arg, hipStream_t st) {
   const int by_lds = (160 * 1024) / (lds_bytes > 0 ? lds_bytes : 1);
   const int resident = 256 * (wg_per_cu < by_lds ? wg_per_cu : by_lds);
   int grid = a.total_tiles < resident ? a.total_tiles : resident;
-  auto kern = a.gamma_route ? (with_arg ? edgeconv_fwd_bf16_kernel<KSTEPS, CW, RWT, true, true> : edgeconv_fwd_bf16_kernel<KSTEPS, CW, RWT, false, true>)
-                            : (with_arg ? edgeconv_fwd_bf16_kernel<KSTEPS, CW, RWT, true, false> : edgeconv_fwd_bf16_kernel<KSTEPS, CW, RWT, false, false>);
+  using kern_t = void (*)(EcArgs);
+  // k = 64 (the configuration everything is tuned on) gets the padded k as a compile-time constant
+  const bool kp64 = RWT == 1 && a.kp == 64;
+  kern_t kern;
+  if (kp64)
+    kern = a.gamma_route ? (with_arg ? (kern_t)edgeconv_fwd_bf16_kernel<KSTEPS, CW, RWT, true, true, 64> : (kern_t)edgeconv_fwd_bf16_kernel<KSTEPS, CW, RWT, false, true, 64>)
+                         : (with_arg ? (kern_t)edgeconv_fwd_bf16_kernel<KSTEPS, CW, RWT, true, false, 64> : (kern_t)edgeconv_fwd_bf16_kernel<KSTEPS, CW, RWT, false, false, 64>);
+  else
+    kern = a.gamma_route ? (with_arg ? (kern_t)edgeconv_fwd_bf16_kernel<KSTEPS, CW, RWT, true, true, 0> : (kern_t)edgeconv_fwd_bf16_kernel<KSTEPS, CW, RWT, false, true, 0>)
+                         : (with_arg ? (kern_t)edgeconv_fwd_bf16_kernel<KSTEPS, CW, RWT, true, false, 0> : (kern_t)edgeconv_fwd_bf16_kernel<KSTEPS, CW, RWT, false, false, 0>);
   GCN_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
   kern<<<grid, 64 * RWT * CW, lds_bytes, st>>>(a);
   return check_launch("edgeconv_fwd_bf16_kernel");
