@@ -109,6 +109,7 @@ def main():
     from gcanet_amd import _lib, dgcnn, parallel
     rank, local, world = parallel.init_distributed()
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    local = local % torch.cuda.device_count()      # one rank per GPU; the modulo only matters when ranks are over-subscribed in a rehearsal
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     _lib.lib()  # fail loudly if the HIP library is missing
