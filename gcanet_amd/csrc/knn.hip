@@ -448,13 +448,37 @@ __global__ __launch_bounds__(256, 4) void knn_mfma16_kernel(const float *__restr
     const float *tb = tile + buf * PIECES * 256;
     const int j0 = t * TC;
     const int jbase = (j0 + TC > N) ? N - TC : j0;
+    // CC <= 64: the B operands of a column block are fetched as ONE batch of CC/4 LDS reads ahead of its MFMA chain
+    // (block cb+1 while block cb computes) instead of a read -> wait -> MFMA pair per step with the LDS latency on the
+    // dependent chain (-2 %); at CC = 128 the 2 x 32 extra registers cost the fourth wave per SIMD (2.1 -> 3.6 ms)
+    constexpr bool PREFETCH_B = CC <= 64;
+    float bv[PREFETCH_B ? CC / 4 : 1];
+    if (PREFETCH_B) {
+      const float *bcol0 = tb + lg * TC + (TC == 64 ? (((0 ^ lg) << 4) + lc) : lc);
+#pragma unroll
+      for (int s = 0; s < CC / 4; ++s) bv[PREFETCH_B ? s : 0] = bcol0[4 * s * TC];
+    }
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) {
       knn_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      const float *bcol = tb + lg * TC + (TC == 64 ? (((cb ^ lg) << 4) + lc) : (cb * 16 + lc));
+      if (PREFETCH_B) {
+        float bcur[PREFETCH_B ? CC / 4 : 1];
 #pragma unroll
-      for (int s = 0; s < CC / 4; ++s)
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[s], bcol[4 * s * TC], acc, 0, 0, 0);
+        for (int s = 0; s < CC / 4; ++s) bcur[PREFETCH_B ? s : 0] = bv[PREFETCH_B ? s : 0];
+        if (cb + 1 < NCB) {
+          const float *bcol = tb + lg * TC + (TC == 64 ? ((((cb + 1) ^ lg) << 4) + lc) : ((cb + 1) * 16 + lc));
+#pragma unroll
+          for (int s = 0; s < CC / 4; ++s) bv[PREFETCH_B ? s : 0] = bcol[4 * s * TC];
+        }
+#pragma unroll
+        for (int s = 0; s < CC / 4; ++s)
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[s], bcur[PREFETCH_B ? s : 0], acc, 0, 0, 0);
+      } else {
+        const float *bcol = tb + lg * TC + (TC == 64 ? (((cb ^ lg) << 4) + lc) : (cb * 16 + lc));
+#pragma unroll
+        for (int s = 0; s < CC / 4; ++s)
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[s], bcol[4 * s * TC], acc, 0, 0, 0);
+      }
       const int j = jbase + cb * 16 + lc;
       const float xxj = tb[CC * TC + cb * 16 + lc];
       const bool fresh = j >= j0 && j < N;
