@@ -65,7 +65,7 @@ def pmc_traffic(tag):
         return None
     ks = json.load(open(path))["kernels"]
     name = {"knn_model[B=8,C=64": "gcn::knn_mfma16_kernel<64, 64>", "knn_model[B=8,C=6,": "gcn::knn_select_kernel<1, 8, 2, 6>",
-            "edgeconv_fwd[B=8,N=8192,k=64,C=64,Cout=128": "gcn::edgeconv_fwd_bf16_kernel<8, 4, 1, true, true>"}
+            "edgeconv_fwd[B=8,N=8192,k=64,C=64,Cout=128": "gcn::edgeconv_fwd_bf16_kernel<8, 4, 1, true, true, 64>"}
     for pre, kn in name.items():
         if tag.startswith(pre) and kn in ks:
             return ks[kn]["hbm_bytes_corrected"]
