@@ -697,7 +697,7 @@ class PrimitivesEmbeddingDGCNGn(nn.Module):
         Activations are point-major (B,N,C) end to end; the reference's (B,C,N) Conv1d tensors are the same
         values transposed.  conv1 on cat[x4 repeated, x_features] (M4:510-511,644) is evaluated as
         W[:, :1024].x4 (once per cloud) + W[:, 1024:].x_features -- identical, 5x fewer FLOPs."""
-        from .layers import conv1x1, group_norm_relu, linear_pm
+        from .layers import conv1x1, group_norm_relu, linear_pm, param_normalise
         B, N, _ = points.shape
         pts = torch.cat([points, normals], dim=-1).contiguous() if self.mode == 5 else points.contiguous()   # (B,N,6)
         pts_cm = pts.transpose(1, 2).contiguous()
@@ -710,9 +710,13 @@ class PrimitivesEmbeddingDGCNGn(nn.Module):
         type_forgroup = conv1x1(x_type, self.mlp_prim_prob2)                                  # (B,N,P)
         type_per_point = F.log_softmax(type_forgroup.float(), dim=-1) if "r" in self.loss_class else type_forgroup
         x_para = group_norm_relu(conv1x1(x_all, self.mlp_param_prob1), self.bn_param_prob1)
-        p = conv1x1(x_para, self.mlp_param_prob2).float()
-        param_per_point = torch.cat([p[:, :, :4], self._unit(p[:, :, 4:7]), p[:, :, 7:8], self._unit(p[:, :, 8:11]),
-                                     p[:, :, 11:15], self._unit(p[:, :, 15:18]), p[:, :, 18:22]], dim=2)
+        p = conv1x1(x_para, self.mlp_param_prob2)
+        if p.shape[-1] == 22 and p.is_cuda:               # one kernel each way instead of the slice/norm/div/cat chain
+            param_per_point = param_normalise(p)
+        else:
+            p = p.float()
+            param_per_point = torch.cat([p[:, :, :4], self._unit(p[:, :, 4:7]), p[:, :, 7:8], self._unit(p[:, :, 8:11]),
+                                         p[:, :, 11:15], self._unit(p[:, :, 15:18]), p[:, :, 18:22]], dim=2)
         # normal-feature EdgeConv: same input as encoder layer 1 -> same neighbour list (M4:691 recomputes it)
         idx1 = self.encoder.last_idx[0]
         if self.mode == 5 and not pts.requires_grad:      # fused: the (B,N,k,7) edge feature is never formed

@@ -164,3 +164,30 @@ class GroupNormReLUMaxFunction(torch.autograd.Function):
 def group_norm_relu_max(x, gn, relu=True):
     """max over dim 1 of group_norm_relu(x, gn): (B,N,C) -> (B,C)."""
     return GroupNormReLUMaxFunction.apply(x, gn.weight, gn.bias, gn.num_groups, gn.eps, relu)
+
+
+class ParamNormaliseFunction(torch.autograd.Function):
+    """(..., 22) parameter rows: unit-normalise the direction triples 4:7, 8:11, 15:18 (M4:664-676)."""
+
+    @staticmethod
+    def forward(ctx, p):
+        _lib.require_cuda(p)
+        assert p.shape[-1] == 22
+        pc = p.float().contiguous()
+        out = torch.empty_like(pc)
+        _run("gcn_param_normalise_fwd", pc, _lib.ptr(pc), pc.numel() // 22, _lib.ptr(out))
+        ctx.save_for_backward(pc)
+        ctx.in_dtype = p.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        (pc,) = ctx.saved_tensors
+        go = go.float().contiguous()
+        gi = torch.empty_like(pc)
+        _run("gcn_param_normalise_bwd", pc, _lib.ptr(pc), _lib.ptr(go), pc.numel() // 22, _lib.ptr(gi))
+        return gi.to(ctx.in_dtype)
+
+
+def param_normalise(p):
+    return ParamNormaliseFunction.apply(p)

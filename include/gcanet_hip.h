@@ -363,6 +363,12 @@ int gcn_gn_max_fwd(const void *x, int dtype, const float *gamma, const float *be
                    float eps, int relu, float *out_max, int64_t *out_arg, float *mean_rstd, double *gsum_ws,
                    void *best_ws, void *stream);
 
+/* Parameter head epilogue (M4:664-676): p (R,22) f32 rows; the triples 4:7, 8:11, 15:18 are divided by
+ * (their L2 norm + 1e-12), the other columns pass through -- one kernel instead of the slice / norm / div / cat
+ * chain; _bwd is its vector-Jacobian product (grad_in (R,22) fully written). */
+int gcn_param_normalise_fwd(const float *p, long R, float *out, void *stream);
+int gcn_param_normalise_bwd(const float *p, const float *grad_out, long R, float *grad_in, void *stream);
+
 /* ------------------------------------------------------------- attention stacks ------ */
 
 /* Fused scaled-dot-product attention forward (online softmax; the (Lq x Lk) score matrix never

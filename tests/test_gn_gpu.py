@@ -55,3 +55,25 @@ def test_group_norm_relu_max_matches_two_step(dev, dtype, B, N, C, G):
     tol = 2e-2 if dtype == torch.bfloat16 else 1e-4
     for u, v in zip(ga, gb):
         assert (u.float() - v.float()).abs().max().item() <= tol * max(v.float().abs().max().item(), 1.0)
+
+
+def test_param_normalise_matches_torch_chain(dev):
+    """csrc/heads.hip vs the reference's slice / norm / div / cat chain (M4:664-676), values and gradient."""
+    from gcanet_amd import layers
+    g = torch.Generator().manual_seed(4)
+    p = torch.randn(3, 500, 22, generator=g).to(dev)
+    p[0, 0, 4:7] = 0.0                                              # a zero triple: 0 / 1e-12
+    go = torch.randn(3, 500, 22, generator=g).to(dev)
+    unit = lambda v: v / (torch.norm(v, dim=-1, keepdim=True).repeat(1, 1, 3) + 1e-12)
+    pa = p.clone().requires_grad_(True)
+    a = layers.param_normalise(pa)
+    (ga,) = torch.autograd.grad(a, pa, go)
+    pb = p.clone().requires_grad_(True)
+    b = torch.cat([pb[:, :, :4], unit(pb[:, :, 4:7]), pb[:, :, 7:8], unit(pb[:, :, 8:11]), pb[:, :, 11:15],
+                   unit(pb[:, :, 15:18]), pb[:, :, 18:22]], dim=2)
+    (gb,) = torch.autograd.grad(b, pb, go)
+    np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=1e-6, atol=1e-7)
+    mask = torch.ones_like(p, dtype=torch.bool)
+    mask[0, 0, 4:7] = False                                         # torch's norm backward is NaN at exactly zero
+    np.testing.assert_allclose(ga[mask].cpu().numpy(), gb[mask].cpu().numpy(), rtol=1e-4, atol=1e-5)
+    assert torch.isfinite(ga).all()
