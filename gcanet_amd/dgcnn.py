@@ -186,7 +186,7 @@ def edge_conv(x, idx, weight, gamma, beta, groups=2, dtype="bf16", eps=1e-5, slo
     """out (B,Cout,N) = max_k LeakyReLU(GroupNorm(Conv2d_1x1(get_graph_feature(x, idx))))  (M4:493-505).
     x (B,C,N) f32, idx (B,N,k) int64, weight (Cout,2C) or the Conv2d's (Cout,2C,1,1)."""
     if weight.dim() == 4:
-        weight = weight[:, :, 0, 0]
+        weight = weight.flatten(1)                      # (Cout,Cin,1,1) -> (Cout,Cin): a view, no select/backward-fill kernels
     return EdgeConvFunction.apply(x, idx, weight, gamma, beta, groups, dtype, eps, slope)
 
 
@@ -342,7 +342,7 @@ def normal_edge_block(pts, idx, weight, gamma, beta, groups=2, eps=1e-5, slope=0
 def grouped_block(ef, weight, gamma, beta, groups=2, eps=1e-5, slope=0.2, dtype="bf16", pm_out=False):
     """ef (B,N,k,F) point-major edge features -> (B,Cout,N), or (B,N,Cout) with pm_out."""
     if weight.dim() == 4:
-        weight = weight[:, :, 0, 0]
+        weight = weight.flatten(1)                      # (Cout,Cin,1,1) -> (Cout,Cin): a view, no select/backward-fill kernels
     return GroupedBlockFunction.apply(ef.float().contiguous(), weight, gamma, beta, groups, eps, slope, dtype, pm_out)
 
 
@@ -645,10 +645,12 @@ class OFFSET_PRED_MODULE(nn.Module):
         dist = cos_dist(instance_feature, key_emb)                             # (B,N,120)
         topk_dist, topk_idx = topk_rows(dist, self.k)                          # once, not twice (M4:421-422)
         att = self.attention.weights(topk_dist)                                # (B,N,k)
-        W = self.conv1[0].weight[:, :, 0, 0]                                   # (128,131)
+        W = self.conv1[0].weight.flatten(1)                                    # (128,131) view of the 1x1 kernel
         Wf, Wp = W[:, :128], W[:, 128:]
         U = key_feat @ Wf.t() + key_pts @ Wp.t()                               # (B,120,128)
-        V = points @ Wp.t()                                                    # (B,N,128)
+        from .layers import linear_pm
+        with torch.autocast("cuda", enabled=False):        # f32 (xyz precision); split-K weight gradient (65536-row reduction)
+            V = linear_pm(points.float(), Wp.float())                          # (B,N,128)
         # fused: conv output att*(U[m]-V) -> GroupNorm -> LeakyReLU -> max over k, (B,N,k,128) never formed
         if pm_out:
             from .layers import conv1x1
@@ -702,7 +704,7 @@ class PrimitivesEmbeddingDGCNGn(nn.Module):
         pts = torch.cat([points, normals], dim=-1).contiguous() if self.mode == 5 else points.contiguous()   # (B,N,6)
         pts_cm = pts.transpose(1, 2).contiguous()
         xf, x4 = self.encoder.forward_pm(pts_cm, pts)
-        w1 = self.conv1.weight[:, :, 0]
+        w1 = self.conv1.weight.flatten(1)
         h = linear_pm(xf, w1[:, 1024:]) + F.linear(x4, w1[:, :1024], self.conv1.bias).unsqueeze(1)
         x = group_norm_relu(h, self.bn1)
         x_all = group_norm_relu(conv1x1(x, self.conv2), self.bn2)                             # (B,N,256)
@@ -805,5 +807,5 @@ class EdgeConvPMFunction(torch.autograd.Function):
 
 
 def edge_conv_pm(x_pm, idx, conv_weight, gn, dtype="bf16", want_cm=True):
-    w = conv_weight[:, :, 0, 0] if conv_weight.dim() == 4 else conv_weight
+    w = conv_weight.flatten(1) if conv_weight.dim() == 4 else conv_weight
     return EdgeConvPMFunction.apply(x_pm, idx, w, gn.weight, gn.bias, gn.num_groups, dtype, gn.eps, 0.2, want_cm)

@@ -94,7 +94,7 @@ def linear_pm(x, weight, bias=None):
 
 def conv1x1(x, conv):
     """Conv1d(kernel 1) applied to point-major x (B,N,Cin) as a GEMM with the SAME parameter tensor."""
-    return linear_pm(x, conv.weight[:, :, 0], conv.bias)
+    return linear_pm(x, conv.weight.flatten(1), conv.bias)      # (Cout,Cin,1) -> (Cout,Cin) view
 
 
 class GlobalMaxPoolFunction(torch.autograd.Function):
