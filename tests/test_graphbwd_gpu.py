@@ -101,3 +101,29 @@ def test_normal_edge_block_matches_materialised(dev, B, N, k):
     assert (out - y).abs().max().item() < 1e-4
     for a, b in zip(g1, g2):
         assert (a - b).abs().max().item() <= 2e-4 * max(b.abs().max().item(), 1.0)
+
+
+def test_new_entry_points_handle_empty_and_reject_bad_shapes(dev):
+    """Empty batches are a no-op (GCN_OK), impossible shapes raise RuntimeError (status int -> exception, never exit)."""
+    from gcanet_amd import _lib
+    t = torch.zeros(64, device=dev)
+    i64 = torch.zeros(64, dtype=torch.int64, device=dev)
+    u8 = torch.zeros(64, dtype=torch.uint8, device=dev)
+    d = torch.zeros(64, dtype=torch.float64, device=dev)
+    st = _lib.stream_of(t)
+    _lib.call("gcn_reverse_sum", _lib.ptr(t), _lib.ptr(i64), 0, 8, 4, 2, _lib.ptr(t), _lib.ptr(t), _lib.ptr(u8), st)
+    _lib.call("gcn_topk_rows", _lib.ptr(t), 0, 0, 8, 4, _lib.ptr(t), _lib.ptr(i64), st)
+    _lib.call("gcn_normal_edge_fwd", _lib.ptr(t), _lib.ptr(i64), _lib.ptr(t), 0, 8, 4, 8, 2, _lib.ptr(t), _lib.ptr(t),
+              _lib.ptr(u8), _lib.ptr(u8), _lib.ptr(d), st)
+    _lib.call("gcn_param_normalise_fwd", _lib.ptr(t), 0, _lib.ptr(t), st)
+    _lib.call("gcn_attention_fwd_bf16", _lib.ptr(t), _lib.ptr(t), _lib.ptr(t), None, 0, 0, 4, 4, 32, 1.0, _lib.ptr(t),
+              _lib.ptr(t), _lib.ptr(u8), st)
+    with pytest.raises(RuntimeError):
+        _lib.call("gcn_topk_rows", _lib.ptr(t), 0, 1, 200, 4, _lib.ptr(t), _lib.ptr(i64), st)            # NK > 128
+    with pytest.raises(RuntimeError):
+        _lib.call("gcn_attention_fwd_bf16", _lib.ptr(t), _lib.ptr(t), _lib.ptr(t), None, 0, 1, 4, 4, 48, 1.0,
+                  _lib.ptr(t), _lib.ptr(t), _lib.ptr(u8), st)                                               # head dim 48
+    with pytest.raises(RuntimeError):
+        _lib.call("gcn_normal_edge_fwd", _lib.ptr(t), _lib.ptr(i64), _lib.ptr(t), 1, 8, 300, 8, 2, _lib.ptr(t), _lib.ptr(t),
+                  _lib.ptr(u8), _lib.ptr(u8), _lib.ptr(d), st)                                              # k > 256
+    torch.cuda.synchronize()
