@@ -60,4 +60,30 @@ __device__ __forceinline__ float wave_shr1_f(float lane0_val, float v) {
 
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Zero up to three device spans with as few hipMemsetAsync calls as possible: spans that are adjacent in memory
+// (the Python side allocates the small per-call accumulators back to back) collapse into one fill -- a fill of a few
+// hundred bytes costs ~4.5 us of GPU time like any other launch, and a training step had ~80 of them.
+struct ZeroSpan { void *p; size_t n; };
+inline hipError_t zero_spans(hipStream_t st, ZeroSpan a, ZeroSpan b = {nullptr, 0}, ZeroSpan c = {nullptr, 0}) {
+  ZeroSpan v[3] = {a, b, c};
+  // sort by address (3 elements), skip empties
+  for (int i = 0; i < 3; ++i)
+    for (int j = i + 1; j < 3; ++j)
+      if (v[j].p && (!v[i].p || (char *)v[j].p < (char *)v[i].p)) { ZeroSpan t = v[i]; v[i] = v[j]; v[j] = t; }
+  int i = 0;
+  while (i < 3 && v[i].p) {
+    char *lo = (char *)v[i].p, *hi = lo + v[i].n;
+    int j = i + 1;
+    while (j < 3 && v[j].p && (char *)v[j].p <= hi) {             // exactly adjacent (or overlapping) spans only
+      char *h2 = (char *)v[j].p + v[j].n;
+      if (h2 > hi) hi = h2;
+      ++j;
+    }
+    hipError_t e = hipMemsetAsync(lo, 0, (size_t)(hi - lo), st);
+    if (e != hipSuccess) return e;
+    i = j;
+  }
+  return hipSuccess;
+}
+
 }  // namespace gcn

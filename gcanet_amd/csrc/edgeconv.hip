@@ -1052,8 +1052,7 @@ GCN_EXPORT int gcn_keyedge_bwd(const float *att, const int64_t *kidx, const floa
   GCN_REQUIRE(lds <= 158 * 1024, "gcn_keyedge_bwd: key tables %zu B exceed LDS", lds);
   if (B == 0) return GCN_OK;
   hipStream_t st = (hipStream_t)stream;
-  GCN_HIP(hipMemsetAsync(dUsp, 0, sizeof(float) * (size_t)B * NK * Cout, st));
-  GCN_HIP(hipMemsetAsync(T12, 0, sizeof(float) * (size_t)B * 2 * NK, st));
+  GCN_HIP(zero_spans(st, {dUsp, sizeof(float) * (size_t)B * NK * Cout}, {T12, sizeof(float) * (size_t)B * 2 * NK}));
   GCN_HIP(hipFuncSetAttribute((const void *)keyedge_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int blocks_per_cloud = (256 + B - 1) / B;
   if (blocks_per_cloud > (N + 3) / 4) blocks_per_cloud = (N + 3) / 4;

@@ -325,10 +325,8 @@ GCN_EXPORT int gcn_gn_bwd(const void *dy, const void *x, int dtype, const float 
   if (rc) return rc;
   GCN_REQUIRE(dy && x && gamma && beta && mean_rstd && dx && dgamma && dbeta && s_ws, "gcn_gn_bwd: null pointer");
   hipStream_t st = (hipStream_t)stream;
-  GCN_HIP(hipMemsetAsync(dgamma, 0, sizeof(float) * C, st));
-  GCN_HIP(hipMemsetAsync(dbeta, 0, sizeof(float) * C, st));
-  if (B == 0) return GCN_OK;
-  GCN_HIP(hipMemsetAsync(s_ws, 0, sizeof(double) * 2 * B * G, st));
+  if (B == 0) { GCN_HIP(zero_spans(st, {dgamma, sizeof(float) * C}, {dbeta, sizeof(float) * C})); return GCN_OK; }
+  GCN_HIP(zero_spans(st, {dgamma, sizeof(float) * C}, {dbeta, sizeof(float) * C}, {s_ws, sizeof(double) * 2 * B * G}));
   const int rows = slab_rows(N, B);
   const dim3 g1(cdiv(N, rows), B);
   const int g2 = (int)(((long)N * C / 4 + 255) / 256 > 2048 ? 2048 : ((long)N * C / 4 + 255) / 256);

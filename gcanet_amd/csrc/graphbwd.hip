@@ -299,10 +299,8 @@ GCN_EXPORT int gcn_route_bwd(const float *dout_pm, const float *ymax, const floa
   GCN_REQUIRE(!(dsp || msel) || idx, "gcn_route_bwd: dsp/msel need idx");
   GCN_REQUIRE((Ac == nullptr) == (Bc == nullptr) && (!Ac || count_per_group > 0), "gcn_route_bwd: Ac/Bc come together, count > 0");
   hipStream_t st = (hipStream_t)stream;
-  GCN_HIP(hipMemsetAsync(dgamma, 0, sizeof(float) * Cout, st));
-  GCN_HIP(hipMemsetAsync(dbeta, 0, sizeof(float) * Cout, st));
-  if (B == 0) return GCN_OK;
-  GCN_HIP(hipMemsetAsync(S, 0, sizeof(double) * 2 * B * G, st));
+  if (B == 0) { GCN_HIP(zero_spans(st, {dgamma, sizeof(float) * Cout}, {dbeta, sizeof(float) * Cout})); return GCN_OK; }
+  GCN_HIP(zero_spans(st, {dgamma, sizeof(float) * Cout}, {dbeta, sizeof(float) * Cout}, {S, sizeof(double) * 2 * B * G}));
   if (dsp) GCN_HIP(hipMemsetAsync(dsp, 0, sizeof(float) * (size_t)B * N * Cout, st));
   // (more, shorter blocks are slower: the end-of-block dgamma/dbeta/S atomics all land on the same few lines)
   int blocks = (512 + B - 1) / B;

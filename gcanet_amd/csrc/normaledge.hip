@@ -213,10 +213,8 @@ GCN_EXPORT int gcn_normal_edge_bwd(const float *pts, const int64_t *idx, const f
   GCN_REQUIRE(pts && idx && coef && jsel && dWsp && esum && gram, "gcn_normal_edge_bwd: null pointer");
   GCN_REQUIRE(B >= 0 && N >= 1 && k >= 1 && Cout >= 1 && Cout <= 128, "gcn_normal_edge_bwd: bad shape (Cout <= 128)");
   hipStream_t st = (hipStream_t)stream;
-  GCN_HIP(hipMemsetAsync(dWsp, 0, sizeof(float) * Cout * NE_F, st));
-  if (B == 0) return GCN_OK;
-  GCN_HIP(hipMemsetAsync(esum, 0, sizeof(float) * B * NE_F, st));
-  GCN_HIP(hipMemsetAsync(gram, 0, sizeof(float) * B * NE_F * NE_F, st));
+  if (B == 0) { GCN_HIP(zero_spans(st, {dWsp, sizeof(float) * Cout * NE_F})); return GCN_OK; }
+  GCN_HIP(zero_spans(st, {dWsp, sizeof(float) * Cout * NE_F}, {esum, sizeof(float) * B * NE_F}, {gram, sizeof(float) * B * NE_F * NE_F}));
   int blocks_per_cloud = (512 + B - 1) / B;
   if (blocks_per_cloud > (N + 3) / 4) blocks_per_cloud = (N + 3) / 4;
   const int ppb = (N + blocks_per_cloud - 1) / blocks_per_cloud;

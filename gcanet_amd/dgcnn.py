@@ -327,7 +327,8 @@ class NormalEdgeBlockFunction(torch.autograd.Function):
         jsel, coef, Ac, Bc, dgamma, dbeta, _ = _route_backward_fused(dpm, gamma, beta, ymax, ymin, amax, amin, mean_rstd, G,
                                                                      slope, float((Cout // G) * N * k), want_jsel=True)
         f32 = dict(dtype=torch.float32, device=pts.device)
-        dWsp, esum, gram = torch.empty(Cout, 7, **f32), torch.empty(B, 7, **f32), torch.empty(B, 7, 7, **f32)
+        raw = torch.empty(Cout * 7 + B * 7 + B * 49, **f32)        # adjacent accumulators: one zero fill in the library
+        dWsp, esum, gram = raw[:Cout * 7].view(Cout, 7), raw[Cout * 7:Cout * 7 + B * 7].view(B, 7), raw[Cout * 7 + B * 7:].view(B, 7, 7)
         _run("gcn_normal_edge_bwd", pts, _lib.ptr(pts), _lib.ptr(idx), _lib.ptr(coef), _lib.ptr(jsel), B, N, k, Cout,
              _lib.ptr(dWsp), _lib.ptr(esum), _lib.ptr(gram))
         dW = dWsp + Ac.t() @ esum + torch.einsum("bo,og,bgf->of", Bc, W, gram)
@@ -358,9 +359,8 @@ def _route_backward_fused(dout_pm, gamma, beta, ymax, ymin, amax, amin, mean_rst
     coef = torch.empty(B, N, Cout, dtype=torch.float32, device=dev)
     jsel = torch.empty(B, N, Cout, dtype=torch.int64, device=dev) if want_jsel else None
     dsp = torch.empty(B, N, Cout, dtype=torch.float32, device=dev) if want_dsp else None
-    dgamma = torch.empty(Cout, dtype=torch.float32, device=dev)
-    dbeta = torch.empty(Cout, dtype=torch.float32, device=dev)
-    S = torch.empty(B, G, 2, dtype=torch.float64, device=dev)
+    from .layers import _acc_buffers
+    S, dgamma, dbeta = _acc_buffers(B * G * 2, Cout, dev)      # adjacent: one zero fill inside gcn_route_bwd
     ymin = ymin if (ymin is not None and ymin.numel()) else None
     amin = amin if (amin is not None and amin.numel()) else None
     Ac = torch.empty(B, Cout, dtype=torch.float32, device=dev)
@@ -447,8 +447,8 @@ class KeyEdgeBlockFunction(torch.autograd.Function):
             X = (V * Bc.unsqueeze(1)) @ U.transpose(1, 2)                   # (B,N,NK)
             datt, dV = torch.empty_like(att), torch.empty_like(V)
             A2 = torch.empty(B, N, NK, dtype=torch.float32, device=att.device)
-            dUsp = torch.empty_like(U)
-            T12 = torch.empty(B, 2, NK, dtype=torch.float32, device=att.device)
+            raw = torch.empty(U.numel() + B * 2 * NK, dtype=torch.float32, device=att.device)   # adjacent: one zero fill
+            dUsp, T12 = raw[:U.numel()].view_as(U), raw[U.numel():].view(B, 2, NK)
             _run("gcn_keyedge_bwd", att, _lib.ptr(att), _lib.ptr(kidx), _lib.ptr(U), _lib.ptr(V), _lib.ptr(coef.contiguous()),
                  _lib.ptr(jsel.contiguous()), _lib.ptr(Ac.contiguous()), _lib.ptr(Bc.contiguous()), _lib.ptr(X.contiguous()),
                  B, N, k, NK, Cout, _lib.ptr(datt), _lib.ptr(dV), _lib.ptr(A2), _lib.ptr(dUsp), _lib.ptr(T12))

@@ -11,6 +11,16 @@ def _run(name, like, *args):
         _lib.call(name, *args, _lib.stream_of(like))
 
 
+def _acc_buffers(n_f64, C, device):
+    """(S (n_f64,) f64, dgamma (C,) f32, dbeta (C,) f32) carved back to back from ONE allocation, so that the library
+    zeroes them with a single fill (csrc/common.h:zero_spans) instead of three 4.5-us launches."""
+    raw = torch.empty(n_f64 * 8 + 2 * C * 4, dtype=torch.uint8, device=device)
+    S = raw[:n_f64 * 8].view(torch.float64)
+    dg = raw[n_f64 * 8:n_f64 * 8 + C * 4].view(torch.float32)
+    db = raw[n_f64 * 8 + C * 4:].view(torch.float32)
+    return S, dg, db
+
+
 class GroupNormReLUFunction(torch.autograd.Function):
     """y = [ReLU](GroupNorm(x)) for x (B,N,C) f32 or bf16 (output dtype = input dtype)."""
 
@@ -38,9 +48,7 @@ class GroupNormReLUFunction(torch.autograd.Function):
         B, N, C = x.shape
         dy = dy.to(x.dtype).contiguous()
         dx = torch.empty_like(x)
-        dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
-        dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
-        ws = torch.empty(B, groups, 2, dtype=torch.float64, device=x.device)
+        ws, dgamma, dbeta = _acc_buffers(B * groups * 2, C, x.device)
         _run("gcn_gn_bwd", x, _lib.ptr(dy), _lib.ptr(x), dt, _lib.ptr(ga), _lib.ptr(be), _lib.ptr(mean_rstd), B, N, C,
              groups, int(relu), _lib.ptr(dx), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ws))
         return dx, dgamma, dbeta, None, None, None
@@ -153,9 +161,7 @@ class GroupNormReLUMaxFunction(torch.autograd.Function):
         dy = torch.zeros(B, N, C, dtype=x.dtype, device=x.device)
         dy.scatter_(1, arg.unsqueeze(1), dout.to(x.dtype).unsqueeze(1))
         dx = torch.empty_like(x)
-        dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
-        dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
-        ws = torch.empty(B, groups, 2, dtype=torch.float64, device=x.device)
+        ws, dgamma, dbeta = _acc_buffers(B * groups * 2, C, x.device)
         _run("gcn_gn_bwd", x, _lib.ptr(dy), _lib.ptr(x), dt, _lib.ptr(ga), _lib.ptr(be), _lib.ptr(mean_rstd), B, N, C,
              groups, int(relu), _lib.ptr(dx), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ws))
         return dx, dgamma, dbeta, None, None, None
