@@ -380,14 +380,15 @@ static int launch_knn(const KnnArgs &a, int B, hipStream_t st) {
 //   spread across all 64 lanes -> 16 lists per wave, 32 VGPRs, four waves per SIMD.  (A 32x32x2
 //   version with 32 queries per wave ran two waves per SIMD and was 6 % slower: the kernel is bound
 //   by the dependent insert chains -- PMC: VALU 42 %, MFMA 31 % of SIMD time.)
-// k <= 64 only (one list entry per lane); larger k uses knn_select_kernel.
+// k <= 64: one list entry per lane (KPL = 1, 7-VALU insert); 64 < k <= 128: two (KPL = 2, generic insert);
+// larger k uses knn_select_kernel.
 //   A[i=l&15][kk=l>>4] = x[4s+kk][q0+i];  B[kk=l>>4][j=l&15] = x[4s+kk][cand j]: the four channel rows a
 //   B fetch touches are one LDS row apart (TC=64: same banks), so the DMA writes row r with its
 //   16-candidate blocks XOR-permuted by (r&3) and the fetch undoes it (source-side swizzle).
 typedef __attribute__((ext_vector_type(4))) float knn_f32x4;
 
-template <int CC, int TC>
-__global__ __launch_bounds__(256, 4) void knn_mfma16_kernel(const float *__restrict__ x, const float *__restrict__ xxg,
+template <int CC, int TC, int KPL>   // KPL list registers per query: k <= 64 * KPL
+__global__ __launch_bounds__(256, KPL == 1 ? 4 : 3) void knn_mfma16_kernel(const float *__restrict__ x, const float *__restrict__ xxg,
                                                             int N, int k, int step, int kout,
                                                             int64_t *__restrict__ ind, float *__restrict__ val) {
   constexpr int ROWS = CC + 1;           // + one row of squared norms
@@ -412,7 +413,7 @@ __global__ __launch_bounds__(256, 4) void knn_mfma16_kernel(const float *__restr
 #pragma unroll
   for (int r = 0; r < 4; ++r) xxq[r] = xxb[min(q0 + 4 * lg + r, N - 1)];
 
-  TopK<1> top[4][4];                     // [r][g]: query q0 + 4g + r
+  TopK<KPL> top[4][4];                   // [r][g]: query q0 + 4g + r
   float thrv[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -420,7 +421,7 @@ __global__ __launch_bounds__(256, 4) void knn_mfma16_kernel(const float *__restr
     for (int g = 0; g < 4; ++g) top[r][g].init();
     thrv[r] = KNN_INF;
   }
-  const int klane = k - 1;
+  const int kslot = (k - 1) >> 6, klane = (k - 1) & 63;
 
   const int ntiles = (N + TC - 1) / TC;
   auto issue_tile = [&](int t, int buf) {
@@ -499,8 +500,14 @@ __global__ __launch_bounds__(256, 4) void knn_mfma16_kernel(const float *__restr
               top[r][g].insert(readlane_f(key, l + 16 * g), cb0 + l, lane);
             }
           }
-          const float t0 = readlane_f(top[r][0].key[0], klane), t1 = readlane_f(top[r][1].key[0], klane);
-          const float t2 = readlane_f(top[r][2].key[0], klane), t3 = readlane_f(top[r][3].key[0], klane);
+          float t0, t1, t2, t3;
+          if (KPL == 1) {
+            t0 = readlane_f(top[r][0].key[0], klane); t1 = readlane_f(top[r][1].key[0], klane);
+            t2 = readlane_f(top[r][2].key[0], klane); t3 = readlane_f(top[r][3].key[0], klane);
+          } else {
+            t0 = top[r][0].kth(kslot, klane); t1 = top[r][1].kth(kslot, klane);
+            t2 = top[r][2].kth(kslot, klane); t3 = top[r][3].kth(kslot, klane);
+          }
           thrv[r] = lg == 0 ? t0 : (lg == 1 ? t1 : (lg == 2 ? t2 : t3));
         }
       }
@@ -514,10 +521,14 @@ __global__ __launch_bounds__(256, 4) void knn_mfma16_kernel(const float *__restr
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int q = q0 + 4 * g + r;
-      if (q < N && lane < k && (lane % step) == 0) {
-        const long o = ((long)b * N + q) * kout + lane / step;
-        ind[o] = (int64_t)top[r][g].idx[0];
-        if (val) val[o] = -top[r][g].key[0];
+#pragma unroll
+      for (int sl = 0; sl < KPL; ++sl) {
+        const int t = sl * 64 + lane;
+        if (q < N && t < k && (t % step) == 0) {
+          const long o = ((long)b * N + q) * kout + t / step;
+          ind[o] = (int64_t)top[r][g].idx[sl];
+          if (val) val[o] = -top[r][g].key[sl];
+        }
       }
     }
 }
@@ -527,8 +538,13 @@ static int launch_knn_mfma16(const float *x, const float *xx, int B, int N, int 
                              float *val, hipStream_t st) {
   constexpr int PIECES = (CC + 1 + 256 / TC - 1) / (256 / TC);
   const int lds = 2 * PIECES * 1024;
-  GCN_HIP(hipFuncSetAttribute((const void *)knn_mfma16_kernel<CC, TC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  knn_mfma16_kernel<CC, TC><<<dim3(cdiv(N, 64), B), 256, lds, st>>>(x, xx, N, k, step, kout, ind, val);
+  if (k <= 64) {
+    GCN_HIP(hipFuncSetAttribute((const void *)knn_mfma16_kernel<CC, TC, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    knn_mfma16_kernel<CC, TC, 1><<<dim3(cdiv(N, 64), B), 256, lds, st>>>(x, xx, N, k, step, kout, ind, val);
+  } else {   // 64 < k <= 128 (the reference's default k = 80): two list registers per query
+    GCN_HIP(hipFuncSetAttribute((const void *)knn_mfma16_kernel<CC, TC, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    knn_mfma16_kernel<CC, TC, 2><<<dim3(cdiv(N, 64), B), 256, lds, st>>>(x, xx, N, k, step, kout, ind, val);
+  }
   return check_launch("knn_mfma16_kernel");
 }
 
@@ -929,7 +945,7 @@ GCN_EXPORT int gcn_knn_model(const float *x, int B, int C, int N, int k1, int k2
                          tile_ws, st);
   if (metric == 1) return launch_knn<2, 6>(a, B, st);
   if (C == 3) return launch_knn<1, 3>(a, B, st);
-  if (k2 <= 64 && N >= 64 && (N % 4) == 0) {  // matrix-core path (bit-identical dot products)
+  if (k2 <= 128 && N >= 64 && (N % 4) == 0) {  // matrix-core path (bit-identical dot products)
     if (C == 32) return launch_knn_mfma16<32, 64>(x, xx_ws, B, N, k2, step, kout, idx, val, st);
     if (C == 64) return launch_knn_mfma16<64, 64>(x, xx_ws, B, N, k2, step, kout, idx, val, st);
     if (C == 128) return launch_knn_mfma16<128, 32>(x, xx_ws, B, N, k2, step, kout, idx, val, st);
