@@ -586,6 +586,7 @@ __global__ __launch_bounds__(1024) void reverse_sum_lds_kernel(const float *__re
                                                                const unsigned int *__restrict__ absmax_bits, int B, int N,
                                                                int C, int k, int R, float *__restrict__ r,
                                                                float *__restrict__ indeg) {
+  if (C64) C = 64;                                       // compile-time channel count: the loads below lose their C > 0 guards
   extern __shared__ unsigned long long qacc[];          // [R][C] fixed-point sums, then [R] u32 counts
   unsigned int *cnt = reinterpret_cast<unsigned int *>(qacc + (long)R * C);
   const int lane = lane_id(), wave = wave_id();
