@@ -338,6 +338,219 @@ __global__ __launch_bounds__(256) void ballquery_grid_kernel(int n, long thre, f
   if (!FILL && lane == 0) counts[p] = cnt < cap ? cnt : cap;
 }
 
+// ---------------------------------------------------------------- ball query with on-the-fly similarity
+// forward_grouping (M4:1218-1226) hands bfs_cluster.cu:18-77 two dense (n,n) matrices
+//     adj = exp(-(cdist(f,f) / max cdist)^2 / 2)   with a zero diagonal            (M4:210-233)
+// that only ever get read at the pairs inside the search radius.  Here the two conditions `adj_inst > thr_inst &&
+// adj_para > thr_para` are evaluated at exactly those pairs from the feature rows and the per-segment diameter
+// (seg_diameter_kernel): no (n,n) tensor, no 12 elementwise passes over it, and every (cloud, class) subset of the
+// model is one segment of a single launch.
+//
+// seg_diameter_kernel: max_{i != j in segment} ||f_i - f_j||^2 in the expanded form xx_i + xx_j - 2 f_i.f_j the
+// reference's cdist uses, Gram blocks on v_mfma_f32_16x16x4_f32.  A workgroup owns 64 rows (16 per wave) and walks the
+// 64-row column tiles from its own diagonal tile to the end of the segment (the matrix is symmetric).  Rows are
+// zero-padded to a multiple of 16 columns by the caller; rows past the end of the segment are clamped duplicates and
+// masked in the epilogue.  Lane group g = lane/16 supplies columns 4g..4g+3 of each 16-column chunk as the k index
+// of four consecutive MFMAs (the same permutation on both operands, so the contraction is complete).
+using bq_f32x4 = __attribute__((__vector_size__(4 * sizeof(float)))) float;
+
+__global__ void row_sqnorm_kernel(int n, int C, const float *__restrict__ f, float *__restrict__ xx) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int c = 0; c < C; ++c) s = fmaf(f[(long)i * C + c], f[(long)i * C + c], s);
+  xx[i] = s;
+}
+
+// tile_prefix[s] = number of 64-row tiles of the segments before s (inactive segments own none)
+__global__ void seg_tile_prefix_kernel(int S, const int32_t *__restrict__ seg_offsets, const int32_t *__restrict__ seg_cls,
+                                       int32_t *__restrict__ tile_prefix) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int run = 0;
+  for (int s = 0; s < S; ++s) {
+    tile_prefix[s] = run;
+    if (seg_cls[s] >= 0) run += (seg_offsets[s + 1] - seg_offsets[s] + 63) / 64;
+  }
+  tile_prefix[S] = run;
+}
+
+__global__ __launch_bounds__(256) void seg_diameter_kernel(int S, int C, const float *__restrict__ f,
+                                                           const float *__restrict__ xx,
+                                                           const int32_t *__restrict__ seg_offsets,
+                                                           const int32_t *__restrict__ tile_prefix,
+                                                           unsigned int *__restrict__ dmax2) {
+  const int tile = blockIdx.x;
+  if (tile >= tile_prefix[S]) return;
+  int lo = 0, hi = S;                       // last s with tile_prefix[s] <= tile
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (tile_prefix[mid] <= tile) lo = mid; else hi = mid;
+  }
+  const int sg = lo;
+  const int beg = seg_offsets[sg], end = seg_offsets[sg + 1];
+  const int lane = lane_id(), wave = wave_id();
+  const int li = lane & 15, lk = lane >> 4;
+  const int i0 = beg + (tile - tile_prefix[sg]) * 64 + wave * 16;       // this wave's 16 rows
+  const float *arow = f + (long)min(i0 + li, end - 1) * C + 4 * lk;
+  float xi[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) xi[r] = xx[min(i0 + 4 * lk + r, end - 1)];
+  float best = 0.f;
+  for (int j0 = beg + (tile - tile_prefix[sg]) * 64; j0 < end; j0 += 64) {
+    bq_f32x4 acc[4];
+    const float *brow[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      acc[t] = {0.f, 0.f, 0.f, 0.f};
+      brow[t] = f + (long)min(j0 + 16 * t + li, end - 1) * C + 4 * lk;
+    }
+    for (int kc = 0; kc < C; kc += 16) {
+      const float4 a = *reinterpret_cast<const float4 *>(arow + kc);
+      float4 b[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) b[t] = *reinterpret_cast<const float4 *>(brow[t] + kc);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[t].x, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[t].y, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[t].z, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[t].w, acc[t], 0, 0, 0);
+      }
+    }
+    // D[i = 4*lk + r][j = li]
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int j = j0 + 16 * t + li;
+      const float xj = xx[min(j, end - 1)];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = i0 + 4 * lk + r;
+        const float d2 = (xi[r] + xj) - 2.f * acc[t][r];
+        if (i < end && j < end && i != j) best = fmaxf(best, d2);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) best = fmaxf(best, __shfl_xor(best, o));
+  if (lane == 0 && best > 0.f) atomicMax(dmax2 + sg, __float_as_uint(best));   // non-negative floats order as uints
+}
+
+struct SimArgs {
+  const float *fi, *fp;           // (n, Ci), (n, Cp) feature rows, point order
+  const float *dmi2, *dmp2;       // (S) squared diameters
+  const int32_t *seg_cls;         // (S) class of the segment, < 0 = inactive
+  float thr_i, thr_p;
+  int Ci, Cp;
+};
+
+// adjacency value of M4:210-233 at (p, k): exp(-(d/dmax)^2 / 2), zero on the diagonal, NaN when dmax == 0 (0/0)
+__device__ __forceinline__ float sim_value(const float *__restrict__ f, int C, int p, int k, float dmax) {
+  if (dmax == 0.f) return __builtin_nanf("");
+  if (p == k) return 0.f;
+  float s = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const float d = f[(long)p * C + c] - f[(long)k * C + c];
+    s = fmaf(d, d, s);
+  }
+  const float a = sqrtf(s) / dmax;
+  return expf(-(a * a) / 2.f);
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void ballquery_sim_kernel(int n, float radius2, int cap, const float *__restrict__ xyz,
+                                                            const int32_t *__restrict__ seg_of,
+                                                            const int32_t *__restrict__ seg_offsets, SimArgs sa,
+                                                            const BqGrid *__restrict__ g,
+                                                            const int32_t *__restrict__ cell_start,
+                                                            const int32_t *__restrict__ sorted, int32_t *__restrict__ idx,
+                                                            int32_t *__restrict__ start_len, int32_t *__restrict__ counts,
+                                                            int32_t *__restrict__ flags) {
+  __shared__ int hits[4][1024];
+  const int lane = lane_id(), wave = wave_id();
+  const int p = blockIdx.x * 4 + wave;
+  if (p >= n) return;
+  const int sg = seg_of[p];
+  if (sa.seg_cls[sg] < 0) {
+    if (!FILL && lane == 0) counts[p] = 0;
+    return;
+  }
+  const float ox = xyz[p * 3], oy = xyz[p * 3 + 1], oz = xyz[p * 3 + 2];
+  const float dmi = sqrtf(sa.dmi2[sg]), dmp = sqrtf(sa.dmp2[sg]);
+  long s0 = 0;
+  int limit = cap;
+  if (FILL) {
+    s0 = start_len[p * 2];
+    limit = start_len[p * 2 + 1];
+    if (limit <= 0) return;
+  }
+  auto accept = [&](int kk) -> bool {
+    if (!(sqdist3s(ox, oy, oz, xyz[kk * 3], xyz[kk * 3 + 1], xyz[kk * 3 + 2]) < radius2)) return false;
+    if (!(sim_value(sa.fi, sa.Ci, p, kk, dmi) > sa.thr_i)) return false;
+    return sim_value(sa.fp, sa.Cp, p, kk, dmp) > sa.thr_p;
+  };
+  int cx, cy, cz;
+  bq_cell_of(g, ox, oy, oz, cx, cy, cz);
+  int rlo = 0, rhi = 0;
+  if (lane < 9) {
+    const int yy = cy + lane % 3 - 1, zz = cz + lane / 3 - 1;
+    if (yy >= 0 && yy < g->dy && zz >= 0 && zz < g->dz) {
+      const int rowc = ((sg * g->dz + zz) * g->dy + yy) * g->dx;
+      rlo = cell_start[rowc + max(cx - 1, 0)];
+      rhi = cell_start[rowc + min(cx + 1, g->dx - 1) + 1];
+    }
+  }
+  int tot = rhi - rlo;
+#pragma unroll
+  for (int o = 8; o >= 1; o >>= 1) tot += __shfl_xor(tot, o);
+  tot = readlane_i(tot, 0);
+  int cnt = 0;
+  int *hb = hits[wave];
+  if (tot <= 1024) {
+    for (int rr = 0; rr < 9; ++rr) {
+      const int lo = readlane_i(rlo, rr), hi = readlane_i(rhi, rr);
+      for (int base = lo; base < hi; base += 64) {
+        const int t = base + lane;
+        int kk = 0;
+        bool hit = false;
+        if (t < hi) {
+          kk = sorted[t];
+          hit = accept(kk);
+        }
+        const unsigned long long mask = __ballot(hit);
+        if (FILL && hit) hb[cnt + __popcll(mask & ((1ull << lane) - 1ull))] = kk;
+        cnt += __popcll(mask);
+      }
+    }
+    if (!FILL) {
+      if (lane == 0) {
+        counts[p] = cnt < cap ? cnt : cap;
+        if (cnt >= cap) atomicOr(flags, 1);
+      }
+      return;
+    }
+    __builtin_amdgcn_wave_barrier();
+    bq_sort_lds(hb, cnt, lane);
+    for (int i = lane; i < min(cnt, limit); i += 64) idx[s0 + i] = hb[i];
+    return;
+  }
+  // crowded neighbourhood: scan the whole segment (ascending by construction)
+  const int start = seg_offsets[sg], end = seg_offsets[sg + 1];
+  for (int base = start; base < end && cnt < limit; base += 64) {
+    const int k = base + lane;
+    const bool hit = k < end && accept(k);
+    const unsigned long long mask = __ballot(hit);
+    if (FILL) {
+      const int slot = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+      if (hit && slot < limit) idx[s0 + slot] = k;
+    }
+    cnt += __popcll(mask);
+  }
+  if (!FILL && lane == 0) {
+    counts[p] = cnt < cap ? cnt : cap;
+    if (cnt >= cap) atomicOr(flags, 1);
+  }
+}
+
 // ---------------------------------------------------------------- segment ops
 // sec_mean.cu:13-85, roipool.cu:12-32.  OP 0 sec_mean (sum of v/count), 1 min, 2 max,
 // 3 global_avg_pool (sum then divide).  Row order is kept sequential per plane -> bit-exact.
@@ -521,6 +734,95 @@ GCN_EXPORT int gcn_ballquery_batch_p(int n, int meanActive, float radius, const 
   GCN_HIP(hipMemcpyAsync(total_host, count_ws + n, sizeof(int), hipMemcpyDeviceToHost, st));
   GCN_HIP(hipStreamSynchronize(st));
   return GCN_OK;
+}
+
+GCN_EXPORT int gcn_segment_diameter2(int n, int C, const float *feats, const int32_t *seg_offsets,
+                                     const int32_t *seg_cls, int S, float *xx_ws, int32_t *tile_ws, float *dmax2,
+                                     void *stream) {
+  GCN_REQUIRE(n >= 0 && S >= 0 && C > 0 && C % 16 == 0, "gcn_segment_diameter2: C must be a positive multiple of 16 (zero-pad the rows), got C=%d", C);
+  if (n == 0 || S == 0) return GCN_OK;
+  GCN_REQUIRE(feats && seg_offsets && seg_cls && xx_ws && tile_ws && dmax2, "gcn_segment_diameter2: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  GCN_HIP(hipMemsetAsync(dmax2, 0, sizeof(float) * (size_t)S, st));
+  row_sqnorm_kernel<<<cdiv(n, 256), 256, 0, st>>>(n, C, feats, xx_ws);
+  seg_tile_prefix_kernel<<<1, 1, 0, st>>>(S, seg_offsets, seg_cls, tile_ws);
+  seg_diameter_kernel<<<n / 64 + S, 256, 0, st>>>(S, C, feats, xx_ws, seg_offsets, tile_ws, (unsigned int *)dmax2);
+  return check_launch("seg_diameter_kernel");
+}
+
+GCN_EXPORT long gcn_ballquery_sim_ws_bytes(int n) {
+  if (n < 0) return -1;
+  const long max_cells = 16L * n + 4096;
+  return 64 + 4 * (2 * max_cells + 1 + 2L * n) + 64;
+}
+
+static int ballquery_sim_args(int n, const float *xyz, const int32_t *seg_of, const int32_t *seg_offsets,
+                              const int32_t *seg_cls, int S, const float *feat_inst, int Ci, const float *dmax2_inst,
+                              const float *feat_para, int Cp, const float *dmax2_para, const int32_t *start_len,
+                              const int32_t *count_ws, const void *grid_ws, const char *who) {
+  GCN_REQUIRE(n >= 0 && S >= 1 && Ci > 0 && Cp > 0, "%s: bad shape", who);
+  GCN_REQUIRE(n == 0 || (xyz && seg_of && seg_offsets && seg_cls && feat_inst && dmax2_inst && feat_para && dmax2_para &&
+                         start_len && count_ws && grid_ws), "%s: null pointer", who);
+  return GCN_OK;
+}
+
+GCN_EXPORT int gcn_ballquery_sim_count(int n, float radius, const float *xyz, const int32_t *seg_of,
+                                       const int32_t *seg_offsets, const int32_t *seg_cls, int S,
+                                       const float *feat_inst, int Ci, const float *dmax2_inst, float thr_inst,
+                                       const float *feat_para, int Cp, const float *dmax2_para, float thr_para,
+                                       int32_t *start_len, int32_t *count_ws, void *grid_ws, int *total_host,
+                                       int *capped_host, void *stream) {
+  GCN_REQUIRE(total_host && capped_host, "gcn_ballquery_sim_count: null result pointer");
+  *total_host = 0;
+  *capped_host = 0;
+  int rc = ballquery_sim_args(n, xyz, seg_of, seg_offsets, seg_cls, S, feat_inst, Ci, dmax2_inst, feat_para, Cp,
+                              dmax2_para, start_len, count_ws, grid_ws, "gcn_ballquery_sim_count");
+  if (rc || n == 0) return rc;
+  GCN_REQUIRE(radius > 0.f, "gcn_ballquery_sim_count: radius must be positive");
+  hipStream_t st = (hipStream_t)stream;
+  const int max_cells = 16 * n + 4096;
+  BqGrid *g = (BqGrid *)grid_ws;
+  int32_t *cell_start = (int32_t *)((char *)grid_ws + 64), *cursor = cell_start + max_cells + 1;
+  int32_t *cell_of_pt = cursor + max_cells, *sorted = cell_of_pt + n;
+  int32_t *flags = (int32_t *)((char *)grid_ws + 56);           // inside the 64-byte header, behind the 56-byte BqGrid
+  GCN_HIP(hipMemsetAsync(g, 0x00, 64, st));
+  GCN_HIP(hipMemsetAsync(&g->bmin[0], 0xff, 12, st));
+  GCN_HIP(hipMemsetAsync(cell_start, 0, sizeof(int32_t) * (size_t)(max_cells + 1), st));
+  bq_bbox_kernel<<<256, 256, 0, st>>>(n, xyz, g);
+  bq_setup_kernel<<<1, 1, 0, st>>>(g, radius, S, max_cells);
+  bq_cell_count_kernel<<<cdiv(n, 256), 256, 0, st>>>(n, xyz, seg_of, g, cell_of_pt, cell_start);
+  bq_cell_scan_kernel<<<1, 1024, 0, st>>>(g, cell_start, cursor);
+  bq_cell_fill_kernel<<<cdiv(n, 256), 256, 0, st>>>(n, cell_of_pt, cursor, sorted);
+  SimArgs sa{feat_inst, feat_para, dmax2_inst, dmax2_para, seg_cls, thr_inst, thr_para, Ci, Cp};
+  ballquery_sim_kernel<false><<<cdiv(n, 4), 256, 0, st>>>(n, radius * radius, 3000, xyz, seg_of, seg_offsets, sa, g, cell_start,
+                                                          sorted, nullptr, start_len, count_ws, flags);
+  scan_counts_kernel<<<1, 1024, 0, st>>>(n, count_ws, start_len);
+  rc = check_launch("ballquery_sim_kernel<count>");
+  if (rc) return rc;
+  GCN_HIP(hipMemcpyAsync(total_host, count_ws + n, sizeof(int), hipMemcpyDeviceToHost, st));
+  GCN_HIP(hipMemcpyAsync(capped_host, flags, sizeof(int), hipMemcpyDeviceToHost, st));
+  GCN_HIP(hipStreamSynchronize(st));
+  return GCN_OK;
+}
+
+GCN_EXPORT int gcn_ballquery_sim_fill(int n, float radius, const float *xyz, const int32_t *seg_of,
+                                      const int32_t *seg_offsets, const int32_t *seg_cls, int S,
+                                      const float *feat_inst, int Ci, const float *dmax2_inst, float thr_inst,
+                                      const float *feat_para, int Cp, const float *dmax2_para, float thr_para,
+                                      const int32_t *start_len, int32_t *idx, void *grid_ws, void *stream) {
+  int rc = ballquery_sim_args(n, xyz, seg_of, seg_offsets, seg_cls, S, feat_inst, Ci, dmax2_inst, feat_para, Cp,
+                              dmax2_para, start_len, start_len, grid_ws, "gcn_ballquery_sim_fill");
+  if (rc || n == 0) return rc;
+  GCN_REQUIRE(idx, "gcn_ballquery_sim_fill: idx is null");
+  hipStream_t st = (hipStream_t)stream;
+  const int max_cells = 16 * n + 4096;
+  BqGrid *g = (BqGrid *)grid_ws;
+  int32_t *cell_start = (int32_t *)((char *)grid_ws + 64), *cursor = cell_start + max_cells + 1;
+  int32_t *cell_of_pt = cursor + max_cells, *sorted = cell_of_pt + n;
+  SimArgs sa{feat_inst, feat_para, dmax2_inst, dmax2_para, seg_cls, thr_inst, thr_para, Ci, Cp};
+  ballquery_sim_kernel<true><<<cdiv(n, 4), 256, 0, st>>>(n, radius * radius, 3000, xyz, seg_of, seg_offsets, sa, g, cell_start,
+                                                         sorted, idx, const_cast<int32_t *>(start_len), nullptr, nullptr);
+  return check_launch("ballquery_sim_kernel<fill>");
 }
 
 GCN_EXPORT int gcn_sec_op(int op, int P, int C, const float *inp, const int32_t *offsets, float *out, void *stream) {

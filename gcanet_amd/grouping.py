@@ -12,8 +12,11 @@ Differences that do not change results:
 Reference quirk kept: proposals index points WITHIN their cloud (object_idxs are per-cloud positions,
 M4:1270), although the features they are applied to are flattened over the batch.
 """
+import ctypes as C
+
 import torch
 
+from . import _lib
 from .softgroup.ops import (ball_query, global_avg_pool, hierarchical_aggregation, sec_max, sec_min, voxelization,
                             voxelization_idx)
 
@@ -77,6 +80,94 @@ def forward_grouping(semantic_scores, pt_offsets, batch_idxs, coords_float, type
     if proposals_idx_list:
         return torch.cat(proposals_idx_list, dim=0), torch.cat(proposals_offset_list)
     return torch.zeros((0, 2), dtype=torch.int32), torch.zeros((0,), dtype=torch.int32)
+
+
+def _pad16(x):
+    """Rows zero-padded to a multiple of 16 columns (zeros leave every distance unchanged)."""
+    c = x.shape[1]
+    return x.contiguous() if c % 16 == 0 else torch.nn.functional.pad(x, (0, 16 - c % 16)).contiguous()
+
+
+def forward_grouping_device(semantic_scores, pt_offsets, batch_idxs, coords_float, type_per_point, param_per_point,
+                            feature_per_point, semantic_classes=10, training_mode='train', using_set_aggr=False,
+                            radius=0.03, similarity_threshold_inst=0.989, similarity_threshold_para=0.0, mean_active=300,
+                            min_npoint=50, to_cpu=True):
+    """forward_grouping (M4:1123-1295) with every (cloud, class) subset handled at once on the device
+    (csrc/softgroup.hip: seg_diameter / ballquery_sim kernels, csrc/cluster_dev.hip):
+
+      * points are sorted by cloud*P + class (stable, so a subset keeps the ascending order of `nonzero()`),
+        subsets below `min_npoint` are switched off instead of skipped by a Python `continue`;
+      * the two (n,n) similarity matrices of compute_batch_adjacency_matrix are never formed: only their global
+        maximum is needed (the per-subset diameter, one MFMA Gram pass) and the exponentials are evaluated at the
+        pairs inside the search radius -- the same predicate `adj_inst > thr_inst and adj_para > thr_para`;
+      * the neighbour lists are sized exactly (count, then fill), which is what the reference's meanActive retry
+        loop (functions.py:460-474) converges to, so `mean_active` does not matter here;
+      * connected components + the reference's BFS member order + the kept/primary merge run on the device;
+        two host synchronisations in total (list total, result sizes) instead of several per subset.
+
+    Same return value as forward_grouping (CPU int32 tensors; device tensors with to_cpu=False).  Pairs whose
+    similarity lies within float rounding of a threshold can fall on the other side than with the dense path, which
+    takes its distances from torch.cdist's matmul form; the reference's own result moves with the torch version there.
+    If a neighbour list hits the 3000 cap (bfs_cluster.cu:54: lists stop being symmetric) or set aggregation is
+    requested (evaluation only), the literal path is taken."""
+    if training_mode != 'train' and using_set_aggr:
+        return forward_grouping(semantic_scores, pt_offsets, batch_idxs, coords_float, type_per_point, param_per_point,
+                                feature_per_point, semantic_classes, training_mode, using_set_aggr, radius,
+                                similarity_threshold_inst, similarity_threshold_para, mean_active, min_npoint)
+    _lib.require_cuda(semantic_scores, pt_offsets, coords_float, param_per_point, feature_per_point)
+    B, N = type_per_point.shape[0], type_per_point.shape[1]
+    P = int(semantic_classes)
+    assert 1 <= P <= 10, "hierarchical_aggregation.cpp:7-8 knows 10 classes"
+    dev = semantic_scores.device
+    n, S = B * N, B * P
+    labels = semantic_scores.softmax(dim=-1).view(n, -1).argmax(dim=1)
+    seg_key = torch.arange(B, device=dev).repeat_interleave(N) * P + labels
+    seg_sorted, order = torch.sort(seg_key, stable=True)
+    counts = torch.bincount(seg_sorted, minlength=S)
+    seg_offsets = torch.cat([counts.new_zeros(1), counts.cumsum(0)]).int()
+    seg_cls = torch.where(counts >= min_npoint, torch.arange(S, device=dev) % P, torch.full_like(counts, -1)).int()
+    seg_of = seg_sorted.int()
+    shifted = (coords_float.view(n, -1).float() + pt_offsets.view(n, -1).float())[order].contiguous()
+    fi = _pad16(feature_per_point.reshape(n, -1).float()[order])
+    fp = _pad16(param_per_point.reshape(n, -1).float()[order])
+    point_index = (order % N).int()
+
+    lib = _lib.lib()
+    st = _lib.stream_of(shifted)
+    xx = torch.empty(n, dtype=torch.float32, device=dev)
+    tiles = torch.empty(S + 1, dtype=torch.int32, device=dev)
+    dm = torch.empty(2, S, dtype=torch.float32, device=dev)
+    with torch.cuda.device_of(shifted):
+        for f, d in ((fi, dm[0]), (fp, dm[1])):
+            _lib.call("gcn_segment_diameter2", n, f.shape[1], _lib.ptr(f), _lib.ptr(seg_offsets), _lib.ptr(seg_cls), S,
+                      _lib.ptr(xx), _lib.ptr(tiles), _lib.ptr(d), st)
+        grid_ws = torch.empty(lib.gcn_ballquery_sim_ws_bytes(n), dtype=torch.uint8, device=dev)
+        start_len = torch.empty(n, 2, dtype=torch.int32, device=dev)
+        count_ws = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        total, capped = C.c_int(0), C.c_int(0)
+        bq = (n, float(radius), _lib.ptr(shifted), _lib.ptr(seg_of), _lib.ptr(seg_offsets), _lib.ptr(seg_cls), S,
+              _lib.ptr(fi), fi.shape[1], _lib.ptr(dm[0]), float(similarity_threshold_inst),
+              _lib.ptr(fp), fp.shape[1], _lib.ptr(dm[1]), float(similarity_threshold_para), _lib.ptr(start_len))
+        _lib.call("gcn_ballquery_sim_count", *bq, _lib.ptr(count_ws), _lib.ptr(grid_ws), C.addressof(total),
+                  C.addressof(capped), st)
+        if capped.value:
+            return forward_grouping(semantic_scores, pt_offsets, batch_idxs, coords_float, type_per_point,
+                                    param_per_point, feature_per_point, semantic_classes, training_mode, using_set_aggr,
+                                    radius, similarity_threshold_inst, similarity_threshold_para, mean_active, min_npoint)
+        nbr = torch.empty(max(total.value, 1), dtype=torch.int32, device=dev)
+        _lib.call("gcn_ballquery_sim_fill", *bq, _lib.ptr(nbr), _lib.ptr(grid_ws), st)
+        ws = torch.empty(lib.gcn_cluster_components_ws_bytes(n), dtype=torch.uint8, device=dev)
+        cluster_idxs = torch.empty(n, 2, dtype=torch.int32, device=dev)
+        cluster_offsets = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        nsum, ncl = C.c_int(0), C.c_int(0)
+        _lib.call("gcn_cluster_components", n, _lib.ptr(nbr), _lib.ptr(start_len), _lib.ptr(seg_of),
+                  _lib.ptr(seg_offsets), _lib.ptr(seg_cls), S, _lib.ptr(point_index), _lib.ptr(ws),
+                  _lib.ptr(cluster_idxs), _lib.ptr(cluster_offsets), C.addressof(nsum), C.addressof(ncl), st)
+    if ncl.value == 0:
+        z = torch.zeros((0, 2), dtype=torch.int32), torch.zeros((0,), dtype=torch.int32)
+        return z if to_cpu else (z[0].to(dev), z[1].to(dev))
+    pi, po = cluster_idxs[:nsum.value], cluster_offsets[:ncl.value + 1]
+    return (pi.cpu(), po.cpu()) if to_cpu else (pi, po)
 
 
 def clusters_voxelization(clusters_idx, clusters_offset, feats, coords, scale, spatial_shape, rand_quantize=False,

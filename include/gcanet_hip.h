@@ -142,6 +142,42 @@ int gcn_ballquery_batch_p(int n, int meanActive, float radius, const float *xyz,
                           float thr_para, int32_t *idx, int32_t *start_len, int32_t *count_ws,
                           int nbatch, void *grid_ws, int *total_host, void *stream);
 
+/* ---- forward_grouping on the device (models/dgcnn-hais-concat-direct-4.py:1123-1295) ----
+ * The reference loops over (cloud, class) subsets; per subset it builds two dense (n,n) similarity matrices
+ * (compute_batch_adjacency_matrix, :210-233), calls ballquery_batch_p (bfs_cluster.cu:18-77) and then the HOST BFS of
+ * hierarchical_aggregation.cpp:20-131.  These entry points do all subsets ("segments": points sorted by
+ * cloud*P + class) at once and never form an (n,n) tensor.
+ *
+ * gcn_segment_diameter2: dmax2[s] = max_{i != j in segment s} ||f_i - f_j||^2 (the `max` of :223-225 squared; its `min`
+ * is 0, the zeroed diagonal).  feats (n,C) rows in segment order, C a multiple of 16 (zero-pad), seg_offsets (S+1),
+ * seg_cls (S) (< 0: segment skipped, dmax2 = 0), xx_ws (n) floats, tile_ws (S+1) ints. */
+int gcn_segment_diameter2(int n, int C, const float *feats, const int32_t *seg_offsets, const int32_t *seg_cls, int S,
+                          float *xx_ws, int32_t *tile_ws, float *dmax2, void *stream);
+long gcn_ballquery_sim_ws_bytes(int n);
+/* ballquery_batch_p with `adj_inst[p][k] > thr_inst && adj_para[p][k] > thr_para` evaluated from the feature rows:
+ * adj = exp(-(||f_p - f_k|| / dmax)^2 / 2), 0 for p == k, NaN (never accepted) when dmax == 0.  Two calls: _count
+ * fills start_len (n,2) = (start, count capped at 3000 as bfs_cluster.cu:54) and returns the total and whether any list
+ * hit the cap (synchronises); the caller allocates idx (total) and calls _fill with the same arguments and workspace.
+ * Lists are ascending, as the reference's scan order. */
+int gcn_ballquery_sim_count(int n, float radius, const float *xyz, const int32_t *seg_of, const int32_t *seg_offsets,
+                            const int32_t *seg_cls, int S, const float *feat_inst, int Ci, const float *dmax2_inst,
+                            float thr_inst, const float *feat_para, int Cp, const float *dmax2_para, float thr_para,
+                            int32_t *start_len, int32_t *count_ws, void *grid_ws, int *total_host, int *capped_host,
+                            void *stream);
+int gcn_ballquery_sim_fill(int n, float radius, const float *xyz, const int32_t *seg_of, const int32_t *seg_offsets,
+                           const int32_t *seg_cls, int S, const float *feat_inst, int Ci, const float *dmax2_inst,
+                           float thr_inst, const float *feat_para, int Cp, const float *dmax2_para, float thr_para,
+                           const int32_t *start_len, int32_t *idx, void *grid_ws, void *stream);
+/* hierarchical_aggregation (hierarchical_aggregation.cpp:20-131 + the kept/primary merge of functions.py:52-72,
+ * using_set_aggr = False) for all segments on the device: components of the (symmetric) neighbour lists, members in the
+ * reference's BFS dequeue order, segment by segment, kept fragments before primaries.  cluster_idxs (n,2) gets
+ * (cluster id, point_index[member]) rows, cluster_offsets (n+1); *sum_host rows / *ncluster_host clusters are valid
+ * (synchronises).  seg_cls (S): semantic class 0..9 of the segment or < 0 to skip it.  n < 2^20. */
+long gcn_cluster_components_ws_bytes(int n);
+int gcn_cluster_components(int n, const int32_t *nbr, const int32_t *start_len, const int32_t *seg_of,
+                           const int32_t *seg_offsets, const int32_t *seg_cls, int S, const int32_t *point_index,
+                           void *ws, int32_t *cluster_idxs, int32_t *cluster_offsets, int *sum_host, int *ncluster_host,
+                           void *stream);
 /* Device scratch for the uniform-grid path of gcn_ballquery_batch_p (easy form, n >= 2048): pass it as grid_ws
  * (NULL selects the brute-force scan).  nbatch = number of batch segments (len(batch_offsets) - 1). */
 long gcn_ballquery_grid_ws_bytes(int n);

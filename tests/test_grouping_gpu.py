@@ -96,3 +96,80 @@ def test_clusters_voxelization_and_global_pool(dev):
     pooled = global_pool(vf, vc[:, 0])
     ref = np.stack([vf[vc[:, 0] == c].mean(0).cpu().numpy() for c in range(3)])
     np.testing.assert_allclose(pooled.cpu().numpy(), ref, rtol=1e-5, atol=1e-6)
+
+
+def _blob_scene(seed, B, N, P, nblob, sizes=None, extent=0.0):
+    """Clouds made of tight blobs; blob b carries class b % P and a one-hot-ish embedding, so that the similarity
+    predicate is far from its thresholds (same blob: ~1, different blobs: ~0.6) and parity cannot hinge on rounding."""
+    rng = np.random.default_rng(seed)
+    centers = rng.random((B, nblob, 3)).astype(np.float32)
+    if sizes is None:
+        which = rng.integers(0, nblob, (B, N))
+    else:
+        which = np.stack([rng.permutation(np.repeat(np.arange(nblob), sizes)) for _ in range(B)])
+    xyz = centers[np.arange(B)[:, None], which] + 0.004 * rng.standard_normal((B, N, 3))
+    if extent > 0:      # stretch every blob into a thin sheet so that a breadth-first search needs many levels
+        dirs = rng.standard_normal((B, nblob, 2, 3))
+        uv = rng.random((B, N, 2)) * np.array([extent, extent / 4])
+        xyz = xyz + np.einsum("bnk,bnkd->bnd", uv, dirs[np.arange(B)[:, None], which] /
+                              np.linalg.norm(dirs[np.arange(B)[:, None], which], axis=-1, keepdims=True))
+    xyz = xyz.astype(np.float32)
+    sem = rng.standard_normal((B * N, P)).astype(np.float32) * 0.3 + 6 * np.eye(P, dtype=np.float32)[(which % P).reshape(-1)]
+    off = (0.001 * rng.standard_normal((B * N, 3))).astype(np.float32)
+    bidx = np.repeat(np.arange(B), N).astype(np.int64)
+    par = (rng.standard_normal((B, N, 22)) * 0.01).astype(np.float32)
+    E = 16
+    feat = (np.eye(E, dtype=np.float32)[which % E] + 0.01 * rng.standard_normal((B, N, E))).astype(np.float32)
+    return xyz, sem, off, bidx, par, feat
+
+
+@pytest.mark.parametrize("case", ["small", "kept_and_primary", "sheets"])
+def test_forward_grouping_device_matches_oracle(dev, case):
+    """The fused device path (no (n,n) matrices, device components + BFS order) against the literal CPU restatement."""
+    from gcanet_amd.grouping import forward_grouping_device
+    if case == "small":
+        B, N, P = 2, 600, 3
+        xyz, sem, off, bidx, par, feat = _blob_scene(0, B, N, P, 6)
+        kw = dict(min_npoint=20)
+    elif case == "sheets":
+        B, N, P = 2, 4000, 5
+        sizes = [1000, 500, 300, 300, 900, 100, 400, 100, 200, 200]
+        xyz, sem, off, bidx, par, feat = _blob_scene(2, B, N, P, 10, sizes, extent=0.6)
+        kw = dict(min_npoint=50)
+    else:
+        # class 4: mean 2303 -> dropped below 116 points, "kept" below 691, primary above; classes 0/1 always primary
+        B, N, P = 2, 3200, 5
+        sizes = [900, 150, 60, 400, 800, 90, 200, 130, 250, 220]      # blob b -> class b % 5
+        xyz, sem, off, bidx, par, feat = _blob_scene(1, B, N, P, 10, sizes)
+        kw = dict(min_npoint=50)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    pi, po = forward_grouping_device(t(sem), t(off), t(bidx), t(xyz.reshape(-1, 3)), torch.zeros(B, N, P), t(par), t(feat),
+                                     semantic_classes=P, radius=0.03, similarity_threshold_inst=0.9,
+                                     similarity_threshold_para=0.0, mean_active=50, **kw)
+    rpi, rpo = _oracle_forward_grouping(sem, off, bidx, xyz.reshape(-1, 3), B, N, par, feat, P, 0.03, 0.9, 0.0, 50,
+                                        kw["min_npoint"])
+    assert rpo.size > 4, "test data produced no clusters"
+    np.testing.assert_array_equal(po.numpy(), rpo)
+    np.testing.assert_array_equal(pi.numpy(), rpi)
+
+
+def test_segment_diameter_matches_cdist(dev):
+    from gcanet_amd import _lib
+    rng = np.random.default_rng(3)
+    sizes = [1, 70, 0, 333, 64, 1000, 129]
+    n, C = sum(sizes), 32
+    f = torch.from_numpy(rng.standard_normal((n, C)).astype(np.float32)).to(dev)
+    offs = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int32, device=dev)
+    cls = torch.tensor([0, 1, 2, -1, 4, 5, 6], dtype=torch.int32, device=dev)
+    S = len(sizes)
+    xx = torch.empty(n, device=dev)
+    tiles = torch.empty(S + 1, dtype=torch.int32, device=dev)
+    out = torch.full((S,), -1.0, device=dev)
+    _lib.call("gcn_segment_diameter2", n, C, _lib.ptr(f), _lib.ptr(offs), _lib.ptr(cls), S, _lib.ptr(xx), _lib.ptr(tiles),
+              _lib.ptr(out), _lib.stream_of(f))
+    got = out.cpu().numpy()
+    fc = f.cpu().double()
+    for s in range(S):
+        a, b = int(offs[s]), int(offs[s + 1])
+        ref = 0.0 if (cls[s] < 0 or b - a < 2) else float(torch.cdist(fc[a:b], fc[a:b]).max() ** 2)
+        np.testing.assert_allclose(got[s], ref, rtol=2e-5, atol=1e-6)
