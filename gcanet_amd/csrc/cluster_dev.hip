@@ -23,37 +23,50 @@ __device__ __forceinline__ int ld_i(const int32_t *p) { return __hip_atomic_load
 __device__ __forceinline__ unsigned int ld_u(const unsigned int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_i(int32_t *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-__global__ void cc_init_kernel(int n, int32_t *__restrict__ parent, int32_t *__restrict__ csize, unsigned int *__restrict__ key,
+// parent = the smallest neighbour below the point (lists are ascending, so that is the first entry) -- already a forest
+// with parent < child that joins most of every component -- or the point itself
+__global__ void cc_init_kernel(int n, const int32_t *__restrict__ nbr, const int32_t *__restrict__ start_len,
+                               int32_t *__restrict__ parent, int32_t *__restrict__ csize, unsigned int *__restrict__ key,
                                int32_t *__restrict__ visited, int32_t *__restrict__ counters) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) { parent[i] = i; csize[i] = 0; key[i] = 0xFFFFFFFFu; visited[i] = 0; }
+  if (i < n) {
+    int par = i;
+    if (start_len[2 * i + 1] > 0) par = min(i, nbr[start_len[2 * i]]);
+    parent[i] = par; csize[i] = 0; key[i] = 0xFFFFFFFFu; visited[i] = 0;
+  }
   if (i < 8) counters[i] = 0;
 }
 
+// Root of x.  FRESH = false reads through the L1: a stale value is an ancestor that was valid earlier, the walk only
+// ever moves to smaller indices, and the compare-and-swap in the union is the arbiter (it returns the current parent
+// when the presumed root has been hooked meanwhile).
+template <bool FRESH>
 __device__ __forceinline__ int uf_find(int32_t *parent, int x) {
   for (;;) {
-    const int p = ld_i(parent + x);
+    const int p = FRESH ? ld_i(parent + x) : parent[x];
     if (p == x) return x;
-    const int gp = ld_i(parent + p);
+    const int gp = FRESH ? ld_i(parent + p) : parent[p];
     if (gp != p) st_i(parent + x, gp);          // path halving: any ancestor is a valid parent
     x = p;
   }
 }
 
-// wave per point, lanes across its neighbour list
+// wave per point, lanes across its neighbour list; the lists are symmetric, so the edges to smaller indices suffice
 __global__ __launch_bounds__(256) void cc_union_kernel(int n, const int32_t *__restrict__ nbr, const int32_t *__restrict__ start_len,
                                                        int32_t *parent) {
   const int p = blockIdx.x * 4 + wave_id();
   if (p >= n) return;
   const int s = start_len[2 * p], len = start_len[2 * p + 1];
-  for (int pos = lane_id(); pos < len; pos += 64) {
-    int a = uf_find(parent, p), b = uf_find(parent, nbr[s + pos]);
+  for (int pos = lane_id() + 1; pos < len; pos += 64) {          // entry 0 is the initial parent
+    const int v = nbr[s + pos];
+    if (v >= p) break;                                            // ascending list: nothing smaller follows
+    int a = uf_find<false>(parent, p), b = uf_find<false>(parent, v);
     while (a != b) {
       if (a < b) { const int t = a; a = b; b = t; }             // hook the larger root a under the smaller b
       const int old = atomicCAS(parent + a, a, b);
       if (old == a) break;
-      a = uf_find(parent, old);
-      b = uf_find(parent, b);
+      a = uf_find<false>(parent, old);
+      b = uf_find<false>(parent, b);
     }
   }
 }
@@ -61,7 +74,7 @@ __global__ __launch_bounds__(256) void cc_union_kernel(int n, const int32_t *__r
 __global__ void cc_flatten_kernel(int n, int32_t *parent, int32_t *__restrict__ comp, int32_t *__restrict__ csize) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const int r = uf_find(parent, i);
+  const int r = uf_find<true>(parent, i);
   comp[i] = r;
   atomicAdd(csize + r, 1);
 }
@@ -87,25 +100,6 @@ __global__ void cluster_classify_kernel(int n, const int32_t *__restrict__ comp,
   }
   const long W = n + 1;
   vals[i] = ks; vals[W + i] = ps; vals[2 * W + i] = ks > 0; vals[3 * W + i] = ps > 0;
-}
-
-// in-place exclusive scans of `rows` arrays of length m (one workgroup per array)
-__global__ __launch_bounds__(1024) void exscan_rows_kernel(int m, int32_t *__restrict__ vals) {
-  __shared__ int wtot[16];
-  int32_t *v = vals + (long)blockIdx.x * m;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int per = (m + 1023) / 1024;
-  const int a = min(tid * per, m), b = min(a + per, m);
-  int sum = 0;
-  for (int i = a; i < b; ++i) sum += v[i];
-  int inc = sum;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(inc, d); if (lane >= d) inc += y; }
-  if (lane == 63) wtot[wave] = inc;
-  __syncthreads();
-  int run = inc - sum;
-  for (int w = 0; w < wave; ++w) run += wtot[w];
-  for (int i = a; i < b; ++i) { const int c = v[i]; v[i] = run; run += c; }
 }
 
 // every emitted root gets its slot and cluster id; components of two or more points go on the BFS work list
@@ -228,8 +222,11 @@ __global__ void cluster_emit_kernel(int n, const int32_t *__restrict__ counters,
     const int mid = (lo + hi) >> 1;
     if (cluster_offsets[mid] <= q) lo = mid; else hi = mid;
   }
+  // a queue slot stays unwritten only when the lists were not symmetric (truncated lists: the caller discards the
+  // result); never index with it
+  const unsigned int v = (unsigned int)out[q];
   cluster_idxs[2 * q] = lo;
-  cluster_idxs[2 * q + 1] = point_index[out[q]];
+  cluster_idxs[2 * q + 1] = v < (unsigned int)n ? point_index[v] : -1;
 }
 
 }  // namespace gcn
@@ -238,18 +235,17 @@ using namespace gcn;
 
 GCN_EXPORT long gcn_cluster_components_ws_bytes(int n) {
   if (n < 0) return -1;
-  return 4L * (20L * n + 64);
+  return 4L * (20L * n + 64 + 4L * scan_blocks(n + 1));
 }
 
 GCN_EXPORT int gcn_cluster_components(int n, const int32_t *nbr, const int32_t *start_len, const int32_t *seg_of,
                                       const int32_t *seg_offsets, const int32_t *seg_cls, int S,
                                       const int32_t *point_index, void *ws, int32_t *cluster_idxs,
-                                      int32_t *cluster_offsets, int *sum_host, int *ncluster_host, void *stream) {
-  GCN_REQUIRE(sum_host && ncluster_host, "gcn_cluster_components: null result pointer");
-  *sum_host = 0;
-  *ncluster_host = 0;
+                                      int32_t *cluster_offsets, int32_t *counts, void *stream) {
+  GCN_REQUIRE(counts, "gcn_cluster_components: counts is null");
   GCN_REQUIRE(n >= 0 && n < (1 << 20) && S >= 1, "gcn_cluster_components: n=%d must be below 2^20 (queue rank is a 20-bit key field)", n);
   hipStream_t st = (hipStream_t)stream;
+  GCN_HIP(hipMemsetAsync(counts, 0, 2 * sizeof(int32_t), st));
   if (n == 0) return GCN_OK;
   GCN_REQUIRE(start_len && seg_of && seg_offsets && seg_cls && point_index && ws && cluster_idxs && cluster_offsets,
               "gcn_cluster_components: null pointer");
@@ -259,22 +255,17 @@ GCN_EXPORT int gcn_cluster_components(int n, const int32_t *nbr, const int32_t *
   unsigned int *key = (unsigned int *)(base + n);
   int32_t *out = (int32_t *)key + n, *work = out + n;           // 3n
   int32_t *vals = work + 3L * n, *scan = vals + 4L * (n + 1);   // 2 x 4(n+1)
-  cc_init_kernel<<<cdiv(n, 256), 256, 0, st>>>(n, parent, csize, key, visited, counters);
+  int32_t *bsum = scan + 4L * (n + 1);
+  cc_init_kernel<<<cdiv(n, 256), 256, 0, st>>>(n, nbr, start_len, parent, csize, key, visited, counters);
   cc_union_kernel<<<cdiv(n, 4), 256, 0, st>>>(n, nbr, start_len, parent);
   cc_flatten_kernel<<<cdiv(n, 256), 256, 0, st>>>(n, parent, comp, csize);
   cluster_classify_kernel<<<cdiv(n + 1, 256), 256, 0, st>>>(n, comp, csize, seg_of, seg_cls, vals);
   GCN_HIP(hipMemcpyAsync(scan, vals, sizeof(int32_t) * 4 * (size_t)(n + 1), hipMemcpyDeviceToDevice, st));
-  exscan_rows_kernel<<<4, 1024, 0, st>>>(n + 1, scan);
+  exscan_rows(st, 4, n + 1, scan, bsum);
   cluster_offsets_kernel<<<cdiv(n, 256), 256, 0, st>>>(n, comp, csize, seg_of, seg_offsets, vals, scan, cluster_offsets, out,
                                                        visited, work, counters);
   cluster_bfs_kernel<<<512, 1024, 0, st>>>(nbr, start_len, work, counters, key, visited, base, out);
   cluster_emit_kernel<<<cdiv(n, 256), 256, 0, st>>>(n, counters, cluster_offsets, out, point_index, cluster_idxs);
-  int rc = check_launch("cluster kernels");
-  if (rc) return rc;
-  int host[2];
-  GCN_HIP(hipMemcpyAsync(host, counters + 2, sizeof(host), hipMemcpyDeviceToHost, st));
-  GCN_HIP(hipStreamSynchronize(st));
-  *sum_host = host[0];
-  *ncluster_host = host[1];
-  return GCN_OK;
+  GCN_HIP(hipMemcpyAsync(counts, counters + 2, 2 * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+  return check_launch("cluster kernels");
 }

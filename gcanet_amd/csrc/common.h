@@ -60,6 +60,79 @@ __device__ __forceinline__ float wave_shr1_f(float lane0_val, float v) {
 
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// ---- device-wide exclusive scan of int32 rows (three small launches; every access coalesced) ----
+// rows arrays of length m, laid out v + row*m; bsum: rows * scan_blocks(m) ints of scratch.  copy (optional, same
+// layout as v) receives the same result.  4096 elements per workgroup.
+inline int scan_blocks(long m) { return (int)((m + 4095) / 4096); }
+
+__device__ __forceinline__ int block_exscan_1024(int sum, int *wtot, int &total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int inc = sum;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(inc, d); if (lane >= d) inc += y; }
+  if (lane == 63) wtot[wave] = inc;
+  __syncthreads();
+  int run = inc - sum, tot = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) { const int t = wtot[w]; run += (w < wave) ? t : 0; tot += t; }
+  total = tot;
+  __syncthreads();
+  return run;
+}
+
+static __global__ __launch_bounds__(1024) void scan_block_sums_kernel(int m, const int32_t *__restrict__ v, int32_t *__restrict__ bsum) {
+  __shared__ int wtot[16];
+  const int32_t *row = v + (long)blockIdx.y * m;
+  const int base = blockIdx.x * 4096 + threadIdx.x * 4;
+  int s = 0;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) s += (base + e < m) ? row[base + e] : 0;
+  int total;
+  block_exscan_1024(s, wtot, total);
+  if (threadIdx.x == 0) bsum[blockIdx.y * gridDim.x + blockIdx.x] = total;
+}
+
+static __global__ __launch_bounds__(1024) void scan_block_offsets_kernel(int nb, int32_t *__restrict__ bsum) {
+  __shared__ int wtot[16];
+  int32_t *row = bsum + (long)blockIdx.x * nb;
+  int carry = 0;
+  for (int b0 = 0; b0 < nb; b0 += 1024) {
+    const int i = b0 + threadIdx.x;
+    const int c = i < nb ? row[i] : 0;
+    int total;
+    const int ex = block_exscan_1024(c, wtot, total);
+    if (i < nb) row[i] = carry + ex;
+    carry += total;
+  }
+}
+
+static __global__ __launch_bounds__(1024) void scan_apply_kernel(int m, int32_t *__restrict__ v, const int32_t *__restrict__ bsum,
+                                                                 int32_t *__restrict__ copy) {
+  __shared__ int wtot[16];
+  int32_t *row = v + (long)blockIdx.y * m;
+  const int base = blockIdx.x * 4096 + threadIdx.x * 4;
+  int c[4], s = 0;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { c[e] = (base + e < m) ? row[base + e] : 0; s += c[e]; }
+  int total;
+  int run = block_exscan_1024(s, wtot, total) + bsum[blockIdx.y * gridDim.x + blockIdx.x];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    if (base + e < m) {
+      row[base + e] = run;
+      if (copy) copy[(long)blockIdx.y * m + base + e] = run;
+    }
+    run += c[e];
+  }
+}
+
+inline void exscan_rows(hipStream_t st, int rows, int m, int32_t *v, int32_t *bsum, int32_t *copy = nullptr) {
+  const int nb = scan_blocks(m);
+  scan_block_sums_kernel<<<dim3(nb, rows), 1024, 0, st>>>(m, v, bsum);
+  scan_block_offsets_kernel<<<rows, 1024, 0, st>>>(nb, bsum);
+  scan_apply_kernel<<<dim3(nb, rows), 1024, 0, st>>>(m, v, bsum, copy);
+}
+
 // Zero up to three device spans with as few hipMemsetAsync calls as possible: spans that are adjacent in memory
 // (the Python side allocates the small per-call accumulators back to back) collapse into one fill -- a fill of a few
 // hundred bytes costs ~4.5 us of GPU time like any other launch, and a training step had ~80 of them.

@@ -164,7 +164,8 @@ __device__ __forceinline__ float ord2f(unsigned int u) {
   return __uint_as_float(u ^ ((u >> 31) ? 0x80000000u : 0xFFFFFFFFu));
 }
 
-__global__ void bq_bbox_kernel(int n, const float *__restrict__ xyz, BqGrid *g) {
+__global__ __launch_bounds__(1024) void bq_bbox_kernel(int n, const float *__restrict__ xyz, BqGrid *g) {
+  __shared__ float red[16][6];
   float mn[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, mx[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
 #pragma unroll
@@ -173,7 +174,14 @@ __global__ void bq_bbox_kernel(int n, const float *__restrict__ xyz, BqGrid *g) 
   for (int a = 0; a < 3; ++a) {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) { mn[a] = fminf(mn[a], __shfl_xor(mn[a], o)); mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o)); }
-    if (lane_id() == 0) { atomicMin(&g->bmin[a], f2ord(mn[a])); atomicMax(&g->bmax[a], f2ord(mx[a])); }
+    if (lane_id() == 0) { red[threadIdx.x >> 6][a] = mn[a]; red[threadIdx.x >> 6][3 + a] = mx[a]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {          // same-address atomics serialise (~0.45 us each): one per block and component
+    const int a = threadIdx.x;
+    float v = red[0][a];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) v = a < 3 ? fminf(v, red[w][a]) : fmaxf(v, red[w][a]);
+    if (a < 3) atomicMin(&g->bmin[a], f2ord(v)); else atomicMax(&g->bmax[a - 3], f2ord(v));
   }
 }
 
@@ -206,33 +214,6 @@ __global__ void bq_cell_count_kernel(int n, const float *__restrict__ xyz, const
   const int c = ((batch_idxs[i] * g->dz + cz) * g->dy + cy) * g->dx + cx;
   cell_of_pt[i] = c;
   atomicAdd(cell_cnt + c, 1);
-}
-
-// exclusive scan of cnt[0..m) in place -> start, cnt[m] = total; m read from the grid header (one workgroup)
-__global__ __launch_bounds__(1024) void bq_cell_scan_kernel(const BqGrid *__restrict__ g, int32_t *__restrict__ cnt,
-                                                            int32_t *__restrict__ cursor) {
-  __shared__ int part[1024];
-  const int m = g->ncell, tid = threadIdx.x;
-  const int chunk = (m + 1023) / 1024;
-  const int lo = min(tid * chunk, m), hi = min(lo + chunk, m);
-  int s = 0;
-  for (int i = lo; i < hi; ++i) s += cnt[i];
-  part[tid] = s;
-  __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {
-    const int v = tid >= off ? part[tid - off] : 0;
-    __syncthreads();
-    part[tid] += v;
-    __syncthreads();
-  }
-  int run = part[tid] - s;
-  for (int i = lo; i < hi; ++i) {
-    const int c = cnt[i];
-    cnt[i] = run;
-    cursor[i] = run;
-    run += c;
-  }
-  if (tid == 1023) cnt[m] = part[1023];
 }
 
 __global__ void bq_cell_fill_kernel(int n, const int32_t *__restrict__ cell_of_pt, int32_t *__restrict__ cursor,
@@ -443,50 +424,64 @@ struct SimArgs {
   int Ci, Cp;
 };
 
-// adjacency value of M4:210-233 at (p, k): exp(-(d/dmax)^2 / 2), zero on the diagonal, NaN when dmax == 0 (0/0)
+// adjacency value of M4:210-233 at (p, k): exp(-(d/dmax)^2 / 2), zero on the diagonal, NaN when dmax == 0 (0/0).
+// Rows are 16-float multiples (64-byte aligned): four floats per load, summed in column order.
 __device__ __forceinline__ float sim_value(const float *__restrict__ f, int C, int p, int k, float dmax) {
   if (dmax == 0.f) return __builtin_nanf("");
   if (p == k) return 0.f;
+  const float4 *a = reinterpret_cast<const float4 *>(f + (long)p * C), *b = reinterpret_cast<const float4 *>(f + (long)k * C);
   float s = 0.f;
-  for (int c = 0; c < C; ++c) {
-    const float d = f[(long)p * C + c] - f[(long)k * C + c];
-    s = fmaf(d, d, s);
+  for (int c = 0; c < C / 4; ++c) {
+    const float4 x = a[c], y = b[c];
+    float d = x.x - y.x; s = fmaf(d, d, s);
+    d = x.y - y.y; s = fmaf(d, d, s);
+    d = x.z - y.z; s = fmaf(d, d, s);
+    d = x.w - y.w; s = fmaf(d, d, s);
   }
-  const float a = sqrtf(s) / dmax;
-  return expf(-(a * a) / 2.f);
+  const float a1 = sqrtf(s) / dmax;
+  return expf(-(a1 * a1) / 2.f);
 }
 
-template <bool FILL>
+// One pass: a wave collects the neighbours of its point (27 cells; the whole segment if those hold more than 1024
+// candidates), orders them ascending, reserves `len` slots of idx with ONE atomic and writes them.  The lists of
+// different points therefore lie in idx in completion order -- start_len carries the start, as in the reference's CSR --
+// and no count pass / exclusive scan / host round trip is needed.  status: [0] slots reserved, [1] a list hit the cap,
+// [2] idx too small (lists missing; the caller retries with a larger buffer).
 __global__ __launch_bounds__(256) void ballquery_sim_kernel(int n, float radius2, int cap, const float *__restrict__ xyz,
                                                             const int32_t *__restrict__ seg_of,
                                                             const int32_t *__restrict__ seg_offsets, SimArgs sa,
                                                             const BqGrid *__restrict__ g,
                                                             const int32_t *__restrict__ cell_start,
                                                             const int32_t *__restrict__ sorted, int32_t *__restrict__ idx,
-                                                            int32_t *__restrict__ start_len, int32_t *__restrict__ counts,
-                                                            int32_t *__restrict__ flags) {
+                                                            int capacity, int32_t *__restrict__ start_len,
+                                                            int32_t *__restrict__ status) {
   __shared__ int hits[4][1024];
   const int lane = lane_id(), wave = wave_id();
   const int p = blockIdx.x * 4 + wave;
   if (p >= n) return;
   const int sg = seg_of[p];
   if (sa.seg_cls[sg] < 0) {
-    if (!FILL && lane == 0) counts[p] = 0;
+    if (lane < 2) start_len[p * 2 + lane] = 0;
     return;
   }
   const float ox = xyz[p * 3], oy = xyz[p * 3 + 1], oz = xyz[p * 3 + 2];
   const float dmi = sqrtf(sa.dmi2[sg]), dmp = sqrtf(sa.dmp2[sg]);
-  long s0 = 0;
-  int limit = cap;
-  if (FILL) {
-    s0 = start_len[p * 2];
-    limit = start_len[p * 2 + 1];
-    if (limit <= 0) return;
-  }
   auto accept = [&](int kk) -> bool {
     if (!(sqdist3s(ox, oy, oz, xyz[kk * 3], xyz[kk * 3 + 1], xyz[kk * 3 + 2]) < radius2)) return false;
     if (!(sim_value(sa.fi, sa.Ci, p, kk, dmi) > sa.thr_i)) return false;
     return sim_value(sa.fp, sa.Cp, p, kk, dmp) > sa.thr_p;
+  };
+  // reserve `len` slots; returns the start (or -1 and len = 0 when idx is full)
+  auto reserve = [&](int &len) -> int {
+    int s0 = 0;
+    if (lane == 0) {
+      s0 = len > 0 ? atomicAdd(status, len) : 0;
+      if (len > 0 && (long)s0 + len > (long)capacity) { atomicOr(status + 2, 1); s0 = -1; }
+    }
+    s0 = readlane_i(s0, 0);
+    if (s0 < 0) len = 0;
+    if (lane == 0) { start_len[p * 2] = s0 < 0 ? 0 : s0; start_len[p * 2 + 1] = len; }
+    return s0;
   };
   int cx, cy, cz;
   bq_cell_of(g, ox, oy, oz, cx, cy, cz);
@@ -517,37 +512,36 @@ __global__ __launch_bounds__(256) void ballquery_sim_kernel(int n, float radius2
           hit = accept(kk);
         }
         const unsigned long long mask = __ballot(hit);
-        if (FILL && hit) hb[cnt + __popcll(mask & ((1ull << lane) - 1ull))] = kk;
+        if (hit) hb[cnt + __popcll(mask & ((1ull << lane) - 1ull))] = kk;
         cnt += __popcll(mask);
       }
     }
-    if (!FILL) {
-      if (lane == 0) {
-        counts[p] = cnt < cap ? cnt : cap;
-        if (cnt >= cap) atomicOr(flags, 1);
-      }
-      return;
-    }
+    if (cnt >= cap && lane == 0) atomicOr(status + 1, 1);
+    int len = min(cnt, cap);
+    const int s0 = reserve(len);
+    if (len == 0) return;
     __builtin_amdgcn_wave_barrier();
     bq_sort_lds(hb, cnt, lane);
-    for (int i = lane; i < min(cnt, limit); i += 64) idx[s0 + i] = hb[i];
+    for (int i = lane; i < len; i += 64) idx[s0 + i] = hb[i];
     return;
   }
-  // crowded neighbourhood: scan the whole segment (ascending by construction)
+  // crowded neighbourhood: scan the whole segment twice (count, then write in ascending order)
   const int start = seg_offsets[sg], end = seg_offsets[sg + 1];
-  for (int base = start; base < end && cnt < limit; base += 64) {
+  for (int base = start; base < end && cnt < cap; base += 64) {
+    const int k = base + lane;
+    cnt += __popcll(__ballot(k < end && accept(k)));
+  }
+  if (cnt >= cap && lane == 0) atomicOr(status + 1, 1);
+  int len = min(cnt, cap);
+  const int s0 = reserve(len);
+  cnt = 0;
+  for (int base = start; base < end && cnt < len; base += 64) {
     const int k = base + lane;
     const bool hit = k < end && accept(k);
     const unsigned long long mask = __ballot(hit);
-    if (FILL) {
-      const int slot = cnt + __popcll(mask & ((1ull << lane) - 1ull));
-      if (hit && slot < limit) idx[s0 + slot] = k;
-    }
+    const int slot = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+    if (hit && slot < len) idx[s0 + slot] = k;
     cnt += __popcll(mask);
-  }
-  if (!FILL && lane == 0) {
-    counts[p] = cnt < cap ? cnt : cap;
-    if (cnt >= cap) atomicOr(flags, 1);
   }
 }
 
@@ -679,10 +673,44 @@ GCN_EXPORT int gcn_voxelize_bp(int M, int maxActive, int C, const float *d_outpu
   return check_launch("voxelize_bp_kernel");
 }
 
+// uniform-grid workspace: [64-byte header: BqGrid (56 B) + flags | cell_start (mc+1) | cursor (mc+1) | cell_of_pt (n) |
+// sorted (n) | scan block sums]
+struct GridWs {
+  BqGrid *g;
+  int32_t *flags, *cell_start, *cursor, *cell_of_pt, *sorted, *bsum;
+  int max_cells;
+};
+static long grid_ws_bytes(long n, long max_cells) {
+  return 64 + 4 * (2 * (max_cells + 1) + 2 * n + scan_blocks(max_cells + 1)) + 64;
+}
+static GridWs grid_ws_carve(void *ws, int n, int max_cells) {
+  GridWs w;
+  w.g = (BqGrid *)ws;
+  w.flags = (int32_t *)((char *)ws + 56);
+  w.cell_start = (int32_t *)((char *)ws + 64);
+  w.cursor = w.cell_start + max_cells + 1;
+  w.cell_of_pt = w.cursor + max_cells + 1;
+  w.sorted = w.cell_of_pt + n;
+  w.bsum = w.sorted + n;
+  w.max_cells = max_cells;
+  return w;
+}
+// counting sort of the points by (segment, z, y, x) cell; everything on the device
+static int grid_build(const GridWs &w, int n, const float *xyz, const int32_t *seg_of, int nseg, float radius, hipStream_t st) {
+  GCN_HIP(hipMemsetAsync(w.g, 0x00, 64, st));
+  GCN_HIP(hipMemsetAsync(&w.g->bmin[0], 0xff, 12, st));
+  GCN_HIP(hipMemsetAsync(w.cell_start, 0, sizeof(int32_t) * (size_t)(w.max_cells + 1), st));
+  bq_bbox_kernel<<<32, 1024, 0, st>>>(n, xyz, w.g);
+  bq_setup_kernel<<<1, 1, 0, st>>>(w.g, radius, nseg, w.max_cells);
+  bq_cell_count_kernel<<<cdiv(n, 256), 256, 0, st>>>(n, xyz, seg_of, w.g, w.cell_of_pt, w.cell_start);
+  exscan_rows(st, 1, w.max_cells + 1, w.cell_start, w.bsum, w.cursor);     // unused cells are empty: start[ncell..] = n
+  bq_cell_fill_kernel<<<cdiv(n, 256), 256, 0, st>>>(n, w.cell_of_pt, w.cursor, w.sorted);
+  return GCN_OK;
+}
+
 GCN_EXPORT long gcn_ballquery_grid_ws_bytes(int n) {
   if (n < 0) return -1;
-  const long max_cells = 4L * n + 4096;
-  return 64 + 4 * (2 * max_cells + 1 + 2L * n) + 64;
+  return grid_ws_bytes(n, 4L * n + 4096);
 }
 
 GCN_EXPORT int gcn_ballquery_batch_p(int n, int meanActive, float radius, const float *xyz,
@@ -702,19 +730,11 @@ GCN_EXPORT int gcn_ballquery_batch_p(int n, int meanActive, float radius, const 
   const float r2 = radius * radius;
   const long thre = (long)n * meanActive;
   if (!adj_inst && grid_ws && n >= 2048 && nbatch >= 1 && radius > 0.f) {
-    // uniform-grid path: [BqGrid | cell_cnt/start (max_cells+1) | cursor (max_cells) | cell_of_pt (n) | sorted (n)]
-    const int max_cells = 4 * n + 4096;
-    BqGrid *g = (BqGrid *)grid_ws;
-    int32_t *cell_start = (int32_t *)((char *)grid_ws + 64), *cursor = cell_start + max_cells + 1;
-    int32_t *cell_of_pt = cursor + max_cells, *sorted = cell_of_pt + n;
-    GCN_HIP(hipMemsetAsync(g, 0x00, 64, st));
-    GCN_HIP(hipMemsetAsync(&g->bmin[0], 0xff, 12, st));
-    GCN_HIP(hipMemsetAsync(cell_start, 0, sizeof(int32_t) * (size_t)(max_cells + 1), st));
-    bq_bbox_kernel<<<256, 256, 0, st>>>(n, xyz, g);
-    bq_setup_kernel<<<1, 1, 0, st>>>(g, radius, nbatch, max_cells);
-    bq_cell_count_kernel<<<cdiv(n, 256), 256, 0, st>>>(n, xyz, batch_idxs, g, cell_of_pt, cell_start);
-    bq_cell_scan_kernel<<<1, 1024, 0, st>>>(g, cell_start, cursor);
-    bq_cell_fill_kernel<<<cdiv(n, 256), 256, 0, st>>>(n, cell_of_pt, cursor, sorted);
+    const GridWs w = grid_ws_carve(grid_ws, n, 4 * n + 4096);
+    int grc = grid_build(w, n, xyz, batch_idxs, nbatch, radius, st);
+    if (grc) return grc;
+    const BqGrid *g = w.g;
+    const int32_t *cell_start = w.cell_start, *sorted = w.sorted;
     ballquery_grid_kernel<false><<<cdiv(n, 4), 256, 0, st>>>(n, thre, r2, cap, xyz, batch_idxs, batch_offsets, g, cell_start,
                                                               sorted, idx, start_len, count_ws);
     scan_counts_kernel<<<1, 1024, 0, st>>>(n, count_ws, start_len);
@@ -752,77 +772,30 @@ GCN_EXPORT int gcn_segment_diameter2(int n, int C, const float *feats, const int
 
 GCN_EXPORT long gcn_ballquery_sim_ws_bytes(int n) {
   if (n < 0) return -1;
-  const long max_cells = 16L * n + 4096;
-  return 64 + 4 * (2 * max_cells + 1 + 2L * n) + 64;
+  return grid_ws_bytes(n, 16L * n + 4096);
 }
 
-static int ballquery_sim_args(int n, const float *xyz, const int32_t *seg_of, const int32_t *seg_offsets,
-                              const int32_t *seg_cls, int S, const float *feat_inst, int Ci, const float *dmax2_inst,
-                              const float *feat_para, int Cp, const float *dmax2_para, const int32_t *start_len,
-                              const int32_t *count_ws, const void *grid_ws, const char *who) {
-  GCN_REQUIRE(n >= 0 && S >= 1 && Ci > 0 && Cp > 0, "%s: bad shape", who);
-  GCN_REQUIRE(n == 0 || (xyz && seg_of && seg_offsets && seg_cls && feat_inst && dmax2_inst && feat_para && dmax2_para &&
-                         start_len && count_ws && grid_ws), "%s: null pointer", who);
-  return GCN_OK;
-}
-
-GCN_EXPORT int gcn_ballquery_sim_count(int n, float radius, const float *xyz, const int32_t *seg_of,
-                                       const int32_t *seg_offsets, const int32_t *seg_cls, int S,
-                                       const float *feat_inst, int Ci, const float *dmax2_inst, float thr_inst,
-                                       const float *feat_para, int Cp, const float *dmax2_para, float thr_para,
-                                       int32_t *start_len, int32_t *count_ws, void *grid_ws, int *total_host,
-                                       int *capped_host, void *stream) {
-  GCN_REQUIRE(total_host && capped_host, "gcn_ballquery_sim_count: null result pointer");
-  *total_host = 0;
-  *capped_host = 0;
-  int rc = ballquery_sim_args(n, xyz, seg_of, seg_offsets, seg_cls, S, feat_inst, Ci, dmax2_inst, feat_para, Cp,
-                              dmax2_para, start_len, count_ws, grid_ws, "gcn_ballquery_sim_count");
-  if (rc || n == 0) return rc;
-  GCN_REQUIRE(radius > 0.f, "gcn_ballquery_sim_count: radius must be positive");
+GCN_EXPORT int gcn_ballquery_sim(int n, float radius, const float *xyz, const int32_t *seg_of,
+                                 const int32_t *seg_offsets, const int32_t *seg_cls, int S, const float *feat_inst,
+                                 int Ci, const float *dmax2_inst, float thr_inst, const float *feat_para, int Cp,
+                                 const float *dmax2_para, float thr_para, int32_t *idx, int capacity,
+                                 int32_t *start_len, int32_t *status, void *grid_ws, void *stream) {
+  GCN_REQUIRE(n >= 0 && S >= 1 && capacity >= 0, "gcn_ballquery_sim: bad shape");
+  GCN_REQUIRE(Ci > 0 && Cp > 0 && Ci % 16 == 0 && Cp % 16 == 0, "gcn_ballquery_sim: feature rows must be zero-padded to a multiple of 16 columns (Ci=%d, Cp=%d)", Ci, Cp);
+  GCN_REQUIRE(status, "gcn_ballquery_sim: status is null");
   hipStream_t st = (hipStream_t)stream;
-  const int max_cells = 16 * n + 4096;
-  BqGrid *g = (BqGrid *)grid_ws;
-  int32_t *cell_start = (int32_t *)((char *)grid_ws + 64), *cursor = cell_start + max_cells + 1;
-  int32_t *cell_of_pt = cursor + max_cells, *sorted = cell_of_pt + n;
-  int32_t *flags = (int32_t *)((char *)grid_ws + 56);           // inside the 64-byte header, behind the 56-byte BqGrid
-  GCN_HIP(hipMemsetAsync(g, 0x00, 64, st));
-  GCN_HIP(hipMemsetAsync(&g->bmin[0], 0xff, 12, st));
-  GCN_HIP(hipMemsetAsync(cell_start, 0, sizeof(int32_t) * (size_t)(max_cells + 1), st));
-  bq_bbox_kernel<<<256, 256, 0, st>>>(n, xyz, g);
-  bq_setup_kernel<<<1, 1, 0, st>>>(g, radius, S, max_cells);
-  bq_cell_count_kernel<<<cdiv(n, 256), 256, 0, st>>>(n, xyz, seg_of, g, cell_of_pt, cell_start);
-  bq_cell_scan_kernel<<<1, 1024, 0, st>>>(g, cell_start, cursor);
-  bq_cell_fill_kernel<<<cdiv(n, 256), 256, 0, st>>>(n, cell_of_pt, cursor, sorted);
-  SimArgs sa{feat_inst, feat_para, dmax2_inst, dmax2_para, seg_cls, thr_inst, thr_para, Ci, Cp};
-  ballquery_sim_kernel<false><<<cdiv(n, 4), 256, 0, st>>>(n, radius * radius, 3000, xyz, seg_of, seg_offsets, sa, g, cell_start,
-                                                          sorted, nullptr, start_len, count_ws, flags);
-  scan_counts_kernel<<<1, 1024, 0, st>>>(n, count_ws, start_len);
-  rc = check_launch("ballquery_sim_kernel<count>");
+  GCN_HIP(hipMemsetAsync(status, 0, 4 * sizeof(int32_t), st));
+  if (n == 0) return GCN_OK;
+  GCN_REQUIRE(xyz && seg_of && seg_offsets && seg_cls && feat_inst && dmax2_inst && feat_para && dmax2_para && start_len &&
+              grid_ws && (idx || capacity == 0), "gcn_ballquery_sim: null pointer");
+  GCN_REQUIRE(radius > 0.f, "gcn_ballquery_sim: radius must be positive");
+  const GridWs w = grid_ws_carve(grid_ws, n, 16 * n + 4096);
+  int rc = grid_build(w, n, xyz, seg_of, S, radius, st);
   if (rc) return rc;
-  GCN_HIP(hipMemcpyAsync(total_host, count_ws + n, sizeof(int), hipMemcpyDeviceToHost, st));
-  GCN_HIP(hipMemcpyAsync(capped_host, flags, sizeof(int), hipMemcpyDeviceToHost, st));
-  GCN_HIP(hipStreamSynchronize(st));
-  return GCN_OK;
-}
-
-GCN_EXPORT int gcn_ballquery_sim_fill(int n, float radius, const float *xyz, const int32_t *seg_of,
-                                      const int32_t *seg_offsets, const int32_t *seg_cls, int S,
-                                      const float *feat_inst, int Ci, const float *dmax2_inst, float thr_inst,
-                                      const float *feat_para, int Cp, const float *dmax2_para, float thr_para,
-                                      const int32_t *start_len, int32_t *idx, void *grid_ws, void *stream) {
-  int rc = ballquery_sim_args(n, xyz, seg_of, seg_offsets, seg_cls, S, feat_inst, Ci, dmax2_inst, feat_para, Cp,
-                              dmax2_para, start_len, start_len, grid_ws, "gcn_ballquery_sim_fill");
-  if (rc || n == 0) return rc;
-  GCN_REQUIRE(idx, "gcn_ballquery_sim_fill: idx is null");
-  hipStream_t st = (hipStream_t)stream;
-  const int max_cells = 16 * n + 4096;
-  BqGrid *g = (BqGrid *)grid_ws;
-  int32_t *cell_start = (int32_t *)((char *)grid_ws + 64), *cursor = cell_start + max_cells + 1;
-  int32_t *cell_of_pt = cursor + max_cells, *sorted = cell_of_pt + n;
   SimArgs sa{feat_inst, feat_para, dmax2_inst, dmax2_para, seg_cls, thr_inst, thr_para, Ci, Cp};
-  ballquery_sim_kernel<true><<<cdiv(n, 4), 256, 0, st>>>(n, radius * radius, 3000, xyz, seg_of, seg_offsets, sa, g, cell_start,
-                                                         sorted, idx, const_cast<int32_t *>(start_len), nullptr, nullptr);
-  return check_launch("ballquery_sim_kernel<fill>");
+  ballquery_sim_kernel<<<cdiv(n, 4), 256, 0, st>>>(n, radius * radius, 3000, xyz, seg_of, seg_offsets, sa, w.g, w.cell_start,
+                                                   w.sorted, idx, capacity, start_len, status);
+  return check_launch("ballquery_sim_kernel");
 }
 
 GCN_EXPORT int gcn_sec_op(int op, int P, int C, const float *inp, const int32_t *offsets, float *out, void *stream) {

@@ -100,10 +100,10 @@ def forward_grouping_device(semantic_scores, pt_offsets, batch_idxs, coords_floa
       * the two (n,n) similarity matrices of compute_batch_adjacency_matrix are never formed: only their global
         maximum is needed (the per-subset diameter, one MFMA Gram pass) and the exponentials are evaluated at the
         pairs inside the search radius -- the same predicate `adj_inst > thr_inst and adj_para > thr_para`;
-      * the neighbour lists are sized exactly (count, then fill), which is what the reference's meanActive retry
-        loop (functions.py:460-474) converges to, so `mean_active` does not matter here;
+      * every point reserves its neighbour list in an n*mean_active buffer with one atomic (a single pass, retried
+        with the exact size if it did not fit -- the reference's meanActive retry loop, functions.py:460-474);
       * connected components + the reference's BFS member order + the kept/primary merge run on the device;
-        two host synchronisations in total (list total, result sizes) instead of several per subset.
+        ONE host synchronisation in total (the result sizes) instead of several per subset.
 
     Same return value as forward_grouping (CPU int32 tensors; device tensors with to_cpu=False).  Pairs whose
     similarity lies within float rounding of a threshold can fall on the other side than with the dense path, which
@@ -142,31 +142,33 @@ def forward_grouping_device(semantic_scores, pt_offsets, batch_idxs, coords_floa
             _lib.call("gcn_segment_diameter2", n, f.shape[1], _lib.ptr(f), _lib.ptr(seg_offsets), _lib.ptr(seg_cls), S,
                       _lib.ptr(xx), _lib.ptr(tiles), _lib.ptr(d), st)
         grid_ws = torch.empty(lib.gcn_ballquery_sim_ws_bytes(n), dtype=torch.uint8, device=dev)
-        start_len = torch.empty(n, 2, dtype=torch.int32, device=dev)
-        count_ws = torch.empty(n + 1, dtype=torch.int32, device=dev)
-        total, capped = C.c_int(0), C.c_int(0)
-        bq = (n, float(radius), _lib.ptr(shifted), _lib.ptr(seg_of), _lib.ptr(seg_offsets), _lib.ptr(seg_cls), S,
-              _lib.ptr(fi), fi.shape[1], _lib.ptr(dm[0]), float(similarity_threshold_inst),
-              _lib.ptr(fp), fp.shape[1], _lib.ptr(dm[1]), float(similarity_threshold_para), _lib.ptr(start_len))
-        _lib.call("gcn_ballquery_sim_count", *bq, _lib.ptr(count_ws), _lib.ptr(grid_ws), C.addressof(total),
-                  C.addressof(capped), st)
-        if capped.value:
-            return forward_grouping(semantic_scores, pt_offsets, batch_idxs, coords_float, type_per_point,
-                                    param_per_point, feature_per_point, semantic_classes, training_mode, using_set_aggr,
-                                    radius, similarity_threshold_inst, similarity_threshold_para, mean_active, min_npoint)
-        nbr = torch.empty(max(total.value, 1), dtype=torch.int32, device=dev)
-        _lib.call("gcn_ballquery_sim_fill", *bq, _lib.ptr(nbr), _lib.ptr(grid_ws), st)
         ws = torch.empty(lib.gcn_cluster_components_ws_bytes(n), dtype=torch.uint8, device=dev)
+        start_len = torch.empty(n, 2, dtype=torch.int32, device=dev)
         cluster_idxs = torch.empty(n, 2, dtype=torch.int32, device=dev)
         cluster_offsets = torch.empty(n + 1, dtype=torch.int32, device=dev)
-        nsum, ncl = C.c_int(0), C.c_int(0)
-        _lib.call("gcn_cluster_components", n, _lib.ptr(nbr), _lib.ptr(start_len), _lib.ptr(seg_of),
-                  _lib.ptr(seg_offsets), _lib.ptr(seg_cls), S, _lib.ptr(point_index), _lib.ptr(ws),
-                  _lib.ptr(cluster_idxs), _lib.ptr(cluster_offsets), C.addressof(nsum), C.addressof(ncl), st)
-    if ncl.value == 0:
+        status = torch.empty(8, dtype=torch.int32, device=dev)     # [0:4] ball query, [4:6] (rows, clusters)
+        capacity = n * int(mean_active)
+        while True:
+            nbr = torch.empty(max(capacity, 1), dtype=torch.int32, device=dev)
+            _lib.call("gcn_ballquery_sim", n, float(radius), _lib.ptr(shifted), _lib.ptr(seg_of), _lib.ptr(seg_offsets),
+                      _lib.ptr(seg_cls), S, _lib.ptr(fi), fi.shape[1], _lib.ptr(dm[0]), float(similarity_threshold_inst),
+                      _lib.ptr(fp), fp.shape[1], _lib.ptr(dm[1]), float(similarity_threshold_para), _lib.ptr(nbr),
+                      capacity, _lib.ptr(start_len), _lib.ptr(status), _lib.ptr(grid_ws), st)
+            _lib.call("gcn_cluster_components", n, _lib.ptr(nbr), _lib.ptr(start_len), _lib.ptr(seg_of),
+                      _lib.ptr(seg_offsets), _lib.ptr(seg_cls), S, _lib.ptr(point_index), _lib.ptr(ws),
+                      _lib.ptr(cluster_idxs), _lib.ptr(cluster_offsets), _lib.ptr(status[4:]), st)
+            total, capped, overflow, _, nsum, ncl = status.cpu().tolist()[:6]       # the one host synchronisation
+            if not overflow:
+                break
+            capacity = total + 1            # lists did not fit (the reference's meanActive retry, functions.py:460-474)
+    if capped:
+        return forward_grouping(semantic_scores, pt_offsets, batch_idxs, coords_float, type_per_point,
+                                param_per_point, feature_per_point, semantic_classes, training_mode, using_set_aggr,
+                                radius, similarity_threshold_inst, similarity_threshold_para, mean_active, min_npoint)
+    if ncl == 0:
         z = torch.zeros((0, 2), dtype=torch.int32), torch.zeros((0,), dtype=torch.int32)
         return z if to_cpu else (z[0].to(dev), z[1].to(dev))
-    pi, po = cluster_idxs[:nsum.value], cluster_offsets[:ncl.value + 1]
+    pi, po = cluster_idxs[:nsum], cluster_offsets[:ncl + 1]
     return (pi.cpu(), po.cpu()) if to_cpu else (pi, po)
 
 

@@ -155,29 +155,25 @@ int gcn_segment_diameter2(int n, int C, const float *feats, const int32_t *seg_o
                           float *xx_ws, int32_t *tile_ws, float *dmax2, void *stream);
 long gcn_ballquery_sim_ws_bytes(int n);
 /* ballquery_batch_p with `adj_inst[p][k] > thr_inst && adj_para[p][k] > thr_para` evaluated from the feature rows:
- * adj = exp(-(||f_p - f_k|| / dmax)^2 / 2), 0 for p == k, NaN (never accepted) when dmax == 0.  Two calls: _count
- * fills start_len (n,2) = (start, count capped at 3000 as bfs_cluster.cu:54) and returns the total and whether any list
- * hit the cap (synchronises); the caller allocates idx (total) and calls _fill with the same arguments and workspace.
- * Lists are ascending, as the reference's scan order. */
-int gcn_ballquery_sim_count(int n, float radius, const float *xyz, const int32_t *seg_of, const int32_t *seg_offsets,
-                            const int32_t *seg_cls, int S, const float *feat_inst, int Ci, const float *dmax2_inst,
-                            float thr_inst, const float *feat_para, int Cp, const float *dmax2_para, float thr_para,
-                            int32_t *start_len, int32_t *count_ws, void *grid_ws, int *total_host, int *capped_host,
-                            void *stream);
-int gcn_ballquery_sim_fill(int n, float radius, const float *xyz, const int32_t *seg_of, const int32_t *seg_offsets,
-                           const int32_t *seg_cls, int S, const float *feat_inst, int Ci, const float *dmax2_inst,
-                           float thr_inst, const float *feat_para, int Cp, const float *dmax2_para, float thr_para,
-                           const int32_t *start_len, int32_t *idx, void *grid_ws, void *stream);
+ * adj = exp(-(||f_p - f_k|| / dmax)^2 / 2), 0 for p == k, NaN (never accepted) when dmax == 0.  One asynchronous pass:
+ * every point reserves its list in idx (capacity ints) with one atomic, so the lists lie in completion order and
+ * start_len (n,2) = (start, count capped at 3000 as bfs_cluster.cu:54) addresses them; each list is ascending, as the
+ * reference's scan order.  Feature rows zero-padded to a multiple of 16 columns.  status (4 ints, device):
+ * [0] ints reserved, [1] != 0 if a list hit the cap, [2] != 0 if idx was too small (lists missing: call again with
+ * capacity >= the reference's n*meanActive retry value).  No host synchronisation. */
+int gcn_ballquery_sim(int n, float radius, const float *xyz, const int32_t *seg_of, const int32_t *seg_offsets,
+                      const int32_t *seg_cls, int S, const float *feat_inst, int Ci, const float *dmax2_inst,
+                      float thr_inst, const float *feat_para, int Cp, const float *dmax2_para, float thr_para,
+                      int32_t *idx, int capacity, int32_t *start_len, int32_t *status, void *grid_ws, void *stream);
 /* hierarchical_aggregation (hierarchical_aggregation.cpp:20-131 + the kept/primary merge of functions.py:52-72,
  * using_set_aggr = False) for all segments on the device: components of the (symmetric) neighbour lists, members in the
  * reference's BFS dequeue order, segment by segment, kept fragments before primaries.  cluster_idxs (n,2) gets
- * (cluster id, point_index[member]) rows, cluster_offsets (n+1); *sum_host rows / *ncluster_host clusters are valid
- * (synchronises).  seg_cls (S): semantic class 0..9 of the segment or < 0 to skip it.  n < 2^20. */
+ * (cluster id, point_index[member]) rows, cluster_offsets (n+1); counts (2 ints, device) = (rows, clusters) that are
+ * valid.  No host synchronisation.  seg_cls (S): semantic class 0..9 of the segment or < 0 to skip it.  n < 2^20. */
 long gcn_cluster_components_ws_bytes(int n);
 int gcn_cluster_components(int n, const int32_t *nbr, const int32_t *start_len, const int32_t *seg_of,
                            const int32_t *seg_offsets, const int32_t *seg_cls, int S, const int32_t *point_index,
-                           void *ws, int32_t *cluster_idxs, int32_t *cluster_offsets, int *sum_host, int *ncluster_host,
-                           void *stream);
+                           void *ws, int32_t *cluster_idxs, int32_t *cluster_offsets, int32_t *counts, void *stream);
 /* Device scratch for the uniform-grid path of gcn_ballquery_batch_p (easy form, n >= 2048): pass it as grid_ws
  * (NULL selects the brute-force scan).  nbatch = number of batch segments (len(batch_offsets) - 1). */
 long gcn_ballquery_grid_ws_bytes(int n);
