@@ -216,11 +216,14 @@ __global__ void bq_cell_count_kernel(int n, const float *__restrict__ xyz, const
   atomicAdd(cell_cnt + c, 1);
 }
 
+// packed (optional): (x, y, z, id) rows in cell order, so that a candidate range is one coalesced 16-byte-per-lane load
 __global__ void bq_cell_fill_kernel(int n, const int32_t *__restrict__ cell_of_pt, int32_t *__restrict__ cursor,
-                                    int32_t *__restrict__ sorted) {
+                                    int32_t *__restrict__ sorted, const float *__restrict__ xyz, float4 *__restrict__ packed) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  sorted[atomicAdd(cursor + cell_of_pt[i], 1)] = i;
+  const int pos = atomicAdd(cursor + cell_of_pt[i], 1);
+  sorted[pos] = i;
+  if (packed) packed[pos] = float4{xyz[i * 3], xyz[i * 3 + 1], xyz[i * 3 + 2], __int_as_float(i)};
 }
 
 // ascending bitonic sort of `m` (<= 1024) ints held in a wave-private LDS buffer padded to a power of two
@@ -416,6 +419,10 @@ __global__ __launch_bounds__(256) void seg_diameter_kernel(int S, int C, const f
   if (lane == 0 && best > 0.f) atomicMax(dmax2 + sg, __float_as_uint(best));   // non-negative floats order as uints
 }
 
+// Same-address atomics retire one every ~10 ns on the L2: 65 536 list reservations on ONE counter cost 0.7 ms.  idx is
+// cut into BQ_REGIONS equal regions with a counter each (128 bytes apart), workgroups take them round robin.
+constexpr int BQ_REGIONS = 64;
+
 struct SimArgs {
   const float *fi, *fp;           // (n, Ci), (n, Cp) feature rows, point order
   const float *dmi2, *dmp2;       // (S) squared diameters
@@ -424,38 +431,54 @@ struct SimArgs {
   int Ci, Cp;
 };
 
-// adjacency value of M4:210-233 at (p, k): exp(-(d/dmax)^2 / 2), zero on the diagonal, NaN when dmax == 0 (0/0).
-// Rows are 16-float multiples (64-byte aligned): four floats per load, summed in column order.
-__device__ __forceinline__ float sim_value(const float *__restrict__ f, int C, int p, int k, float dmax) {
+// adjacency value of M4:210-233 from a squared feature distance: exp(-(d/dmax)^2 / 2), zero on the diagonal, NaN when
+// dmax == 0 (the reference's 0/0)
+__device__ __forceinline__ float sim_from_dist2(float d2, float dmax, bool self) {
   if (dmax == 0.f) return __builtin_nanf("");
-  if (p == k) return 0.f;
-  const float4 *a = reinterpret_cast<const float4 *>(f + (long)p * C), *b = reinterpret_cast<const float4 *>(f + (long)k * C);
-  float s = 0.f;
-  for (int c = 0; c < C / 4; ++c) {
-    const float4 x = a[c], y = b[c];
-    float d = x.x - y.x; s = fmaf(d, d, s);
-    d = x.y - y.y; s = fmaf(d, d, s);
-    d = x.z - y.z; s = fmaf(d, d, s);
-    d = x.w - y.w; s = fmaf(d, d, s);
-  }
-  const float a1 = sqrtf(s) / dmax;
-  return expf(-(a1 * a1) / 2.f);
+  if (self) return 0.f;
+  const float a = sqrtf(d2) / dmax;
+  return expf(-(a * a) / 2.f);
 }
 
-// One pass: a wave collects the neighbours of its point (27 cells; the whole segment if those hold more than 1024
-// candidates), orders them ascending, reserves `len` slots of idx with ONE atomic and writes them.  The lists of
-// different points therefore lie in idx in completion order -- start_len carries the start, as in the reference's CSR --
-// and no count pass / exclusive scan / host round trip is needed.  status: [0] slots reserved, [1] a list hit the cap,
-// [2] idx too small (lists missing; the caller retries with a larger buffer).
+// ||f_p - f_k||^2 by the 16 lanes of a group: lane `sub` owns the float4 columns sub, sub+16, ... (rows are 64-byte
+// multiples, so four rows make one fully coalesced 64-lane load), butterfly sum inside the group.  Every lane of the
+// group ends with the same value, and the value is symmetric in (p, k) bit for bit -- the neighbour lists must be.
+__device__ __forceinline__ float row_dist2_16(const float4 *__restrict__ prow, const float *__restrict__ f, int C4, int k, int sub) {
+  const float4 *b = reinterpret_cast<const float4 *>(f) + (long)k * C4;
+  float s = 0.f;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int c = sub + 16 * u;
+    if (c < C4) {
+      const float4 x = prow[u], y = b[c];
+      float d = x.x - y.x; s = fmaf(d, d, s);
+      d = x.y - y.y; s = fmaf(d, d, s);
+      d = x.z - y.z; s = fmaf(d, d, s);
+      d = x.w - y.w; s = fmaf(d, d, s);
+    }
+  }
+  s += __shfl_xor(s, 8);
+  s += __shfl_xor(s, 4);
+  s += __shfl_xor(s, 2);
+  s += __shfl_xor(s, 1);
+  return s;
+}
+
+// One pass: a wave collects the points inside the radius of its point (27 cells; the whole segment if more than ~1900
+// lie inside) in LDS, four 16-lane groups then evaluate the two similarities of four candidates at a time and
+// compact the list in place; it is ordered ascending, `len` slots of idx are reserved with ONE atomic and written.  The
+// lists of different points therefore lie in idx in completion order -- start_len carries the start, as in the
+// reference's CSR -- and no count pass / exclusive scan / host round trip is needed.  status: [0] sufficient capacity,
+// [1] a list hit the cap, [2] idx too small (lists missing; the caller retries with a larger buffer).
 __global__ __launch_bounds__(256) void ballquery_sim_kernel(int n, float radius2, int cap, const float *__restrict__ xyz,
                                                             const int32_t *__restrict__ seg_of,
                                                             const int32_t *__restrict__ seg_offsets, SimArgs sa,
                                                             const BqGrid *__restrict__ g,
                                                             const int32_t *__restrict__ cell_start,
-                                                            const int32_t *__restrict__ sorted, int32_t *__restrict__ idx,
+                                                            const float4 *__restrict__ packed, int32_t *__restrict__ idx,
                                                             int capacity, int32_t *__restrict__ start_len,
-                                                            int32_t *__restrict__ status) {
-  __shared__ int hits[4][1024];
+                                                            int32_t *__restrict__ region, int32_t *__restrict__ status) {
+  __shared__ int hits[4][2048];
   const int lane = lane_id(), wave = wave_id();
   const int p = blockIdx.x * 4 + wave;
   if (p >= n) return;
@@ -466,17 +489,46 @@ __global__ __launch_bounds__(256) void ballquery_sim_kernel(int n, float radius2
   }
   const float ox = xyz[p * 3], oy = xyz[p * 3 + 1], oz = xyz[p * 3 + 2];
   const float dmi = sqrtf(sa.dmi2[sg]), dmp = sqrtf(sa.dmp2[sg]);
-  auto accept = [&](int kk) -> bool {
-    if (!(sqdist3s(ox, oy, oz, xyz[kk * 3], xyz[kk * 3 + 1], xyz[kk * 3 + 2]) < radius2)) return false;
-    if (!(sim_value(sa.fi, sa.Ci, p, kk, dmi) > sa.thr_i)) return false;
-    return sim_value(sa.fp, sa.Cp, p, kk, dmp) > sa.thr_p;
+  const int sub = lane & 15, grp = lane >> 4;
+  const int Ci4 = sa.Ci / 4, Cp4 = sa.Cp / 4;
+  float4 pi[4], pp[4];                                   // this point's rows, the columns lane `sub` owns
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int c = sub + 16 * u;
+    pi[u] = c < Ci4 ? reinterpret_cast<const float4 *>(sa.fi)[(long)p * Ci4 + c] : float4{0.f, 0.f, 0.f, 0.f};
+    pp[u] = c < Cp4 ? reinterpret_cast<const float4 *>(sa.fp)[(long)p * Cp4 + c] : float4{0.f, 0.f, 0.f, 0.f};
+  }
+  auto in_radius = [&](int kk) -> bool {
+    return sqdist3s(ox, oy, oz, xyz[kk * 3], xyz[kk * 3 + 1], xyz[kk * 3 + 2]) < radius2;
   };
-  // reserve `len` slots; returns the start (or -1 and len = 0 when idx is full)
+  // keeps the ids[0..m) that pass both similarity thresholds, in place and in order; returns the new count.  Eight
+  // candidates per step (two per 16-lane group) so that two row loads are in flight per lane.
+  auto sim_filter = [&](int *ids, int m) -> int {
+    int kept = 0;
+    for (int i0 = 0; i0 < m; i0 += 8) {
+      const int ia = i0 + grp, ib = i0 + 4 + grp;
+      const int ka = ia < m ? ids[ia] : p, kb = ib < m ? ids[ib] : p;
+      const float dia = row_dist2_16(pi, sa.fi, Ci4, ka, sub), dib = row_dist2_16(pi, sa.fi, Ci4, kb, sub);
+      const float dpa = row_dist2_16(pp, sa.fp, Cp4, ka, sub), dpb = row_dist2_16(pp, sa.fp, Cp4, kb, sub);
+      const bool oka = ia < m && sub == 0 && sim_from_dist2(dia, dmi, ka == p) > sa.thr_i && sim_from_dist2(dpa, dmp, ka == p) > sa.thr_p;
+      const bool okb = ib < m && sub == 0 && sim_from_dist2(dib, dmi, kb == p) > sa.thr_i && sim_from_dist2(dpb, dmp, kb == p) > sa.thr_p;
+      const unsigned long long ma = __ballot(oka), mb = __ballot(okb);
+      const unsigned long long lt = (1ull << lane) - 1ull;
+      if (oka) ids[kept + __popcll(ma & lt)] = ka;                     // slots never run ahead of the reads
+      kept += __popcll(ma);
+      if (okb) ids[kept + __popcll(mb & lt)] = kb;
+      kept += __popcll(mb);
+    }
+    return kept;
+  };
+  // reserve `len` slots in this workgroup's region of idx; returns the start (or -1 and len = 0 when it is full)
   auto reserve = [&](int &len) -> int {
+    const int rg = blockIdx.x % BQ_REGIONS, rcap = capacity / BQ_REGIONS;
     int s0 = 0;
     if (lane == 0) {
-      s0 = len > 0 ? atomicAdd(status, len) : 0;
-      if (len > 0 && (long)s0 + len > (long)capacity) { atomicOr(status + 2, 1); s0 = -1; }
+      s0 = len > 0 ? atomicAdd(region + rg * 32, len) : 0;
+      if (len > 0 && s0 + len > rcap) { atomicOr(status + 2, 1); s0 = -1; }
+      else s0 += rg * rcap;
     }
     s0 = readlane_i(s0, 0);
     if (s0 < 0) len = 0;
@@ -500,22 +552,35 @@ __global__ __launch_bounds__(256) void ballquery_sim_kernel(int n, float radius2
   tot = readlane_i(tot, 0);
   int cnt = 0;
   int *hb = hits[wave];
-  if (tot <= 1024) {
-    for (int rr = 0; rr < 9; ++rr) {
-      const int lo = readlane_i(rlo, rr), hi = readlane_i(rhi, rr);
-      for (int base = lo; base < hi; base += 64) {
-        const int t = base + lane;
-        int kk = 0;
-        bool hit = false;
-        if (t < hi) {
-          kk = sorted[t];
-          hit = accept(kk);
-        }
-        const unsigned long long mask = __ballot(hit);
-        if (hit) hb[cnt + __popcll(mask & ((1ull << lane) - 1ull))] = kk;
-        cnt += __popcll(mask);
-      }
+  bool crowded = false;
+  {
+    // the nine row ranges as ONE candidate stream: stream position t -> range r with pre[r] <= t < pre[r+1]
+    int pre = rhi - rlo;                                   // inclusive prefix over lanes 0..8
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) { const int y = __shfl_up(pre, d); if (lane >= d) pre += y; }
+    int rpre[9], rbase[9];
+#pragma unroll
+    for (int r = 0; r < 9; ++r) { rpre[r] = readlane_i(pre, r); rbase[r] = readlane_i(rlo, r) - (r ? readlane_i(pre, r - 1) : 0); }
+    for (int base = 0; base < tot; base += 128) {
+      if (cnt > 2048 - 128) { crowded = true; break; }          // more points INSIDE the radius than the buffer holds
+      const int ta = base + lane, tb = base + 64 + lane;
+      int offa = rbase[0], offb = rbase[0];
+#pragma unroll
+      for (int r = 1; r < 9; ++r) { offa = ta >= rpre[r - 1] ? rbase[r] : offa; offb = tb >= rpre[r - 1] ? rbase[r] : offb; }
+      const float4 qa = packed[ta < tot ? ta + offa : 0], qb = packed[tb < tot ? tb + offb : 0];
+      const bool ha = ta < tot && sqdist3s(ox, oy, oz, qa.x, qa.y, qa.z) < radius2;
+      const bool hb2 = tb < tot && sqdist3s(ox, oy, oz, qb.x, qb.y, qb.z) < radius2;
+      const unsigned long long ma = __ballot(ha), mb = __ballot(hb2);
+      const unsigned long long lt = (1ull << lane) - 1ull;
+      if (ha) hb[cnt + __popcll(ma & lt)] = __float_as_int(qa.w);
+      cnt += __popcll(ma);
+      if (hb2) hb[cnt + __popcll(mb & lt)] = __float_as_int(qb.w);
+      cnt += __popcll(mb);
     }
+  }
+  if (!crowded) {
+    __builtin_amdgcn_wave_barrier();
+    cnt = sim_filter(hb, cnt);
     if (cnt >= cap && lane == 0) atomicOr(status + 1, 1);
     int len = min(cnt, cap);
     const int s0 = reserve(len);
@@ -525,24 +590,36 @@ __global__ __launch_bounds__(256) void ballquery_sim_kernel(int n, float radius2
     for (int i = lane; i < len; i += 64) idx[s0 + i] = hb[i];
     return;
   }
-  // crowded neighbourhood: scan the whole segment twice (count, then write in ascending order)
+  // more than ~1900 points inside the radius: scan the whole segment twice (count, then write; ascending by construction)
   const int start = seg_offsets[sg], end = seg_offsets[sg + 1];
-  for (int base = start; base < end && cnt < cap; base += 64) {
-    const int k = base + lane;
-    cnt += __popcll(__ballot(k < end && accept(k)));
+  for (int pass = 0, len = 0, s0 = 0; pass < 2; ++pass) {
+    cnt = 0;
+    const int limit = pass == 0 ? cap : len;
+    for (int base = start; base < end && cnt < limit; base += 64) {
+      const int k = base + lane;
+      const bool hit = k < end && in_radius(k);
+      const unsigned long long mask = __ballot(hit);
+      if (hit) hb[__popcll(mask & ((1ull << lane) - 1ull))] = k;
+      __builtin_amdgcn_wave_barrier();
+      const int m = sim_filter(hb, __popcll(mask));
+      __builtin_amdgcn_wave_barrier();
+      if (pass == 1 && lane < m && cnt + lane < len) idx[s0 + cnt + lane] = hb[lane];
+      cnt += m;
+    }
+    if (pass == 0) {
+      if (cnt >= cap && lane == 0) atomicOr(status + 1, 1);
+      len = min(cnt, cap);
+      s0 = reserve(len);
+      if (len == 0) return;
+    }
   }
-  if (cnt >= cap && lane == 0) atomicOr(status + 1, 1);
-  int len = min(cnt, cap);
-  const int s0 = reserve(len);
-  cnt = 0;
-  for (int base = start; base < end && cnt < len; base += 64) {
-    const int k = base + lane;
-    const bool hit = k < end && accept(k);
-    const unsigned long long mask = __ballot(hit);
-    const int slot = cnt + __popcll(mask & ((1ull << lane) - 1ull));
-    if (hit && slot < len) idx[s0 + slot] = k;
-    cnt += __popcll(mask);
-  }
+}
+
+// status[0] = a capacity that holds every list: BQ_REGIONS x the fullest region (+ one cap-sized list of slack each)
+__global__ void bq_status_kernel(const int32_t *__restrict__ region, int32_t *__restrict__ status) {
+  int m = 0;
+  for (int r = 0; r < BQ_REGIONS; ++r) m = max(m, region[r * 32]);
+  status[0] = (int)min((long)BQ_REGIONS * (m + 3000L), 2147483647L);
 }
 
 // ---------------------------------------------------------------- segment ops
@@ -673,25 +750,28 @@ GCN_EXPORT int gcn_voxelize_bp(int M, int maxActive, int C, const float *d_outpu
   return check_launch("voxelize_bp_kernel");
 }
 
-// uniform-grid workspace: [64-byte header: BqGrid (56 B) + flags | cell_start (mc+1) | cursor (mc+1) | cell_of_pt (n) |
+// uniform-grid workspace: [64-byte header: BqGrid (56 B) + flags | packed (n float4) | cell_start (mc+1) | cursor (mc+1) | cell_of_pt (n) |
 // sorted (n) | scan block sums]
 struct GridWs {
   BqGrid *g;
-  int32_t *flags, *cell_start, *cursor, *cell_of_pt, *sorted, *bsum;
+  int32_t *flags, *cell_start, *cursor, *cell_of_pt, *sorted, *bsum, *region;
+  float4 *packed;
   int max_cells;
 };
 static long grid_ws_bytes(long n, long max_cells) {
-  return 64 + 4 * (2 * (max_cells + 1) + 2 * n + scan_blocks(max_cells + 1)) + 64;
+  return 64 + 16 * n + 4 * (2 * (max_cells + 1) + 2 * n + scan_blocks(max_cells + 1) + BQ_REGIONS * 32) + 64;
 }
 static GridWs grid_ws_carve(void *ws, int n, int max_cells) {
   GridWs w;
   w.g = (BqGrid *)ws;
   w.flags = (int32_t *)((char *)ws + 56);
-  w.cell_start = (int32_t *)((char *)ws + 64);
+  w.packed = (float4 *)((char *)ws + 64);
+  w.cell_start = (int32_t *)((char *)ws + 64 + 16L * n);
   w.cursor = w.cell_start + max_cells + 1;
   w.cell_of_pt = w.cursor + max_cells + 1;
   w.sorted = w.cell_of_pt + n;
   w.bsum = w.sorted + n;
+  w.region = w.bsum + scan_blocks(max_cells + 1);
   w.max_cells = max_cells;
   return w;
 }
@@ -704,7 +784,7 @@ static int grid_build(const GridWs &w, int n, const float *xyz, const int32_t *s
   bq_setup_kernel<<<1, 1, 0, st>>>(w.g, radius, nseg, w.max_cells);
   bq_cell_count_kernel<<<cdiv(n, 256), 256, 0, st>>>(n, xyz, seg_of, w.g, w.cell_of_pt, w.cell_start);
   exscan_rows(st, 1, w.max_cells + 1, w.cell_start, w.bsum, w.cursor);     // unused cells are empty: start[ncell..] = n
-  bq_cell_fill_kernel<<<cdiv(n, 256), 256, 0, st>>>(n, w.cell_of_pt, w.cursor, w.sorted);
+  bq_cell_fill_kernel<<<cdiv(n, 256), 256, 0, st>>>(n, w.cell_of_pt, w.cursor, w.sorted, xyz, w.packed);
   return GCN_OK;
 }
 
@@ -772,7 +852,7 @@ GCN_EXPORT int gcn_segment_diameter2(int n, int C, const float *feats, const int
 
 GCN_EXPORT long gcn_ballquery_sim_ws_bytes(int n) {
   if (n < 0) return -1;
-  return grid_ws_bytes(n, 16L * n + 4096);
+  return grid_ws_bytes(n, 128L * n + 4096);
 }
 
 GCN_EXPORT int gcn_ballquery_sim(int n, float radius, const float *xyz, const int32_t *seg_of,
@@ -780,8 +860,8 @@ GCN_EXPORT int gcn_ballquery_sim(int n, float radius, const float *xyz, const in
                                  int Ci, const float *dmax2_inst, float thr_inst, const float *feat_para, int Cp,
                                  const float *dmax2_para, float thr_para, int32_t *idx, int capacity,
                                  int32_t *start_len, int32_t *status, void *grid_ws, void *stream) {
-  GCN_REQUIRE(n >= 0 && S >= 1 && capacity >= 0, "gcn_ballquery_sim: bad shape");
-  GCN_REQUIRE(Ci > 0 && Cp > 0 && Ci % 16 == 0 && Cp % 16 == 0, "gcn_ballquery_sim: feature rows must be zero-padded to a multiple of 16 columns (Ci=%d, Cp=%d)", Ci, Cp);
+  GCN_REQUIRE(n >= 0 && n <= (1 << 23) && S >= 1 && capacity >= 0, "gcn_ballquery_sim: bad shape");
+  GCN_REQUIRE(Ci > 0 && Cp > 0 && Ci % 16 == 0 && Cp % 16 == 0 && Ci <= 256 && Cp <= 256, "gcn_ballquery_sim: feature rows must be zero-padded to a multiple of 16 columns, at most 256 (Ci=%d, Cp=%d)", Ci, Cp);
   GCN_REQUIRE(status, "gcn_ballquery_sim: status is null");
   hipStream_t st = (hipStream_t)stream;
   GCN_HIP(hipMemsetAsync(status, 0, 4 * sizeof(int32_t), st));
@@ -789,12 +869,14 @@ GCN_EXPORT int gcn_ballquery_sim(int n, float radius, const float *xyz, const in
   GCN_REQUIRE(xyz && seg_of && seg_offsets && seg_cls && feat_inst && dmax2_inst && feat_para && dmax2_para && start_len &&
               grid_ws && (idx || capacity == 0), "gcn_ballquery_sim: null pointer");
   GCN_REQUIRE(radius > 0.f, "gcn_ballquery_sim: radius must be positive");
-  const GridWs w = grid_ws_carve(grid_ws, n, 16 * n + 4096);
+  const GridWs w = grid_ws_carve(grid_ws, n, 128 * n + 4096);     // segments x cells of edge ~radius: HBM is plentiful
   int rc = grid_build(w, n, xyz, seg_of, S, radius, st);
   if (rc) return rc;
   SimArgs sa{feat_inst, feat_para, dmax2_inst, dmax2_para, seg_cls, thr_inst, thr_para, Ci, Cp};
+  GCN_HIP(hipMemsetAsync(w.region, 0, sizeof(int32_t) * BQ_REGIONS * 32, st));
   ballquery_sim_kernel<<<cdiv(n, 4), 256, 0, st>>>(n, radius * radius, 3000, xyz, seg_of, seg_offsets, sa, w.g, w.cell_start,
-                                                   w.sorted, idx, capacity, start_len, status);
+                                                   w.packed, idx, capacity, start_len, w.region, status);
+  bq_status_kernel<<<1, 1, 0, st>>>(w.region, status);
   return check_launch("ballquery_sim_kernel");
 }
 

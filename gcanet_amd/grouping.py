@@ -160,7 +160,7 @@ def forward_grouping_device(semantic_scores, pt_offsets, batch_idxs, coords_floa
             total, capped, overflow, _, nsum, ncl = status.cpu().tolist()[:6]       # the one host synchronisation
             if not overflow:
                 break
-            capacity = total + 1            # lists did not fit (the reference's meanActive retry, functions.py:460-474)
+            capacity = total                # lists did not fit (the reference's meanActive retry, functions.py:460-474)
     if capped:
         return forward_grouping(semantic_scores, pt_offsets, batch_idxs, coords_float, type_per_point,
                                 param_per_point, feature_per_point, semantic_classes, training_mode, using_set_aggr,

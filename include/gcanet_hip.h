@@ -156,11 +156,12 @@ int gcn_segment_diameter2(int n, int C, const float *feats, const int32_t *seg_o
 long gcn_ballquery_sim_ws_bytes(int n);
 /* ballquery_batch_p with `adj_inst[p][k] > thr_inst && adj_para[p][k] > thr_para` evaluated from the feature rows:
  * adj = exp(-(||f_p - f_k|| / dmax)^2 / 2), 0 for p == k, NaN (never accepted) when dmax == 0.  One asynchronous pass:
- * every point reserves its list in idx (capacity ints) with one atomic, so the lists lie in completion order and
+ * every point reserves its list in idx (capacity ints, cut into 64 regions with a counter each) with one atomic, so the
+ * lists lie in completion order and
  * start_len (n,2) = (start, count capped at 3000 as bfs_cluster.cu:54) addresses them; each list is ascending, as the
  * reference's scan order.  Feature rows zero-padded to a multiple of 16 columns.  status (4 ints, device):
- * [0] ints reserved, [1] != 0 if a list hit the cap, [2] != 0 if idx was too small (lists missing: call again with
- * capacity >= the reference's n*meanActive retry value).  No host synchronisation. */
+ * [0] a capacity that holds every list, [1] != 0 if a list hit the cap, [2] != 0 if idx was too small (lists missing:
+ * call again with capacity = status[0]; the reference's n*meanActive retry, functions.py:460-474).  No host sync. */
 int gcn_ballquery_sim(int n, float radius, const float *xyz, const int32_t *seg_of, const int32_t *seg_offsets,
                       const int32_t *seg_cls, int S, const float *feat_inst, int Ci, const float *dmax2_inst,
                       float thr_inst, const float *feat_para, int Cp, const float *dmax2_para, float thr_para,
