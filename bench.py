@@ -95,6 +95,36 @@ def cpu_baseline(N, k, seconds_budget=25.0):
                       "(torch CPU restatement of M4:634-747), best of %d" % (N, k, runs)}
 
 
+def grouping_times(model, pts, nrm, reps=5):
+    """forward_grouping (M4:737, the stage right after the timed step) on the model's own
+    predictions for this batch: the fused device path vs the literal per-(cloud, class) path.  Reported beside the
+    headline number, never part of it."""
+    from gcanet_amd.grouping import forward_grouping, forward_grouping_device
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        out = model(pts, nrm)
+    B, N = pts.shape[:2]
+    args = (out["semantic_scores"].float(), out["pt_offsets"].float(),
+            torch.arange(B, device=pts.device).repeat_interleave(N), pts.reshape(-1, 3), out["type_per_point"],
+            out["param_per_point"].float(), out["output_feats"].float())
+    res = {}
+    for name, fn, r in (("device_ms", forward_grouping_device, reps), ("literal_ms", forward_grouping, 2)):
+        pi, po = fn(*args)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(r):
+            pi, po = fn(*args)
+        torch.cuda.synchronize()
+        res[name] = round((time.perf_counter() - t0) / r * 1e3, 3)
+        res.setdefault("proposals", int(po.numel()) - 1 if po.numel() else 0)
+        res.setdefault("members", int(pi.shape[0]))
+        if name == "device_ms":
+            dev_out = (pi, po)
+        else:
+            res["identical"] = bool(torch.equal(dev_out[0], pi) and torch.equal(dev_out[1], po))
+    res["note"] = "forward_grouping on this batch's predictions (random-init weights), outside the timed step"
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -190,6 +220,7 @@ def main():
         "roofline": roofline, "kernels": kernels, "loss": float(loss.detach()),
     }
     if world == 1 and not args.no_cpu_baseline:
+        res["forward_grouping"] = grouping_times(model, pts, nrm)
         res["cpu_baseline"] = cpu_baseline(N, args.k)
     print(json.dumps(res))
     if world > 1:

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """forward_grouping: literal per-(cloud, class) path vs the fused device path, B clouds x N points, P classes.
-usage: grouping_bench.py [B N P reps]"""
+usage: grouping_bench.py [B N P reps] [uniform]"""
 import os
 import sys
 import time
@@ -29,9 +29,22 @@ def scene(seed, B, N, P, nblob, extent):
     return f(sem), f(off), torch.arange(B).repeat_interleave(N).cuda(), f(xyz.reshape(-1, 3)), torch.zeros(B, N, P), f(par), f(feat)
 
 
+def uniform_scene(seed, B, N, P):
+    """uniform cube, labels uniform over the classes, offsets N(0, 0.01^2)."""
+    g = torch.Generator().manual_seed(seed)
+    lab = torch.randint(0, P, (B * N,), generator=g)
+    sem = torch.nn.functional.one_hot(lab, P).float() * 6 + 0.3 * torch.randn(B * N, P, generator=g)
+    c = lambda t: t.cuda()
+    return (c(sem), c(0.01 * torch.randn(B * N, 3, generator=g)), torch.arange(B).repeat_interleave(N).cuda(),
+            c(torch.rand(B * N, 3, generator=g)), torch.zeros(B, N, P), c(torch.randn(B, N, 22, generator=g)),
+            c(torch.randn(B, N, 64, generator=g)))
+
+
 def main():
-    B, N, P, reps = (int(a) for a in (sys.argv[1:5] + ["8", "8192", "10", "3"][len(sys.argv) - 1:]))
-    args = scene(0, B, N, P, 40, 0.3)
+    uniform = "uniform" in sys.argv
+    argv = [a for a in sys.argv if a != "uniform"]
+    B, N, P, reps = (int(a) for a in (argv[1:5] + ["8", "8192", "10", "3"][len(argv) - 1:]))
+    args = uniform_scene(0, B, N, P) if uniform else scene(0, B, N, P, 40, 0.3)
     kw = dict(semantic_classes=P, radius=0.03, similarity_threshold_inst=0.989, similarity_threshold_para=0.0,
               mean_active=300, min_npoint=50)
     for name, fn in (("device", forward_grouping_device), ("literal", forward_grouping)):
