@@ -1,0 +1,260 @@
+// sparseconv.hip -- the sparse 3-D convolutions of the instance-refinement "tiny U-Net" (softgroup/model/blocks.py:
+// 44-143, models/dgcnn-hais-concat-direct-4.py:611-616,1379-1392).  The reference takes them from the third-party
+// `spconv` package (not vendored, no version pinned); this file states the same operators on the format
+// clusters_voxelization already produces -- features (M,C) f32, coords (M,4) int32 [sample,x,y,z] -- as
+// gather -> GEMM on the f32 matrix cores.  SURVEY.md section 8(f) rank 3.
+//
+//   rule tables   MI355X has 288 GB: the voxel index is a DENSE int32 grid [sample][x][y][z] (210 MB for 200 proposals
+//                 at 64^3), so a neighbour lookup is one load -- no hash table, no sort.
+//                   submanifold 3x3x3:  nbr (M,27): index of the voxel at offset (dx,dy,dz), k = (dx+1)*9+(dy+1)*3+dz+1
+//                   stride-2 2x2x2:     coarse voxels numbered in key order (flag grid + exclusive scan);
+//                                       child (M2,8) for the forward, parent slot (M,8) (one entry) for the inverse
+//   sc_gather_gemm   out[o, :] = sum_k in[rule[o,k], :] . W[k]   (rule < 0: no contribution).  One kernel serves the
+//                 forward of all three conv types and every input gradient (the transposed rule table of a
+//                 submanifold conv is its own column reversal; strided and inverse conv are each other's transpose).
+//                 A wave owns 64 output rows x 64 output columns: W[k] fragments (64x64) live in 64 VGPRs while the
+//                 four 16-row tiles are gathered (one float4 per lane per 16 input columns; lane group g = lane/16
+//                 supplies columns 4g..4g+3 as the k index of four consecutive v_mfma_f32_16x16x4_f32).
+//   sc_wgrad      dW[k] = sum_o in[rule[o,k], :]^T (x) dOut[o, :]: rows are the MFMA k dimension; 16 accumulator tiles
+//                 per wave, f32 atomics into dW at the end.
+#include "common.h"
+
+namespace gcn {
+
+using sc_f32x4 = __attribute__((__vector_size__(4 * sizeof(float)))) float;
+
+// ---------------------------------------------------------------- rule tables
+__global__ void sc_grid_fill_kernel(int M, const int32_t *__restrict__ coords, int D, int32_t *__restrict__ grid) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M) return;
+  const int32_t *c = coords + 4L * i;
+  grid[(((long)c[0] * D + c[1]) * D + c[2]) * D + c[3]] = i;
+}
+
+__global__ void sc_subm_rules_kernel(int M, const int32_t *__restrict__ coords, int D, const int32_t *__restrict__ grid,
+                                     int32_t *__restrict__ nbr) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 27L * M) return;
+  const int i = (int)(t / 27), k = (int)(t % 27);
+  const int32_t *c = coords + 4L * i;
+  const int x = c[1] + k / 9 - 1, y = c[2] + (k / 3) % 3 - 1, z = c[3] + k % 3 - 1;
+  int v = -1;
+  if (x >= 0 && x < D && y >= 0 && y < D && z >= 0 && z < D) v = grid[(((long)c[0] * D + x) * D + y) * D + z];
+  nbr[t] = v;
+}
+
+// flag the coarse cells that own a voxel
+__global__ void sc_coarse_flag_kernel(int M, const int32_t *__restrict__ coords, int D2, int32_t *__restrict__ flag) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M) return;
+  const int32_t *c = coords + 4L * i;
+  flag[(((long)c[0] * D2 + (c[1] >> 1)) * D2 + (c[2] >> 1)) * D2 + (c[3] >> 1)] = 1;
+}
+
+// after the exclusive scan: rank[cell] = coarse voxel id of a flagged cell.  Writes the coarse coords, child / parent tables.
+__global__ void sc_coarse_rules_kernel(int M, const int32_t *__restrict__ coords, int D2, const int32_t *__restrict__ rank,
+                                       int32_t *__restrict__ coords2, int32_t *__restrict__ child,
+                                       int32_t *__restrict__ parent) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M) return;
+  const int32_t *c = coords + 4L * i;
+  const int o = rank[(((long)c[0] * D2 + (c[1] >> 1)) * D2 + (c[2] >> 1)) * D2 + (c[3] >> 1)];
+  const int k = ((c[1] & 1) * 2 + (c[2] & 1)) * 2 + (c[3] & 1);
+  child[8L * o + k] = i;
+  parent[8L * i + k] = o;
+  coords2[4L * o] = c[0]; coords2[4L * o + 1] = c[1] >> 1; coords2[4L * o + 2] = c[2] >> 1; coords2[4L * o + 3] = c[3] >> 1;  // same value from every child
+}
+
+// ---------------------------------------------------------------- out = sum_k gather(in, rule[:,k]) . W[k]
+// W (K, Cin, Cout) row-major, or (K, Cout, Cin) read transposed when WT (input gradients).  KREV: use rule column K-1-k
+// with weight k (the transposed rule table of a submanifold convolution).  Cin, Cout multiples of 64.
+template <bool WT, bool KREV>
+__global__ __launch_bounds__(256) void sc_gather_gemm_kernel(int Mout, int K, int Cin, int Cout, const float *__restrict__ in,
+                                                             const int32_t *__restrict__ rule, const float *__restrict__ W,
+                                                             float *__restrict__ out) {
+  const int lane = lane_id(), wave = wave_id();
+  const int li = lane & 15, lk = lane >> 4;
+  const int r0 = (blockIdx.x * 4 + wave) * 64;
+  if (r0 >= Mout) return;
+  const int n0 = blockIdx.y * 64;
+  sc_f32x4 acc[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[r][t] = {0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < K; ++k) {
+    const int kc = KREV ? K - 1 - k : k;
+    int src[4];
+    bool any = false;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = r0 + 16 * r + li;
+      src[r] = row < Mout ? rule[(long)row * K + kc] : -1;
+      any |= __ballot(src[r] >= 0) != 0ull;
+    }
+    if (!any) continue;                       // no row of this wave has a voxel at this offset
+    for (int c0 = 0; c0 < Cin; c0 += 64) {
+      // W[k] fragment of this 64x64 block: step (q, s) needs B[kdim = lk][col = li] = W[k][c0 + 16q + 4lk + s][n0 + 16t + li]
+      float wf[4][4][4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int c = c0 + 16 * q + 4 * lk + s, n = n0 + 16 * t + li;
+            wf[q][s][t] = WT ? W[((long)k * Cout + n) * Cin + c] : W[((long)k * Cin + c) * Cout + n];
+          }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (__ballot(src[r] >= 0) == 0ull) continue;
+        const float *row = in + (long)max(src[r], 0) * Cin + c0 + 4 * lk;
+        const bool ok = src[r] >= 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float4 a = *reinterpret_cast<const float4 *>(row + 16 * q);
+          if (!ok) a = float4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, wf[q][0][t], acc[r][t], 0, 0, 0);
+            acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, wf[q][1][t], acc[r][t], 0, 0, 0);
+            acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, wf[q][2][t], acc[r][t], 0, 0, 0);
+            acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, wf[q][3][t], acc[r][t], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  // D[i = 4*lk + e][j = li]
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int row = r0 + 16 * r + 4 * lk + e;
+      if (row < Mout)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) out[(long)row * Cout + n0 + 16 * t + li] = acc[r][t][e];
+    }
+}
+
+// ---------------------------------------------------------------- dW[k] = sum_o gather(in, rule[o,k])^T (x) dOut[o]
+// grid (row chunks, K, (Cin/64)*(Cout/64)); a wave walks its rows four at a time (the MFMA k dimension) and keeps the
+// 64x64 block of dW[k] as 16 accumulator tiles.  dW (K, Cin, Cout) must be zero on entry.
+__global__ __launch_bounds__(256) void sc_wgrad_kernel(int Mout, int K, int Cin, int Cout, int rows_per_block,
+                                                       const float *__restrict__ in, const int32_t *__restrict__ rule,
+                                                       const float *__restrict__ dout, float *__restrict__ dW) {
+  const int lane = lane_id(), wave = wave_id();
+  const int li = lane & 15, lk = lane >> 4;
+  const int k = blockIdx.y;
+  const int c0 = (blockIdx.z / (Cout / 64)) * 64, n0 = (blockIdx.z % (Cout / 64)) * 64;
+  const int b0 = blockIdx.x * rows_per_block, b1 = min(b0 + rows_per_block, Mout);
+  sc_f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[a][t] = {0.f, 0.f, 0.f, 0.f};
+  for (int o0 = b0 + 4 * wave; o0 < b1; o0 += 16) {
+    const int o = o0 + lk;
+    const int src = o < b1 ? rule[(long)o * K + k] : -1;
+    if (__ballot(src >= 0) == 0ull) continue;
+    const bool ok = src >= 0;
+    const float *xi = in + (long)max(src, 0) * Cin + c0 + li;
+    const float *dy = dout + (long)min(o, Mout - 1) * Cout + n0 + li;
+    float av[4], bv[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) { const float v = xi[16 * a]; av[a] = ok ? v : 0.f; }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { const float v = dy[16 * t]; bv[t] = ok ? v : 0.f; }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[t], acc[a][t], 0, 0, 0);
+  }
+  // D[i = c = 4*lk + e][j = n = li]
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v = acc[a][t][e];
+        if (v != 0.f) atomicAdd(dW + ((long)k * Cin + c0 + 16 * a + 4 * lk + e) * Cout + n0 + 16 * t + li, v);
+      }
+}
+
+}  // namespace gcn
+
+using namespace gcn;
+
+GCN_EXPORT long gcn_sparse_grid_bytes(int batch, int D) {
+  if (batch < 0 || D <= 0) return -1;
+  return 4L * batch * D * D * D;
+}
+
+GCN_EXPORT int gcn_sparse_subm_rules(int M, const int32_t *coords, int batch, int D, int32_t *grid, int32_t *nbr, void *stream) {
+  GCN_REQUIRE(M >= 0 && batch >= 1 && D >= 1, "gcn_sparse_subm_rules: bad shape");
+  if (M == 0) return GCN_OK;
+  GCN_REQUIRE(coords && grid && nbr, "gcn_sparse_subm_rules: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  GCN_HIP(hipMemsetAsync(grid, 0xff, (size_t)gcn_sparse_grid_bytes(batch, D), st));
+  sc_grid_fill_kernel<<<cdiv(M, 256), 256, 0, st>>>(M, coords, D, grid);
+  sc_subm_rules_kernel<<<cdiv(27L * M, 256), 256, 0, st>>>(M, coords, D, grid, nbr);
+  return check_launch("sc_subm_rules_kernel");
+}
+
+GCN_EXPORT long gcn_sparse_coarse_ws_bytes(int batch, int D) {
+  if (batch < 0 || D <= 0) return -1;
+  const long cells = (long)batch * ((D + 1) / 2) * ((D + 1) / 2) * ((D + 1) / 2) + 1;
+  return 4L * (cells + scan_blocks(cells) + 16);
+}
+
+GCN_EXPORT int gcn_sparse_coarse_rules(int M, const int32_t *coords, int batch, int D, void *ws, int32_t *coords2,
+                                       int32_t *child, int32_t *parent, int32_t *m2_dev, void *stream) {
+  GCN_REQUIRE(M >= 0 && batch >= 1 && D >= 1, "gcn_sparse_coarse_rules: bad shape");
+  GCN_REQUIRE(m2_dev, "gcn_sparse_coarse_rules: m2_dev is null");
+  hipStream_t st = (hipStream_t)stream;
+  GCN_HIP(hipMemsetAsync(m2_dev, 0, sizeof(int32_t), st));
+  if (M == 0) return GCN_OK;
+  GCN_REQUIRE(coords && ws && coords2 && child && parent, "gcn_sparse_coarse_rules: null pointer");
+  const int D2 = (D + 1) / 2;
+  const long cells = (long)batch * D2 * D2 * D2 + 1;
+  GCN_REQUIRE(cells < (1L << 31), "gcn_sparse_coarse_rules: grid too large");
+  int32_t *flag = (int32_t *)ws, *bsum = flag + cells;
+  GCN_HIP(hipMemsetAsync(flag, 0, sizeof(int32_t) * (size_t)cells, st));
+  GCN_HIP(hipMemsetAsync(child, 0xff, sizeof(int32_t) * 8 * (size_t)M, st));      // at most M coarse voxels
+  GCN_HIP(hipMemsetAsync(parent, 0xff, sizeof(int32_t) * 8 * (size_t)M, st));
+  sc_coarse_flag_kernel<<<cdiv(M, 256), 256, 0, st>>>(M, coords, D2, flag);
+  exscan_rows(st, 1, (int)cells, flag, bsum);                 // flag[cells-1] = number of coarse voxels
+  sc_coarse_rules_kernel<<<cdiv(M, 256), 256, 0, st>>>(M, coords, D2, flag, coords2, child, parent);
+  GCN_HIP(hipMemcpyAsync(m2_dev, flag + cells - 1, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+  return check_launch("sc_coarse_rules_kernel");
+}
+
+GCN_EXPORT int gcn_sparse_gather_gemm(int Mout, int K, int Cin, int Cout, const float *in, const int32_t *rule, const float *W,
+                                      int w_transposed, int k_reversed, float *out, void *stream) {
+  GCN_REQUIRE(Mout >= 0 && K >= 1 && Cin > 0 && Cout > 0 && Cin % 64 == 0 && Cout % 64 == 0,
+              "gcn_sparse_gather_gemm: channels must be multiples of 64 (Cin=%d, Cout=%d)", Cin, Cout);
+  if (Mout == 0) return GCN_OK;
+  GCN_REQUIRE(in && rule && W && out, "gcn_sparse_gather_gemm: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(cdiv(Mout, 256), Cout / 64);
+  if (w_transposed && k_reversed) sc_gather_gemm_kernel<true, true><<<grid, 256, 0, st>>>(Mout, K, Cin, Cout, in, rule, W, out);
+  else if (w_transposed) sc_gather_gemm_kernel<true, false><<<grid, 256, 0, st>>>(Mout, K, Cin, Cout, in, rule, W, out);
+  else if (k_reversed) sc_gather_gemm_kernel<false, true><<<grid, 256, 0, st>>>(Mout, K, Cin, Cout, in, rule, W, out);
+  else sc_gather_gemm_kernel<false, false><<<grid, 256, 0, st>>>(Mout, K, Cin, Cout, in, rule, W, out);
+  return check_launch("sc_gather_gemm_kernel");
+}
+
+GCN_EXPORT int gcn_sparse_wgrad(int Mout, int K, int Cin, int Cout, const float *in, const int32_t *rule, const float *dout,
+                                float *dW, void *stream) {
+  GCN_REQUIRE(Mout >= 0 && K >= 1 && Cin > 0 && Cout > 0 && Cin % 64 == 0 && Cout % 64 == 0,
+              "gcn_sparse_wgrad: channels must be multiples of 64 (Cin=%d, Cout=%d)", Cin, Cout);
+  GCN_REQUIRE(dW, "gcn_sparse_wgrad: dW is null");
+  hipStream_t st = (hipStream_t)stream;
+  GCN_HIP(hipMemsetAsync(dW, 0, sizeof(float) * (size_t)K * Cin * Cout, st));
+  if (Mout == 0) return GCN_OK;
+  GCN_REQUIRE(in && rule && dout, "gcn_sparse_wgrad: null pointer");
+  const int rows = 1024;
+  sc_wgrad_kernel<<<dim3(cdiv(Mout, rows), K, (Cin / 64) * (Cout / 64)), 256, 0, st>>>(Mout, K, Cin, Cout, rows, in, rule, dout, dW);
+  return check_launch("sc_wgrad_kernel");
+}

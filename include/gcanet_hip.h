@@ -175,6 +175,29 @@ long gcn_cluster_components_ws_bytes(int n);
 int gcn_cluster_components(int n, const int32_t *nbr, const int32_t *start_len, const int32_t *seg_of,
                            const int32_t *seg_offsets, const int32_t *seg_cls, int S, const int32_t *point_index,
                            void *ws, int32_t *cluster_idxs, int32_t *cluster_offsets, int32_t *counts, void *stream);
+/* ---- sparse 3-D convolutions of the instance "tiny U-Net" (softgroup/model/blocks.py:44-143; M4:611-616,1379-1392;
+ * the reference calls the un-vendored third-party spconv package: SubMConv3d / SparseConv3d(k=2,s=2) /
+ * SparseInverseConv3d).  Sparse tensor = features (M,C) f32 + coords (M,4) int32 [sample,x,y,z] with 0 <= x,y,z < D,
+ * the on-wire format of clusters_voxelization (M4:1300-1355).  SURVEY.md section 8f rank 3. ---- */
+long gcn_sparse_grid_bytes(int batch, int D);                 /* dense voxel-index grid, int32 [batch][D][D][D] */
+/* nbr (M,27): index of the active voxel at offset (dx,dy,dz) in {-1,0,1}^3, column k = (dx+1)*9 + (dy+1)*3 + (dz+1);
+ * -1 where there is none.  grid: gcn_sparse_grid_bytes scratch (left filled: grid[sample][x][y][z] = voxel or -1). */
+int gcn_sparse_subm_rules(int M, const int32_t *coords, int batch, int D, int32_t *grid, int32_t *nbr, void *stream);
+/* stride-2 kernel-2 downsampling: coarse voxels = occupied 2x2x2 cells, numbered in (sample,x,y,z) order.  coords2 (<=M,4),
+ * child (<=M,8): fine voxel of coarse voxel o at corner k = (x&1)*4 + (y&1)*2 + (z&1) or -1; parent (M,8): row i holds its
+ * coarse voxel in column k(i), -1 elsewhere (the rule table of the inverse convolution); *m2_dev (device) = number of
+ * coarse voxels.  ws: gcn_sparse_coarse_ws_bytes. */
+long gcn_sparse_coarse_ws_bytes(int batch, int D);
+int gcn_sparse_coarse_rules(int M, const int32_t *coords, int batch, int D, void *ws, int32_t *coords2, int32_t *child,
+                            int32_t *parent, int32_t *m2_dev, void *stream);
+/* out (Mout,Cout) = sum_k in[rule[o,k], :] . W[k]  (rule < 0 contributes nothing); rule (Mout,K).  W (K,Cin,Cout), or
+ * (K,Cout,Cin) used transposed when w_transposed; k_reversed pairs rule column K-1-k with W[k] (input gradient of a
+ * submanifold convolution).  Cin, Cout multiples of 64.  f32 on v_mfma_f32_16x16x4_f32. */
+int gcn_sparse_gather_gemm(int Mout, int K, int Cin, int Cout, const float *in, const int32_t *rule, const float *W,
+                           int w_transposed, int k_reversed, float *out, void *stream);
+/* dW (K,Cin,Cout) = sum_o in[rule[o,k], :]^T (x) dout[o, :]  (zeroed here first). */
+int gcn_sparse_wgrad(int Mout, int K, int Cin, int Cout, const float *in, const int32_t *rule, const float *dout, float *dW,
+                     void *stream);
 /* Device scratch for the uniform-grid path of gcn_ballquery_batch_p (easy form, n >= 2048): pass it as grid_ws
  * (NULL selects the brute-force scan).  nbatch = number of batch segments (len(batch_offsets) - 1). */
 long gcn_ballquery_grid_ws_bytes(int n);

@@ -332,3 +332,79 @@ def hot_path(sd, points, normals, k, knn_fn=None, idxs=None):
     return dict(type_per_point=type_per_point, param_per_point=param,
                 semantic_scores=type_forgroup.reshape(-1, type_forgroup.shape[-1]),
                 pt_offsets=off.permute(0, 2, 1).reshape(-1, 3), output_feats=output_feats), used
+
+
+# ------------------------------------------------------------------------------------------
+# Sparse convolutions of the instance tiny U-Net by their DEFINITION: a dense conv3d on the densified grid, read back at
+# the active sites (softgroup/model/blocks.py:44-143 uses the un-vendored spconv package for these; "parity unpinned").
+# Weights (K, Cin, Cout), K = 27 offsets (dx,dy,dz) x-major resp. 8 corners -- the layout of gcanet_amd/sparseconv.py.
+# ------------------------------------------------------------------------------------------
+def _densify(feats, idx, D, batch):
+    out = feats.new_zeros(batch, D, D, D, feats.shape[1])
+    i = idx.long()
+    out[i[:, 0], i[:, 1], i[:, 2], i[:, 3]] = feats
+    return out.permute(0, 4, 1, 2, 3)
+
+
+def _read(dense, idx):
+    i = idx.long()
+    return dense.permute(0, 2, 3, 4, 1)[i[:, 0], i[:, 1], i[:, 2], i[:, 3]]
+
+
+def subm_conv3(feats, idx, D, batch, W):
+    """SubMConv3d(k=3, pad=1, no bias): out[x] = sum_d W[d] . in[x+d] at the active sites only."""
+    Cin, Cout = W.shape[1], W.shape[2]
+    w = W.view(3, 3, 3, Cin, Cout).permute(4, 3, 0, 1, 2)
+    return _read(F.conv3d(_densify(feats, idx, D, batch), w, padding=1), idx)
+
+
+def coarse_sites(idx):
+    """Occupied 2x2x2 cells in (sample, x, y, z) order -> (M2,4)."""
+    c = idx.long().clone()
+    c[:, 1:] //= 2
+    return torch.unique(c, dim=0).to(idx.dtype)
+
+
+def strided_conv2(feats, idx, D, batch, W):
+    """SparseConv3d(k=2, s=2, no bias) -> (feats2, idx2)."""
+    Cin, Cout = W.shape[1], W.shape[2]
+    w = W.view(2, 2, 2, Cin, Cout).permute(4, 3, 0, 1, 2)
+    Dp = D + (D % 2)
+    dense = F.pad(_densify(feats, idx, D, batch), (0, Dp - D, 0, Dp - D, 0, Dp - D))
+    idx2 = coarse_sites(idx)
+    return _read(F.conv3d(dense, w, stride=2), idx2), idx2
+
+
+def inverse_conv2(feats2, idx2, D, batch, W, idx_fine):
+    """SparseInverseConv3d(k=2): out[i] = W[corner(i)] . in2[parent(i)] on the fine sites of the paired strided conv."""
+    Cin, Cout = W.shape[1], W.shape[2]
+    w = W.view(2, 2, 2, Cin, Cout).permute(3, 4, 0, 1, 2)
+    D2 = (D + 1) // 2
+    up = F.conv_transpose3d(_densify(feats2, idx2, D2, batch), w, stride=2)[:, :, :D, :D, :D]
+    return _read(up, idx_fine)
+
+
+def _bn(x, sd, p, eps=1e-4):
+    return F.batch_norm(x, None, None, sd[p + ".weight"], sd[p + ".bias"], True, 0.1, eps)
+
+
+def _res_block(sd, p, x, idx, D, batch):
+    h = subm_conv3(F.relu(_bn(x, sd, p + ".conv_branch.0")), idx, D, batch, sd[p + ".conv_branch.2.weight"])
+    h = subm_conv3(F.relu(_bn(h, sd, p + ".conv_branch.3")), idx, D, batch, sd[p + ".conv_branch.5.weight"])
+    ib = p + ".i_branch.0.weight"
+    return h + (x @ sd[ib].t() if ib in sd else x)
+
+
+def tiny_unet(sd, feats, idx, D, batch, prefix="tiny_unet", reps=2):
+    """UBlock([C, 2C], BatchNorm1d(eps 1e-4), 2, ResidualBlock) in training mode (blocks.py:83-143)."""
+    x = feats
+    for i in range(reps):
+        x = _res_block(sd, "%s.blocks.block%d" % (prefix, i), x, idx, D, batch)
+    if (prefix + ".conv.2.weight") in sd:
+        h, idx2 = strided_conv2(F.relu(_bn(x, sd, prefix + ".conv.0")), idx, D, batch, sd[prefix + ".conv.2.weight"])
+        h = tiny_unet(sd, h, idx2, (D + 1) // 2, batch, prefix + ".u", reps)
+        h = inverse_conv2(F.relu(_bn(h, sd, prefix + ".deconv.0")), idx2, D, batch, sd[prefix + ".deconv.2.weight"], idx)
+        x = torch.cat((x, h), dim=1)
+        for i in range(reps):
+            x = _res_block(sd, "%s.blocks_tail.block%d" % (prefix, i), x, idx, D, batch)
+    return x
