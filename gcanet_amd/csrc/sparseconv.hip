@@ -68,107 +68,138 @@ __global__ void sc_coarse_rules_kernel(int M, const int32_t *__restrict__ coords
 // ---------------------------------------------------------------- out = sum_k gather(in, rule[:,k]) . W[k]
 // W (K, Cin, Cout) row-major, or (K, Cout, Cin) read transposed when WT (input gradients).  KREV: use rule column K-1-k
 // with weight k (the transposed rule table of a submanifold convolution).  Cin, Cout multiples of 64.
+//
+// Voxelised surfaces fill ~10-30 % of the 27 neighbour slots, so a 16-row MFMA tile taken from consecutive output rows
+// would be mostly zeros.  A wave therefore owns 64 output rows x 64 output columns with the ACCUMULATORS IN LDS (16 KB),
+// and per offset k compacts the rows that do have a neighbour (ballot) into tiles of 16 (row, source) pairs: the MFMA
+// count follows the pairs, not the rows.  A tile's product is added to the LDS rows of its pairs (no conflicts: a row
+// appears once per offset; one wave owns the rows).
 template <bool WT, bool KREV>
 __global__ __launch_bounds__(256) void sc_gather_gemm_kernel(int Mout, int K, int Cin, int Cout, const float *__restrict__ in,
                                                              const int32_t *__restrict__ rule, const float *__restrict__ W,
                                                              float *__restrict__ out) {
+  constexpr int LD = 64 + 4;                                   // accumulator row stride (floats)
+  __shared__ float accs[4][64 * LD];
+  __shared__ int prow[4][64], psrc[4][64];
   const int lane = lane_id(), wave = wave_id();
   const int li = lane & 15, lk = lane >> 4;
   const int r0 = (blockIdx.x * 4 + wave) * 64;
   if (r0 >= Mout) return;
   const int n0 = blockIdx.y * 64;
-  sc_f32x4 acc[4][4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc[r][t] = {0.f, 0.f, 0.f, 0.f};
+  float *acc = accs[wave];
+  int *pr = prow[wave], *ps = psrc[wave];
+  for (int i = lane; i < 64 * LD; i += 64) acc[i] = 0.f;
+  const int myrow = r0 + lane;
+  const unsigned long long lt = (1ull << lane) - 1ull;
   for (int k = 0; k < K; ++k) {
     const int kc = KREV ? K - 1 - k : k;
-    int src[4];
-    bool any = false;
+    const int src = myrow < Mout ? rule[(long)myrow * K + kc] : -1;
+    const unsigned long long mask = __ballot(src >= 0);
+    const int c = __popcll(mask);
+    if (c == 0) continue;
+    __builtin_amdgcn_wave_barrier();
+    if (src >= 0) { const int pos = __popcll(mask & lt); pr[pos] = lane; ps[pos] = src; }
+    __builtin_amdgcn_wave_barrier();
+    for (int j0 = 0; j0 < c; j0 += 16) {
+      const int pa = j0 + li;                                  // the pair this lane gathers (A operand row li)
+      const bool oka = pa < c;
+      const float *arow = in + (long)(oka ? ps[pa] : 0) * Cin + 4 * lk;
+      sc_f32x4 d[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = r0 + 16 * r + li;
-      src[r] = row < Mout ? rule[(long)row * K + kc] : -1;
-      any |= __ballot(src[r] >= 0) != 0ull;
-    }
-    if (!any) continue;                       // no row of this wave has a voxel at this offset
-    for (int c0 = 0; c0 < Cin; c0 += 64) {
-      // W[k] fragment of this 64x64 block: step (q, s) needs B[kdim = lk][col = li] = W[k][c0 + 16q + 4lk + s][n0 + 16t + li]
-      float wf[4][4][4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const int c = c0 + 16 * q + 4 * lk + s, n = n0 + 16 * t + li;
-            wf[q][s][t] = WT ? W[((long)k * Cout + n) * Cin + c] : W[((long)k * Cin + c) * Cout + n];
-          }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (__ballot(src[r] >= 0) == 0ull) continue;
-        const float *row = in + (long)max(src[r], 0) * Cin + c0 + 4 * lk;
-        const bool ok = src[r] >= 0;
+      for (int t = 0; t < 4; ++t) d[t] = {0.f, 0.f, 0.f, 0.f};
+      for (int c0 = 0; c0 < Cin; c0 += 64) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          float4 a = *reinterpret_cast<const float4 *>(row + 16 * q);
-          if (!ok) a = float4{0.f, 0.f, 0.f, 0.f};
+          float4 a = *reinterpret_cast<const float4 *>(arow + c0 + 16 * q);
+          if (!oka) a = float4{0.f, 0.f, 0.f, 0.f};
+          // B[kdim = lk][col = li] of step s = W[k][c0 + 16q + 4lk + s][n0 + 16t + li]
+          float wf[4][4];
+#pragma unroll
+          for (int sI = 0; sI < 4; ++sI)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const int cc = c0 + 16 * q + 4 * lk + sI, n = n0 + 16 * t + li;
+              wf[sI][t] = WT ? W[((long)k * Cout + n) * Cin + cc] : W[((long)k * Cin + cc) * Cout + n];
+            }
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
-            acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, wf[q][0][t], acc[r][t], 0, 0, 0);
-            acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, wf[q][1][t], acc[r][t], 0, 0, 0);
-            acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, wf[q][2][t], acc[r][t], 0, 0, 0);
-            acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, wf[q][3][t], acc[r][t], 0, 0, 0);
+            d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, wf[0][t], d[t], 0, 0, 0);
+            d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, wf[1][t], d[t], 0, 0, 0);
+            d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, wf[2][t], d[t], 0, 0, 0);
+            d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, wf[3][t], d[t], 0, 0, 0);
           }
+        }
+      }
+      // D[i = 4*lk + e][j = li] belongs to the output row of pair j0 + 4*lk + e
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int pd = j0 + 4 * lk + e;
+        if (pd < c) {
+          float *dst = acc + pr[pd] * LD + li;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) dst[16 * t] += d[t][e];
         }
       }
     }
   }
-  // D[i = 4*lk + e][j = li]
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int row = r0 + 16 * r + 4 * lk + e;
-      if (row < Mout)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) out[(long)row * Cout + n0 + 16 * t + li] = acc[r][t][e];
+  __builtin_amdgcn_wave_barrier();
+  for (int i = lane; i < 64 * 16; i += 64) {                    // 16 float4 per row
+    const int row = i >> 4, c4 = (i & 15) * 4;
+    if (r0 + row < Mout) {
+      const float *sp = acc + row * LD + c4;
+      *reinterpret_cast<float4 *>(out + (long)(r0 + row) * Cout + n0 + c4) = float4{sp[0], sp[1], sp[2], sp[3]};
     }
+  }
 }
 
 // ---------------------------------------------------------------- dW[k] = sum_o gather(in, rule[o,k])^T (x) dOut[o]
-// grid (row chunks, K, (Cin/64)*(Cout/64)); a wave walks its rows four at a time (the MFMA k dimension) and keeps the
-// 64x64 block of dW[k] as 16 accumulator tiles.  dW (K, Cin, Cout) must be zero on entry.
+// grid (row chunks, K, (Cin/64)*(Cout/64)); ruleT (K, Mout) is the transposed rule table (coalesced column reads).  A
+// wave takes 256 rows at a time, compacts the (o, source) pairs of offset k and feeds them four at a time as the MFMA k
+// dimension; the 64x64 block of dW[k] is 16 accumulator tiles.  dW (K, Cin, Cout) must be zero on entry.
 __global__ __launch_bounds__(256) void sc_wgrad_kernel(int Mout, int K, int Cin, int Cout, int rows_per_block,
-                                                       const float *__restrict__ in, const int32_t *__restrict__ rule,
+                                                       const float *__restrict__ in, const int32_t *__restrict__ ruleT,
                                                        const float *__restrict__ dout, float *__restrict__ dW) {
+  __shared__ int po[4][256], psr[4][256];
   const int lane = lane_id(), wave = wave_id();
   const int li = lane & 15, lk = lane >> 4;
   const int k = blockIdx.y;
   const int c0 = (blockIdx.z / (Cout / 64)) * 64, n0 = (blockIdx.z % (Cout / 64)) * 64;
   const int b0 = blockIdx.x * rows_per_block, b1 = min(b0 + rows_per_block, Mout);
+  const int32_t *rk = ruleT + (long)k * Mout;
+  int *qo = po[wave], *qs = psr[wave];
+  const unsigned long long lt = (1ull << lane) - 1ull;
   sc_f32x4 acc[4][4];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[a][t] = {0.f, 0.f, 0.f, 0.f};
-  for (int o0 = b0 + 4 * wave; o0 < b1; o0 += 16) {
-    const int o = o0 + lk;
-    const int src = o < b1 ? rule[(long)o * K + k] : -1;
-    if (__ballot(src >= 0) == 0ull) continue;
-    const bool ok = src >= 0;
-    const float *xi = in + (long)max(src, 0) * Cin + c0 + li;
-    const float *dy = dout + (long)min(o, Mout - 1) * Cout + n0 + li;
-    float av[4], bv[4];
+  for (int o0 = b0 + 256 * wave; o0 < b1; o0 += 1024) {
+    int c = 0;
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int a = 0; a < 4; ++a) { const float v = xi[16 * a]; av[a] = ok ? v : 0.f; }
+    for (int u = 0; u < 4; ++u) {
+      const int o = o0 + 64 * u + lane;
+      const int src = o < b1 ? rk[o] : -1;
+      const unsigned long long mask = __ballot(src >= 0);
+      if (src >= 0) { const int pos = c + __popcll(mask & lt); qo[pos] = o; qs[pos] = src; }
+      c += __popcll(mask);
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int p0 = 0; p0 < c; p0 += 4) {
+      const int p = p0 + lk;
+      const bool ok = p < c;
+      const float *xi = in + (long)(ok ? qs[p] : 0) * Cin + c0 + li;
+      const float *dy = dout + (long)(ok ? qo[p] : 0) * Cout + n0 + li;
+      float av[4], bv[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) { const float v = dy[16 * t]; bv[t] = ok ? v : 0.f; }
+      for (int a = 0; a < 4; ++a) { const float v = xi[16 * a]; av[a] = ok ? v : 0.f; }
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+      for (int t = 0; t < 4; ++t) { const float v = dy[16 * t]; bv[t] = ok ? v : 0.f; }
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[t], acc[a][t], 0, 0, 0);
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[t], acc[a][t], 0, 0, 0);
+    }
   }
   // D[i = c = 4*lk + e][j = n = li]
 #pragma unroll
@@ -245,7 +276,7 @@ GCN_EXPORT int gcn_sparse_gather_gemm(int Mout, int K, int Cin, int Cout, const 
   return check_launch("sc_gather_gemm_kernel");
 }
 
-GCN_EXPORT int gcn_sparse_wgrad(int Mout, int K, int Cin, int Cout, const float *in, const int32_t *rule, const float *dout,
+GCN_EXPORT int gcn_sparse_wgrad(int Mout, int K, int Cin, int Cout, const float *in, const int32_t *ruleT, const float *dout,
                                 float *dW, void *stream) {
   GCN_REQUIRE(Mout >= 0 && K >= 1 && Cin > 0 && Cout > 0 && Cin % 64 == 0 && Cout % 64 == 0,
               "gcn_sparse_wgrad: channels must be multiples of 64 (Cin=%d, Cout=%d)", Cin, Cout);
@@ -253,8 +284,8 @@ GCN_EXPORT int gcn_sparse_wgrad(int Mout, int K, int Cin, int Cout, const float 
   hipStream_t st = (hipStream_t)stream;
   GCN_HIP(hipMemsetAsync(dW, 0, sizeof(float) * (size_t)K * Cin * Cout, st));
   if (Mout == 0) return GCN_OK;
-  GCN_REQUIRE(in && rule && dout, "gcn_sparse_wgrad: null pointer");
-  const int rows = 1024;
-  sc_wgrad_kernel<<<dim3(cdiv(Mout, rows), K, (Cin / 64) * (Cout / 64)), 256, 0, st>>>(Mout, K, Cin, Cout, rows, in, rule, dout, dW);
+  GCN_REQUIRE(in && ruleT && dout, "gcn_sparse_wgrad: null pointer");
+  const int rows = 4096;
+  sc_wgrad_kernel<<<dim3(cdiv(Mout, rows), K, (Cin / 64) * (Cout / 64)), 256, 0, st>>>(Mout, K, Cin, Cout, rows, in, ruleT, dout, dW);
   return check_launch("sc_wgrad_kernel");
 }

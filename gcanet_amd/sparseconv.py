@@ -81,10 +81,11 @@ def coarse_rules(x: SparseConvTensor):
 
 
 class GatherGemmFunction(torch.autograd.Function):
-    """out = sum_k in[rule[:,k]] @ W[k].  `rule_t` / `k_rev_t` describe the transposed gather (the input gradient)."""
+    """out = sum_k in[rule[:,k]] @ W[k].  `rule_t` / `k_rev_t` describe the transposed gather (the input gradient);
+    `rule_cols` = rule.t().contiguous() (K, Mout), the layout the weight-gradient kernel reads."""
 
     @staticmethod
-    def forward(ctx, feats, weight, rule, rule_t, k_rev_t):
+    def forward(ctx, feats, weight, rule, rule_t, k_rev_t, rule_cols):
         _lib.require_cuda(feats, weight)
         feats, weight = feats.float().contiguous(), weight.float().contiguous()
         K, Cin, Cout = weight.shape
@@ -92,13 +93,13 @@ class GatherGemmFunction(torch.autograd.Function):
         out = torch.empty(Mout, Cout, dtype=torch.float32, device=feats.device)
         _call("gcn_sparse_gather_gemm", feats, Mout, K, Cin, Cout, _lib.ptr(feats), _lib.ptr(rule), _lib.ptr(weight), 0, 0,
               _lib.ptr(out))
-        ctx.save_for_backward(feats, weight, rule, rule_t)
+        ctx.save_for_backward(feats, weight, rule_cols, rule_t)
         ctx.k_rev_t = bool(k_rev_t)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        feats, weight, rule, rule_t = ctx.saved_tensors
+        feats, weight, rule_cols, rule_t = ctx.saved_tensors
         K, Cin, Cout = weight.shape
         dout = dout.float().contiguous()
         din = dw = None
@@ -109,9 +110,9 @@ class GatherGemmFunction(torch.autograd.Function):
                   int(ctx.k_rev_t), _lib.ptr(din))
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(weight)
-            _call("gcn_sparse_wgrad", dout, rule.shape[0], K, Cin, Cout, _lib.ptr(feats), _lib.ptr(rule), _lib.ptr(dout),
-                  _lib.ptr(dw))
-        return din, dw, None, None, None
+            _call("gcn_sparse_wgrad", dout, rule_cols.shape[1], K, Cin, Cout, _lib.ptr(feats), _lib.ptr(rule_cols),
+                  _lib.ptr(dout), _lib.ptr(dw))
+        return din, dw, None, None, None, None
 
 
 class _SparseConvBase(nn.Module):
@@ -132,9 +133,10 @@ class SubMConv3d(_SparseConvBase):
     def forward(self, x: SparseConvTensor):
         key = ("subm", self.indice_key)
         if key not in x.rules:
-            x.rules[key] = subm_rules(x)
-        nbr = x.rules[key]
-        return x.replace_feature(GatherGemmFunction.apply(x.features, self.weight, nbr, nbr, True))
+            nbr = subm_rules(x)
+            x.rules[key] = (nbr, nbr.t().contiguous())
+        nbr, nbr_cols = x.rules[key]
+        return x.replace_feature(GatherGemmFunction.apply(x.features, self.weight, nbr, nbr, True, nbr_cols))
 
 
 class SparseConv3d(_SparseConvBase):
@@ -144,9 +146,10 @@ class SparseConv3d(_SparseConvBase):
     def forward(self, x: SparseConvTensor):
         key = ("spconv", self.indice_key)
         if key not in x.rules:
-            x.rules[key] = coarse_rules(x) + (x.indices, x.spatial_shape)
-        coords2, child, parent, _, _ = x.rules[key]
-        feats = GatherGemmFunction.apply(x.features, self.weight, child, parent, False)
+            coords2, child, parent = coarse_rules(x)
+            x.rules[key] = (coords2, child, parent, x.indices, x.spatial_shape, child.t().contiguous(), parent.t().contiguous())
+        coords2, child, parent, _, _, child_cols, _ = x.rules[key]
+        feats = GatherGemmFunction.apply(x.features, self.weight, child, parent, False, child_cols)
         return SparseConvTensor(feats, coords2, [(x.D + 1) // 2] * 3, x.batch_size, x.rules)
 
 
@@ -155,8 +158,8 @@ class SparseInverseConv3d(_SparseConvBase):
     K = 8
 
     def forward(self, x: SparseConvTensor):
-        coords2, child, parent, fine_indices, fine_shape = x.rules[("spconv", self.indice_key)]
-        feats = GatherGemmFunction.apply(x.features, self.weight, parent, child, False)
+        coords2, child, parent, fine_indices, fine_shape, _, parent_cols = x.rules[("spconv", self.indice_key)]
+        feats = GatherGemmFunction.apply(x.features, self.weight, parent, child, False, parent_cols)
         return SparseConvTensor(feats, fine_indices, fine_shape, x.batch_size, x.rules)
 
 

@@ -195,8 +195,9 @@ int gcn_sparse_coarse_rules(int M, const int32_t *coords, int batch, int D, void
  * submanifold convolution).  Cin, Cout multiples of 64.  f32 on v_mfma_f32_16x16x4_f32. */
 int gcn_sparse_gather_gemm(int Mout, int K, int Cin, int Cout, const float *in, const int32_t *rule, const float *W,
                            int w_transposed, int k_reversed, float *out, void *stream);
-/* dW (K,Cin,Cout) = sum_o in[rule[o,k], :]^T (x) dout[o, :]  (zeroed here first). */
-int gcn_sparse_wgrad(int Mout, int K, int Cin, int Cout, const float *in, const int32_t *rule, const float *dout, float *dW,
+/* dW (K,Cin,Cout) = sum_o in[rule[o,k], :]^T (x) dout[o, :]  (zeroed here first).  ruleT (K,Mout): the rule table
+ * transposed, so that one offset's column is contiguous. */
+int gcn_sparse_wgrad(int Mout, int K, int Cin, int Cout, const float *in, const int32_t *ruleT, const float *dout, float *dW,
                      void *stream);
 /* Device scratch for the uniform-grid path of gcn_ballquery_batch_p (easy form, n >= 2048): pass it as grid_ws
  * (NULL selects the brute-force scan).  nbatch = number of batch segments (len(batch_offsets) - 1). */
