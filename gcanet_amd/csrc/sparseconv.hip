@@ -66,89 +66,99 @@ __global__ void sc_coarse_rules_kernel(int M, const int32_t *__restrict__ coords
 }
 
 // ---------------------------------------------------------------- out = sum_k gather(in, rule[:,k]) . W[k]
-// W (K, Cin, Cout) row-major, or (K, Cout, Cin) read transposed when WT (input gradients).  KREV: use rule column K-1-k
-// with weight k (the transposed rule table of a submanifold convolution).  Cin, Cout multiples of 64.
+// W (K, Cin, Cout) row-major.  KREV: use rule column K-1-k with weight k (the transposed rule table of a submanifold
+// convolution).  Cin, Cout multiples of 64.
 //
 // Voxelised surfaces fill ~10-30 % of the 27 neighbour slots, so a 16-row MFMA tile taken from consecutive output rows
-// would be mostly zeros.  A wave therefore owns 64 output rows x 64 output columns with the ACCUMULATORS IN LDS (16 KB),
-// and per offset k compacts the rows that do have a neighbour (ballot) into tiles of 16 (row, source) pairs: the MFMA
-// count follows the pairs, not the rows.  A tile's product is added to the LDS rows of its pairs (no conflicts: a row
-// appears once per offset; one wave owns the rows).
-template <bool WT, bool KREV>
+// would be mostly zeros.  A wave therefore owns 64 output rows x 64 output columns and per offset k compacts the rows that
+// do have a neighbour (ballot) into tiles of 16 (row, source) pairs: the MFMA count follows the pairs, not the rows.
+// Layout: lane = output row (64 rows per wave), 64 accumulator VGPRs = the row's 64 output columns.  A tile's 16x64
+// product goes through a 4 KB per-wave LDS staging buffer, from which the (at most 16) lanes owning its rows pick their
+// row up -- so the only per-wave LDS is staging + pair list, 16 waves fit a CU and hide the gather latency.  The
+// 64x64 block of W[k] is staged in LDS once per offset for the four waves of the workgroup (two barriers per offset)
+// and read as the B operand with one ds_read per MFMA; row stride 68 floats keeps the four lane groups on disjoint banks.
+template <bool KREV>
 __global__ __launch_bounds__(256) void sc_gather_gemm_kernel(int Mout, int K, int Cin, int Cout, const float *__restrict__ in,
                                                              const int32_t *__restrict__ rule, const float *__restrict__ W,
                                                              float *__restrict__ out) {
-  constexpr int LD = 64 + 4;                                   // accumulator row stride (floats)
-  __shared__ float accs[4][64 * LD];
-  __shared__ int prow[4][64], psrc[4][64];
+  constexpr int LD = 64 + 4;
+  __shared__ float wt[64 * LD];
+  __shared__ float stage[4][16 * LD];
+  __shared__ int psrc[4][64];
   const int lane = lane_id(), wave = wave_id();
   const int li = lane & 15, lk = lane >> 4;
-  const int r0 = (blockIdx.x * 4 + wave) * 64;
-  if (r0 >= Mout) return;
+  const int r0 = (blockIdx.x * 4 + wave) * 64;                 // may lie past the end: the wave still helps staging W
   const int n0 = blockIdx.y * 64;
-  float *acc = accs[wave];
-  int *pr = prow[wave], *ps = psrc[wave];
-  for (int i = lane; i < 64 * LD; i += 64) acc[i] = 0.f;
+  float *stg = stage[wave];
+  int *ps = psrc[wave];
   const int myrow = r0 + lane;
   const unsigned long long lt = (1ull << lane) - 1ull;
+  float acc[64];
+#pragma unroll
+  for (int j = 0; j < 64; ++j) acc[j] = 0.f;
   for (int k = 0; k < K; ++k) {
     const int kc = KREV ? K - 1 - k : k;
     const int src = myrow < Mout ? rule[(long)myrow * K + kc] : -1;
     const unsigned long long mask = __ballot(src >= 0);
     const int c = __popcll(mask);
-    if (c == 0) continue;
-    __builtin_amdgcn_wave_barrier();
-    if (src >= 0) { const int pos = __popcll(mask & lt); pr[pos] = lane; ps[pos] = src; }
-    __builtin_amdgcn_wave_barrier();
-    for (int j0 = 0; j0 < c; j0 += 16) {
-      const int pa = j0 + li;                                  // the pair this lane gathers (A operand row li)
-      const bool oka = pa < c;
-      const float *arow = in + (long)(oka ? ps[pa] : 0) * Cin + 4 * lk;
-      sc_f32x4 d[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) d[t] = {0.f, 0.f, 0.f, 0.f};
-      for (int c0 = 0; c0 < Cin; c0 += 64) {
+    const int pos = __popcll(mask & lt);                       // this row's place among the offset's pairs
+    if (src >= 0) ps[pos] = src;
+    for (int c0 = 0; c0 < Cin; c0 += 64) {
+      __syncthreads();                                         // previous weight tile fully consumed
+      for (int i = threadIdx.x; i < 64 * 16; i += 256) {       // W[k][c0 + row][n0 + 4*c4 ..]: 16 float4 per row
+        const int row = i >> 4, c4 = (i & 15) * 4;
+        const float4 v = *reinterpret_cast<const float4 *>(W + ((long)k * Cin + c0 + row) * Cout + n0 + c4);
+        float *d = wt + row * LD + c4;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+      }
+      __syncthreads();
+      for (int j0 = 0; j0 < c; j0 += 16) {
+        const int pa = j0 + li;                                // the pair this lane gathers (A operand row li)
+        const bool oka = pa < c;
+        const float *arow = in + (long)(oka ? ps[pa] : 0) * Cin + c0 + 4 * lk;
+        float4 a[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          float4 a = *reinterpret_cast<const float4 *>(arow + c0 + 16 * q);
-          if (!oka) a = float4{0.f, 0.f, 0.f, 0.f};
+          a[q] = *reinterpret_cast<const float4 *>(arow + 16 * q);
+          if (!oka) a[q] = float4{0.f, 0.f, 0.f, 0.f};
+        }
+        sc_f32x4 d[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) d[t] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
           // B[kdim = lk][col = li] of step s = W[k][c0 + 16q + 4lk + s][n0 + 16t + li]
-          float wf[4][4];
-#pragma unroll
-          for (int sI = 0; sI < 4; ++sI)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-              const int cc = c0 + 16 * q + 4 * lk + sI, n = n0 + 16 * t + li;
-              wf[sI][t] = WT ? W[((long)k * Cout + n) * Cin + cc] : W[((long)k * Cin + cc) * Cout + n];
-            }
+          const float *wq = wt + (16 * q + 4 * lk) * LD + li;
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
-            d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, wf[0][t], d[t], 0, 0, 0);
-            d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, wf[1][t], d[t], 0, 0, 0);
-            d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, wf[2][t], d[t], 0, 0, 0);
-            d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, wf[3][t], d[t], 0, 0, 0);
+            d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].x, wq[0 * LD + 16 * t], d[t], 0, 0, 0);
+            d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].y, wq[1 * LD + 16 * t], d[t], 0, 0, 0);
+            d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].z, wq[2 * LD + 16 * t], d[t], 0, 0, 0);
+            d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].w, wq[3 * LD + 16 * t], d[t], 0, 0, 0);
           }
         }
-      }
-      // D[i = 4*lk + e][j = li] belongs to the output row of pair j0 + 4*lk + e
+        // D[i = 4*lk + e][j = li] -> staging row i; the lane whose pair sits in slot i adds the row to its accumulators
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int pd = j0 + 4 * lk + e;
-        if (pd < c) {
-          float *dst = acc + pr[pd] * LD + li;
+        for (int e = 0; e < 4; ++e)
 #pragma unroll
-          for (int t = 0; t < 4; ++t) dst[16 * t] += d[t][e];
+          for (int t = 0; t < 4; ++t) stg[(4 * lk + e) * LD + 16 * t + li] = d[t][e];
+        __builtin_amdgcn_wave_barrier();
+        if (src >= 0 && pos >= j0 && pos < j0 + 16) {
+          const float4 *sp = reinterpret_cast<const float4 *>(stg + (pos - j0) * LD);
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            const float4 v = sp[j];
+            acc[4 * j] += v.x; acc[4 * j + 1] += v.y; acc[4 * j + 2] += v.z; acc[4 * j + 3] += v.w;
+          }
         }
       }
     }
   }
-  __builtin_amdgcn_wave_barrier();
-  for (int i = lane; i < 64 * 16; i += 64) {                    // 16 float4 per row
-    const int row = i >> 4, c4 = (i & 15) * 4;
-    if (r0 + row < Mout) {
-      const float *sp = acc + row * LD + c4;
-      *reinterpret_cast<float4 *>(out + (long)(r0 + row) * Cout + n0 + c4) = float4{sp[0], sp[1], sp[2], sp[3]};
-    }
+  if (myrow < Mout) {
+    float4 *op = reinterpret_cast<float4 *>(out + (long)myrow * Cout + n0);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) op[j] = float4{acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]};
   }
 }
 
@@ -201,16 +211,26 @@ __global__ __launch_bounds__(256) void sc_wgrad_kernel(int Mout, int K, int Cin,
         for (int t = 0; t < 4; ++t) acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[t], acc[a][t], 0, 0, 0);
     }
   }
-  // D[i = c = 4*lk + e][j = n = li]
+  // D[i = c = 4*lk + e][j = n = li]: the four waves add their blocks in LDS, then ONE atomic per element and workgroup
+  __shared__ float red[64 * 64];
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+      for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float v = acc[a][t][e];
-        if (v != 0.f) atomicAdd(dW + ((long)k * Cin + c0 + 16 * a + 4 * lk + e) * Cout + n0 + 16 * t + li, v);
-      }
+          for (int e = 0; e < 4; ++e) {
+            float *d = red + (16 * a + 4 * lk + e) * 64 + 16 * t + li;
+            *d = (w ? *d : 0.f) + acc[a][t][e];
+          }
+    }
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const float v = red[i];
+    if (v != 0.f) atomicAdd(dW + ((long)k * Cin + c0 + (i >> 6)) * Cout + n0 + (i & 63), v);
+  }
 }
 
 }  // namespace gcn
@@ -268,11 +288,10 @@ GCN_EXPORT int gcn_sparse_gather_gemm(int Mout, int K, int Cin, int Cout, const 
   if (Mout == 0) return GCN_OK;
   GCN_REQUIRE(in && rule && W && out, "gcn_sparse_gather_gemm: null pointer");
   hipStream_t st = (hipStream_t)stream;
+  GCN_REQUIRE(!w_transposed, "gcn_sparse_gather_gemm: pass the weight as (K, Cin, Cout) of THIS product (transpose on the caller's side)");
   const dim3 grid(cdiv(Mout, 256), Cout / 64);
-  if (w_transposed && k_reversed) sc_gather_gemm_kernel<true, true><<<grid, 256, 0, st>>>(Mout, K, Cin, Cout, in, rule, W, out);
-  else if (w_transposed) sc_gather_gemm_kernel<true, false><<<grid, 256, 0, st>>>(Mout, K, Cin, Cout, in, rule, W, out);
-  else if (k_reversed) sc_gather_gemm_kernel<false, true><<<grid, 256, 0, st>>>(Mout, K, Cin, Cout, in, rule, W, out);
-  else sc_gather_gemm_kernel<false, false><<<grid, 256, 0, st>>>(Mout, K, Cin, Cout, in, rule, W, out);
+  if (k_reversed) sc_gather_gemm_kernel<true><<<grid, 256, 0, st>>>(Mout, K, Cin, Cout, in, rule, W, out);
+  else sc_gather_gemm_kernel<false><<<grid, 256, 0, st>>>(Mout, K, Cin, Cout, in, rule, W, out);
   return check_launch("sc_gather_gemm_kernel");
 }
 

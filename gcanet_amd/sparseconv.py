@@ -106,7 +106,8 @@ class GatherGemmFunction(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             Min = rule_t.shape[0]
             din = torch.empty(Min, Cin, dtype=torch.float32, device=dout.device)
-            _call("gcn_sparse_gather_gemm", dout, Min, K, Cout, Cin, _lib.ptr(dout), _lib.ptr(rule_t), _lib.ptr(weight), 1,
+            wt = weight.transpose(1, 2).contiguous()              # (K, Cout, Cin): the weight of the transposed product
+            _call("gcn_sparse_gather_gemm", dout, Min, K, Cout, Cin, _lib.ptr(dout), _lib.ptr(rule_t), _lib.ptr(wt), 0,
                   int(ctx.k_rev_t), _lib.ptr(din))
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(weight)

@@ -190,9 +190,9 @@ int gcn_sparse_subm_rules(int M, const int32_t *coords, int batch, int D, int32_
 long gcn_sparse_coarse_ws_bytes(int batch, int D);
 int gcn_sparse_coarse_rules(int M, const int32_t *coords, int batch, int D, void *ws, int32_t *coords2, int32_t *child,
                             int32_t *parent, int32_t *m2_dev, void *stream);
-/* out (Mout,Cout) = sum_k in[rule[o,k], :] . W[k]  (rule < 0 contributes nothing); rule (Mout,K).  W (K,Cin,Cout), or
- * (K,Cout,Cin) used transposed when w_transposed; k_reversed pairs rule column K-1-k with W[k] (input gradient of a
- * submanifold convolution).  Cin, Cout multiples of 64.  f32 on v_mfma_f32_16x16x4_f32. */
+/* out (Mout,Cout) = sum_k in[rule[o,k], :] . W[k]  (rule < 0 contributes nothing); rule (Mout,K); W (K,Cin,Cout).
+ * k_reversed pairs rule column K-1-k with W[k] (input gradient of a submanifold convolution, with the per-offset
+ * transposed weight).  w_transposed must be 0 (reserved).  Cin, Cout multiples of 64.  f32 on v_mfma_f32_16x16x4_f32. */
 int gcn_sparse_gather_gemm(int Mout, int K, int Cin, int Cout, const float *in, const int32_t *rule, const float *W,
                            int w_transposed, int k_reversed, float *out, void *stream);
 /* dW (K,Cin,Cout) = sum_o in[rule[o,k], :]^T (x) dout[o, :]  (zeroed here first).  ruleT (K,Mout): the rule table
