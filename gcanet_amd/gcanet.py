@@ -1,0 +1,45 @@
+"""The reference's whole training forward (models/dgcnn-hais-concat-direct-4.py:634-777 `forward_train`) assembled from
+the pieces of this package: the hot path (gcanet_amd.dgcnn.PrimitivesEmbeddingDGCNGn, M4:634-736), forward_grouping on
+the device (M4:737-748), the proposal cap (M4:750-753), clusters_voxelization (M4:762-770) and the sparse instance head
+(M4:771-772).  Same outputs, in the reference's order."""
+import torch
+from torch import nn
+
+from .dgcnn import PrimitivesEmbeddingDGCNGn
+from .grouping import clusters_voxelization, forward_grouping_device
+from .sparseconv import InstanceHead, SparseConvTensor
+
+
+class GCANet(nn.Module):
+    def __init__(self, emb_size=64, num_primitives=10, mode=5, nn_nb=80, dtype="bf16", max_proposal_num=200,
+                 grouping_cfg=None):
+        super().__init__()
+        self.point_net = PrimitivesEmbeddingDGCNGn(emb_size=emb_size, num_primitives=num_primitives, mode=mode, nn_nb=nn_nb,
+                                                   dtype=dtype)
+        self.instance_head = InstanceHead(emb_size, num_primitives)
+        self.semantic_classes, self.max_proposal_num = num_primitives, max_proposal_num
+        self.grouping_cfg = dict(grouping_cfg or {})
+
+    def forward(self, points, normals, rand=None):
+        """points, normals (B,N,3).  Returns (type_per_point, param_per_point, semantic_scores, pt_offsets,
+        instance_batch_idxs, cls_scores, iou_scores, mask_scores, proposals_idx, proposals_offset, output_feats)."""
+        B, N, _ = points.shape
+        out = self.point_net(points, normals)
+        batch_idxs = torch.arange(B, device=points.device).repeat_interleave(N)
+        coords_float = points.reshape(-1, 3)
+        with torch.no_grad():
+            proposals_idx, proposals_offset = forward_grouping_device(
+                out["semantic_scores"].float(), out["pt_offsets"].float(), batch_idxs, coords_float, out["type_per_point"],
+                out["param_per_point"].float(), out["output_feats"].float(), semantic_classes=self.semantic_classes,
+                training_mode='train', **self.grouping_cfg)
+        if proposals_offset.shape[0] > self.max_proposal_num:                       # M4:750-753
+            proposals_offset = proposals_offset[:self.max_proposal_num + 1]
+            proposals_idx = proposals_idx[:int(proposals_offset[-1])]
+        feats = out["output_feats"].float().reshape(B * N, -1)
+        vf, vc, shape, nb, inst_map = clusters_voxelization(proposals_idx, proposals_offset, feats, coords_float, scale=64,
+                                                            spatial_shape=64, rand_quantize=True, rand=rand)
+        inst = SparseConvTensor(vf, vc, shape, nb)
+        instance_batch_idxs, cls_scores, iou_scores, mask_scores = self.instance_head(inst, inst_map.to(points.device))
+        return (out["type_per_point"], out["param_per_point"], out["semantic_scores"], out["pt_offsets"],
+                instance_batch_idxs, cls_scores, iou_scores, mask_scores, proposals_idx, proposals_offset,
+                out["output_feats"])

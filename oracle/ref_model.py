@@ -408,3 +408,57 @@ def tiny_unet(sd, feats, idx, D, batch, prefix="tiny_unet", reps=2):
         for i in range(reps):
             x = _res_block(sd, "%s.blocks_tail.block%d" % (prefix, i), x, idx, D, batch)
     return x
+
+
+# ------------------------------------------------------------------------------------------
+# Loss-side callers (utils/loss_utils.py), restated literally for the parity tests of gcanet_amd/losses.py.
+# ------------------------------------------------------------------------------------------
+def embedding_loss(pred_feat, gt_label, t_pull=0.5, t_push=1.5):
+    """loss_utils.py:203-257, one cloud and one label at a time."""
+    B = pred_feat.shape[0]
+    pull_total, push_total = pred_feat.new_zeros(1), pred_feat.new_zeros(1)
+    for b in range(B):
+        groups = [pred_feat[b][gt_label[b] == v] for v in range(-1, int(gt_label[b].max()) + 1)]
+        groups = [g for g in groups if g.shape[0] > 0]
+        means = [g.mean(0, keepdim=True) for g in groups]
+        pull_b = sum(F.relu(torch.norm(g - m, 2, dim=1) - t_pull).mean() for g, m in zip(groups, means))
+        pull_total = pull_total + pull_b / len(groups)
+        if len(means) > 1:
+            c = torch.cat(means, 0)
+            d = torch.norm(c[:, None, :] - c[None, :, :], 2, dim=2)
+            off = d[~torch.eye(c.shape[0], dtype=torch.bool)]
+            push_total = push_total + F.relu(t_push - off).mean()
+    pull_total, push_total = pull_total / B, push_total / B
+    return pull_total + push_total, pull_total, push_total
+
+
+def instance_loss(cls_scores, mask_scores, iou_scores, proposals_idx, proposals_offset, instance_labels,
+                  instance_pointnum, instance_cls, instance_batch_idxs, instance_classes=10):
+    """loss_utils.py:308-435 on the CPU oracle ops."""
+    from . import get_mask_iou, get_mask_label
+    bg, thr = instance_classes - 1, 0.5
+    pidx, poff = proposals_idx[:, 1].int().numpy(), proposals_offset.int().numpy()
+    il, ipn, ic = instance_labels.numpy(), instance_pointnum.numpy(), instance_cls.numpy()
+    iou_c = torch.from_numpy(get_mask_iou(pidx, poff, il, ipn))
+    fg = instance_cls != 0
+    fg_cls = instance_cls[fg]
+    n = iou_c.shape[0]
+    assigned = torch.full((n,), -1, dtype=torch.long)
+    mx, am = iou_c[:, fg].max(1)
+    assigned[mx >= thr] = am[mx >= thr]
+    labels = torch.full((n,), bg, dtype=torch.long)
+    labels[assigned >= 0] = fg_cls[assigned[assigned >= 0]]
+    cls_loss = F.cross_entropy(cls_scores, labels)
+    mcl = labels[instance_batch_idxs.long()]
+    sig = mask_scores.sigmoid()[torch.arange(mcl.shape[0]), mcl]
+    ml = torch.from_numpy(get_mask_label(pidx, poff, il, ic, ipn, iou_c.numpy(), thr))
+    w = (ml != -1).float()
+    ml = ml.clone()
+    ml[ml == -1.] = 0.5
+    mask_loss = F.binary_cross_entropy(sig, ml, weight=w, reduction='sum') / (w.sum() + 1)
+    ious = torch.from_numpy(get_mask_iou(pidx, poff, il, ipn, sig.detach().numpy()))
+    gt_ious, _ = ious[:, fg].max(1)
+    iw = (labels < bg).float()
+    sl = iou_scores[torch.arange(n), labels]
+    iou_loss = (F.mse_loss(sl, gt_ious, reduction='none') * iw).sum() / (iw.sum() + 1)
+    return cls_loss + mask_loss + iou_loss

@@ -106,3 +106,29 @@ def test_hot_path_model_matches_cpu_oracle(dev):
             assert ok.mean() > 0.97, ok.mean()
             continue
         np.testing.assert_allclose(a, b, rtol=1e-3, atol=1e-4 * max(1.0, np.abs(b).max()), err_msg=k_)
+
+
+def test_full_forward_train_runs_end_to_end(dev):
+    """M4:634-777 assembled (gcanet_amd/gcanet.py): hot path -> device grouping -> voxelisation -> sparse instance head,
+    forward and backward, on clouds made of tight blobs so that proposals exist."""
+    from gcanet_amd.gcanet import GCANet
+    torch.manual_seed(0)
+    B, N = 2, 1024
+    g = torch.Generator().manual_seed(1)
+    centers = torch.rand(B, 8, 3, generator=g)
+    which = torch.randint(0, 8, (B, N), generator=g)
+    pts = (centers[torch.arange(B)[:, None], which] + 0.01 * torch.randn(B, N, 3, generator=g)).to(dev)
+    nrm = torch.nn.functional.normalize(torch.randn(B, N, 3, generator=g), dim=-1).to(dev)
+    net = GCANet(nn_nb=16, dtype="f32", grouping_cfg=dict(similarity_threshold_inst=0.0, min_npoint=10)).to(dev)
+    outs = net(pts, nrm, rand=(torch.full((3,), 0.5), torch.full((3,), 0.5)))
+    (type_pp, param_pp, sem, off, ibi, cls, iou, mask, pidx, poff, feats) = outs
+    P = poff.shape[0] - 1
+    assert 1 <= P <= 200 and pidx.shape[0] == int(poff[-1]) and pidx.dtype == torch.int32
+    assert cls.shape == (P, 10) and iou.shape == (P, 10) and mask.shape == (pidx.shape[0], 10) and ibi.shape == (pidx.shape[0],)
+    assert int(pidx[:, 1].max()) < N and int(pidx[:, 0].max()) == P - 1
+    loss = cls.pow(2).mean() + iou.pow(2).mean() + mask.pow(2).mean() + sem.float().pow(2).mean() + off.pow(2).mean()
+    loss.backward()
+    grads = [p.grad for p in net.parameters() if p.grad is not None]
+    assert len(grads) > 100 and all(torch.isfinite(g_).all() for g_ in grads)
+    assert net.instance_head.tiny_unet.blocks.block0.conv_branch[2].weight.grad.abs().sum() > 0
+    assert net.point_net.mlp_seg_prob2.weight.grad.abs().sum() > 0          # the embedding feeds the sparse head
