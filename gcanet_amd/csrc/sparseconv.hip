@@ -74,86 +74,131 @@ __global__ void sc_coarse_rules_kernel(int M, const int32_t *__restrict__ coords
 // do have a neighbour (ballot) into tiles of 16 (row, source) pairs: the MFMA count follows the pairs, not the rows.
 // Layout: lane = output row (64 rows per wave), 64 accumulator VGPRs = the row's 64 output columns.  A tile's 16x64
 // product goes through a 4 KB per-wave LDS staging buffer, from which the (at most 16) lanes owning its rows pick their
-// row up -- so the only per-wave LDS is staging + pair list, 16 waves fit a CU and hide the gather latency.  The
-// 64x64 block of W[k] is staged in LDS once per offset for the four waves of the workgroup (two barriers per offset)
-// and read as the B operand with one ds_read per MFMA; row stride 68 floats keeps the four lane groups on disjoint banks.
+// row up.  The 64x64 block of W[k] is staged in LDS for the four waves of the workgroup and read as the B operand with
+// one ds_read per MFMA (row stride 68 floats keeps the four lane groups on disjoint banks).
+// At a few hundred voxels per proposal a launch has only ~130 workgroups, so its duration is the LATENCY of one
+// workgroup's 27 offsets: the loop is software pipelined -- while offset k is multiplied, the weight block of the next
+// phase is already in flight to registers (written to the other LDS buffer afterwards: one barrier per phase), the
+// next offset's pair list is built from a rule entry loaded two offsets ahead, and the source rows of its first tile
+// are being gathered.
 template <bool KREV>
 __global__ __launch_bounds__(256) void sc_gather_gemm_kernel(int Mout, int K, int Cin, int Cout, const float *__restrict__ in,
                                                              const int32_t *__restrict__ rule, const float *__restrict__ W,
                                                              float *__restrict__ out) {
   constexpr int LD = 64 + 4;
-  __shared__ float wt[64 * LD];
+  __shared__ float wt[2][64 * LD];
   __shared__ float stage[4][16 * LD];
-  __shared__ int psrc[4][64];
+  __shared__ int psrc[4][2][64];
   const int lane = lane_id(), wave = wave_id();
   const int li = lane & 15, lk = lane >> 4;
   const int r0 = (blockIdx.x * 4 + wave) * 64;                 // may lie past the end: the wave still helps staging W
   const int n0 = blockIdx.y * 64;
   float *stg = stage[wave];
-  int *ps = psrc[wave];
   const int myrow = r0 + lane;
   const unsigned long long lt = (1ull << lane) - 1ull;
+  const int nc = Cin / 64, P = K * nc;
   float acc[64];
 #pragma unroll
   for (int j = 0; j < 64; ++j) acc[j] = 0.f;
-  for (int k = 0; k < K; ++k) {
-    const int kc = KREV ? K - 1 - k : k;
-    const int src = myrow < Mout ? rule[(long)myrow * K + kc] : -1;
-    const unsigned long long mask = __ballot(src >= 0);
-    const int c = __popcll(mask);
-    const int pos = __popcll(mask & lt);                       // this row's place among the offset's pairs
-    if (src >= 0) ps[pos] = src;
-    for (int c0 = 0; c0 < Cin; c0 += 64) {
-      __syncthreads();                                         // previous weight tile fully consumed
-      for (int i = threadIdx.x; i < 64 * 16; i += 256) {       // W[k][c0 + row][n0 + 4*c4 ..]: 16 float4 per row
-        const int row = i >> 4, c4 = (i & 15) * 4;
-        const float4 v = *reinterpret_cast<const float4 *>(W + ((long)k * Cin + c0 + row) * Cout + n0 + c4);
-        float *d = wt + row * LD + c4;
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+
+  auto load_rule = [&](int kk) -> int {
+    return (myrow < Mout && kk < K) ? rule[(long)myrow * K + (KREV ? K - 1 - kk : kk)] : -1;
+  };
+  auto load_w = [&](int ph, float4 (&r)[4]) {
+    const int k = ph / nc, c0 = (ph % nc) * 64;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = threadIdx.x + 256 * u, row = i >> 4, c4 = (i & 15) * 4;
+      r[u] = *reinterpret_cast<const float4 *>(W + ((long)k * Cin + c0 + row) * Cout + n0 + c4);
+    }
+  };
+  auto store_w = [&](int buf, const float4 (&r)[4]) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = threadIdx.x + 256 * u, row = i >> 4, c4 = (i & 15) * 4;
+      float *d = wt[buf] + row * LD + c4;
+      d[0] = r[u].x; d[1] = r[u].y; d[2] = r[u].z; d[3] = r[u].w;
+    }
+  };
+  auto gather = [&](const int *list, int cnt, int j0, int c0, float4 (&a)[4]) {
+    const int pa = j0 + li;
+    const bool ok = pa < cnt;
+    const float *arow = in + (long)(ok ? list[pa] : 0) * Cin + c0 + 4 * lk;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      a[q] = *reinterpret_cast<const float4 *>(arow + 16 * q);
+      if (!ok) a[q] = float4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+
+  int src_c = load_rule(0), src_n = load_rule(1);
+  unsigned long long mask = __ballot(src_c >= 0);
+  int c_c = __popcll(mask), pos_c = __popcll(mask & lt);
+  if (src_c >= 0) psrc[wave][0][pos_c] = src_c;
+  float4 wr[4], a_next[4];
+  load_w(0, wr);
+  store_w(0, wr);
+  __builtin_amdgcn_wave_barrier();
+  gather(psrc[wave][0], c_c, 0, 0, a_next);
+  __syncthreads();
+
+  for (int ph = 0; ph < P; ++ph) {
+    const int k = ph / nc, c0 = (ph % nc) * 64, buf = ph & 1;
+    const bool last_chunk = (ph % nc) == nc - 1;
+    const int *list = psrc[wave][k & 1];
+    if (ph + 1 < P) load_w(ph + 1, wr);
+    int src_nn = -1, c_n = 0, pos_n = 0;
+    if (last_chunk) {                                           // the next phase starts offset k+1: build its pair list now
+      src_nn = load_rule(k + 2);
+      const unsigned long long mn = __ballot(src_n >= 0);
+      c_n = __popcll(mn);
+      pos_n = __popcll(mn & lt);
+      if (src_n >= 0) psrc[wave][(k + 1) & 1][pos_n] = src_n;
+      __builtin_amdgcn_wave_barrier();
+    }
+    float4 a[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a[q] = a_next[q];
+    if (ph + 1 < P) {
+      if (last_chunk) gather(psrc[wave][(k + 1) & 1], c_n, 0, 0, a_next);
+      else gather(list, c_c, 0, c0 + 64, a_next);
+    }
+    for (int j0 = 0; j0 < c_c; j0 += 16) {
+      if (j0 > 0) gather(list, c_c, j0, c0, a);
+      sc_f32x4 d[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) d[t] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        // B[kdim = lk][col = li] of step s = W[k][c0 + 16q + 4lk + s][n0 + 16t + li]
+        const float *wq = wt[buf] + (16 * q + 4 * lk) * LD + li;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].x, wq[0 * LD + 16 * t], d[t], 0, 0, 0);
+          d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].y, wq[1 * LD + 16 * t], d[t], 0, 0, 0);
+          d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].z, wq[2 * LD + 16 * t], d[t], 0, 0, 0);
+          d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].w, wq[3 * LD + 16 * t], d[t], 0, 0, 0);
+        }
       }
-      __syncthreads();
-      for (int j0 = 0; j0 < c; j0 += 16) {
-        const int pa = j0 + li;                                // the pair this lane gathers (A operand row li)
-        const bool oka = pa < c;
-        const float *arow = in + (long)(oka ? ps[pa] : 0) * Cin + c0 + 4 * lk;
-        float4 a[4];
+      // D[i = 4*lk + e][j = li] -> staging row i; the lane whose pair sits in slot i adds the row to its accumulators
+      __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          a[q] = *reinterpret_cast<const float4 *>(arow + 16 * q);
-          if (!oka) a[q] = float4{0.f, 0.f, 0.f, 0.f};
-        }
-        sc_f32x4 d[4];
+      for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) d[t] = {0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < 4; ++t) stg[(4 * lk + e) * LD + 16 * t + li] = d[t][e];
+      __builtin_amdgcn_wave_barrier();
+      if (src_c >= 0 && pos_c >= j0 && pos_c < j0 + 16) {
+        const float4 *sp = reinterpret_cast<const float4 *>(stg + (pos_c - j0) * LD);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          // B[kdim = lk][col = li] of step s = W[k][c0 + 16q + 4lk + s][n0 + 16t + li]
-          const float *wq = wt + (16 * q + 4 * lk) * LD + li;
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].x, wq[0 * LD + 16 * t], d[t], 0, 0, 0);
-            d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].y, wq[1 * LD + 16 * t], d[t], 0, 0, 0);
-            d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].z, wq[2 * LD + 16 * t], d[t], 0, 0, 0);
-            d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].w, wq[3 * LD + 16 * t], d[t], 0, 0, 0);
-          }
-        }
-        // D[i = 4*lk + e][j = li] -> staging row i; the lane whose pair sits in slot i adds the row to its accumulators
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int t = 0; t < 4; ++t) stg[(4 * lk + e) * LD + 16 * t + li] = d[t][e];
-        __builtin_amdgcn_wave_barrier();
-        if (src >= 0 && pos >= j0 && pos < j0 + 16) {
-          const float4 *sp = reinterpret_cast<const float4 *>(stg + (pos - j0) * LD);
-#pragma unroll
-          for (int j = 0; j < 16; ++j) {
-            const float4 v = sp[j];
-            acc[4 * j] += v.x; acc[4 * j + 1] += v.y; acc[4 * j + 2] += v.z; acc[4 * j + 3] += v.w;
-          }
+        for (int j = 0; j < 16; ++j) {
+          const float4 v = sp[j];
+          acc[4 * j] += v.x; acc[4 * j + 1] += v.y; acc[4 * j + 2] += v.z; acc[4 * j + 3] += v.w;
         }
       }
     }
+    if (ph + 1 < P) store_w(buf ^ 1, wr);                        // last read in phase ph-1, before the previous barrier
+    __syncthreads();
+    if (last_chunk) { src_c = src_n; c_c = c_n; pos_c = pos_n; src_n = src_nn; }
   }
   if (myrow < Mout) {
     float4 *op = reinterpret_cast<float4 *>(out + (long)myrow * Cout + n0);
@@ -195,16 +240,24 @@ __global__ __launch_bounds__(256) void sc_wgrad_kernel(int Mout, int K, int Cin,
       c += __popcll(mask);
     }
     __builtin_amdgcn_wave_barrier();
-    for (int p0 = 0; p0 < c; p0 += 4) {
+    // operands of step p0+4 are fetched before the MFMAs of step p0 issue (the loop is latency-bound otherwise)
+    float an[4], bn[4];
+    auto fetch = [&](int p0) {
       const int p = p0 + lk;
       const bool ok = p < c;
       const float *xi = in + (long)(ok ? qs[p] : 0) * Cin + c0 + li;
       const float *dy = dout + (long)(ok ? qo[p] : 0) * Cout + n0 + li;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) { const float v = xi[16 * a]; an[a] = ok ? v : 0.f; }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { const float v = dy[16 * t]; bn[t] = ok ? v : 0.f; }
+    };
+    if (c > 0) fetch(0);
+    for (int p0 = 0; p0 < c; p0 += 4) {
       float av[4], bv[4];
 #pragma unroll
-      for (int a = 0; a < 4; ++a) { const float v = xi[16 * a]; av[a] = ok ? v : 0.f; }
-#pragma unroll
-      for (int t = 0; t < 4; ++t) { const float v = dy[16 * t]; bv[t] = ok ? v : 0.f; }
+      for (int a = 0; a < 4; ++a) { av[a] = an[a]; bv[a] = bn[a]; }
+      if (p0 + 4 < c) fetch(p0 + 4);
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -304,7 +357,8 @@ GCN_EXPORT int gcn_sparse_wgrad(int Mout, int K, int Cin, int Cout, const float 
   GCN_HIP(hipMemsetAsync(dW, 0, sizeof(float) * (size_t)K * Cin * Cout, st));
   if (Mout == 0) return GCN_OK;
   GCN_REQUIRE(in && ruleT && dout, "gcn_sparse_wgrad: null pointer");
-  const int rows = 4096;
+  int rows = 1024;                                   // >= ~1000 workgroups; at most 4096 rows each
+  while (rows < 4096 && (long)cdiv(Mout, rows) * K * (Cin / 64) * (Cout / 64) > 2048) rows *= 2;
   sc_wgrad_kernel<<<dim3(cdiv(Mout, rows), K, (Cin / 64) * (Cout / 64)), 256, 0, st>>>(Mout, K, Cin, Cout, rows, in, ruleT, dout, dW);
   return check_launch("sc_wgrad_kernel");
 }
