@@ -64,11 +64,13 @@ def pmc_traffic(tag):
     if not os.path.exists(path) or "B=8" not in tag or "N=8192" not in tag:
         return None
     ks = json.load(open(path))["kernels"]
-    name = {"knn_model[B=8,C=64": "gcn::knn_mfma16_kernel<64, 64>", "knn_model[B=8,C=6,": "gcn::knn_select_kernel<1, 8, 2, 6>",
+    name = {"knn_model[B=8,C=64": "gcn::knn_mfma16_kernel<64, 64", "knn_model[B=8,C=6,": "gcn::knn_select_kernel<1, 8, 2, 6>",
             "edgeconv_fwd[B=8,N=8192,k=64,C=64,Cout=128": "gcn::edgeconv_fwd_bf16_kernel<8, 4, 1, true, true, 64>"}
     for pre, kn in name.items():
-        if tag.startswith(pre) and kn in ks:
-            return ks[kn]["hbm_bytes_corrected"]
+        if tag.startswith(pre):
+            for full, rec in ks.items():          # template arguments appended later (e.g. the list-registers count) still match
+                if full.startswith(kn):
+                    return rec["hbm_bytes_corrected"]
     return None
 
 
