@@ -58,6 +58,15 @@ __device__ __forceinline__ float wave_shr1_f(float lane0_val, float v) {
   return __builtin_bit_cast(float, wave_shr1_i(__builtin_bit_cast(int, lane0_val), __builtin_bit_cast(int, v)));
 }
 
+// (tile, cloud) of this workgroup in a (tiles, clouds) grid.  Workgroups are dealt to the 8 XCDs round robin by linear
+// id, each XCD with its own 4 MB L2: cloud = id % clouds makes the workgroups of one XCD share clouds (one cloud per
+// XCD at 8 clouds), so the rows a cloud's neighbour lists keep re-reading stay in ONE L2 instead of thrashing all eight.
+__device__ __forceinline__ void xcd_tile_cloud(int &tile, int &cloud) {
+  const int lin = blockIdx.x + gridDim.x * blockIdx.y;
+  cloud = lin % (int)gridDim.y;
+  tile = lin / (int)gridDim.y;
+}
+
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---- device-wide exclusive scan of int32 rows (three small launches; every access coalesced) ----

@@ -149,9 +149,13 @@ __global__ __launch_bounds__(64 * RWT * CW, 2) void edgeconv_fwd_bf16_kernel(EcA
     }
   }
 
+  // Workgroup g runs on XCD g % 8.  Give the workgroups of one XCD CONSECUTIVE tile ranges, i.e. (with 8 clouds) one
+  // cloud per XCD: its point rows (1-2 MB) then stay in that XCD's 4 MB L2 across the k-fold gathers instead of every
+  // L2 seeing every cloud.
   const int G = gridDim.x;
-  const int t_begin = (int)((long)blockIdx.x * a.total_tiles / G);
-  const int t_end = (int)((long)(blockIdx.x + 1) * a.total_tiles / G);
+  const int vb = (G % 8 == 0) ? (int)(blockIdx.x % 8) * (G / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+  const int t_begin = (int)((long)vb * a.total_tiles / G);
+  const int t_end = (int)((long)(vb + 1) * a.total_tiles / G);
   if (t_begin >= t_end) return;
 
   const int kp = KP ? KP : a.kp, k = a.k, TP = a.TP;      // a constant kp turns the row -> (point, slot) divisions into shifts
@@ -536,7 +540,9 @@ __global__ __launch_bounds__(256) void edgeconv_finish_kernel(const float *__res
 __global__ __launch_bounds__(256) void neighbor_sum_kernel(const float *__restrict__ x, const int64_t *__restrict__ idx,
                                                            int N, int C, int k, float *__restrict__ s) {
   const int lane = lane_id();
-  const int n = blockIdx.x * 4 + wave_id(), b = blockIdx.y;
+  int tile, b;
+  xcd_tile_cloud(tile, b);
+  const int n = tile * 4 + wave_id();
   if (n >= N) return;
   const float *xb = x + (long)b * N * C;
   const int64_t *ip = idx + ((long)b * N + n) * k;

@@ -25,8 +25,9 @@ __global__ __launch_bounds__(256) void route_bwd_kernel(const float *__restrict_
   for (int i = threadIdx.x; i < 2 * G; i += 256) sm[i] = 0.0;
   for (int i = threadIdx.x; i < 2 * Cout; i += 256) cs[i] = 0.f;
   __syncthreads();
-  const int b = blockIdx.y;
-  const int r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, N);
+  int tile, b;
+  xcd_tile_cloud(tile, b);
+  const int r0 = tile * rows_per_block, r1 = min(r0 + rows_per_block, N);
   const int cpg = Cout / G;
   // thread -> fixed channel (Cout <= 256 and divides 256, or a multiple of 256)
   const int nct = Cout <= 256 ? Cout : 256;
@@ -126,8 +127,9 @@ __global__ __launch_bounds__(256) void edge_wgrad_kernel(const float *__restrict
   constexpr bool HAS_G = true;
   const int lane = lane_id(), wave = wave_id();
   const int li = lane & 15, lk = lane >> 4;
-  const int b = blockIdx.y;
-  const int r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, N);
+  int tile, b;
+  xcd_tile_cloud(tile, b);
+  const int r0 = tile * rows_per_block, r1 = min(r0 + rows_per_block, N);
   const float *xb = x + (long)b * N * C, *sb = sx + (long)b * N * C;
   const float *pb = dsp + (long)b * N * Cout, *qb = d2 + (long)b * N * Cout;
   const float *ib = indeg + (long)b * N;

@@ -400,8 +400,11 @@ __global__ __launch_bounds__(256, KPL == 1 ? 4 : 3) void knn_mfma16_kernel(const
 
   const int lane = lane_id(), wave = wave_id();
   const int lc = lane & 15, lg = lane >> 4;
-  const int b = blockIdx.y;
-  const int q0 = (blockIdx.x * 4 + wave) * 16;
+  // Workgroups go to the 8 XCDs round robin by their linear id; cloud = id % B keeps a cloud's candidate rows (2 MB at
+  // C = 64) in ONE XCD's L2 when B is a multiple of 8 instead of streaming every cloud through all eight.
+  const int lin = blockIdx.x + gridDim.x * blockIdx.y;
+  const int b = lin % (int)gridDim.y;
+  const int q0 = ((lin / (int)gridDim.y) * 4 + wave) * 16;
   const float *xb = x + (long)b * CC * N;
   const float *xxb = xxg + (long)b * N;
 

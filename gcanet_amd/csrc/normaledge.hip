@@ -19,8 +19,9 @@ __global__ __launch_bounds__(256) void normal_edge_fwd_kernel(const float *__res
                                                               unsigned char *__restrict__ amin, double *__restrict__ gsum) {
   __shared__ double red[128];                 // (group, stat) partial sums of this workgroup, G <= 64
   const int lane = lane_id(), wave = wave_id();
-  const int b = blockIdx.y;
-  const int n_lo = blockIdx.x * pts_per_block, n_hi = min(n_lo + pts_per_block, N);
+  int tile, b;
+  xcd_tile_cloud(tile, b);
+  const int n_lo = tile * pts_per_block, n_hi = min(n_lo + pts_per_block, N);
   const int cpg = Cout / G;
   const float *pb = pts + (long)b * N * 6;
   if (threadIdx.x < 2 * G) red[threadIdx.x] = 0.0;
@@ -98,8 +99,9 @@ __global__ __launch_bounds__(256) void normal_edge_bwd_kernel(const float *__res
                                                               float *__restrict__ dWsp, float *__restrict__ esum,
                                                               float *__restrict__ gram) {
   const int lane = lane_id(), wave = wave_id();
-  const int b = blockIdx.y;
-  const int n_lo = blockIdx.x * pts_per_block, n_hi = min(n_lo + pts_per_block, N);
+  int tile, b;
+  xcd_tile_cloud(tile, b);
+  const int n_lo = tile * pts_per_block, n_hi = min(n_lo + pts_per_block, N);
   const float *pb = pts + (long)b * N * 6;
   float es[NE_F], gr[28];
 #pragma unroll

@@ -598,8 +598,12 @@ class KPAM(nn.Module):
                                    nn.Conv1d(C, C, kernel_size=1, bias=False))
 
     def weights(self, attention_feature):
-        a = self.conv1(attention_feature.permute(0, 2, 1)).permute(0, 2, 1)
-        return torch.softmax(a, dim=2)                                         # (B,N,k)
+        # the two Conv1d(k -> k, 1x1) act along the last axis of the point-major (B,N,k) tensor: plain GEMMs with the same
+        # parameters (no permutes, and no MIOpen convolution whose solver search lands on a naive kernel on a fresh box)
+        from .layers import linear_pm
+        a = linear_pm(torch.relu(linear_pm(attention_feature, self.conv1[0].weight.flatten(1))),
+                      self.conv1[2].weight.flatten(1))
+        return torch.softmax(a.float(), dim=2)                                 # (B,N,k)
 
     def forward(self, x, attention_feature):
         return self.weights(attention_feature).unsqueeze(-1) * x
