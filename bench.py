@@ -150,7 +150,7 @@ def main():
     model = dgcnn.PrimitivesEmbeddingDGCNGn(nn_nb=args.k, dtype="bf16").to(dev)
     dp = parallel.FlatGradDP(model, world)
     dp.sync_params()
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3)   # option_new.py:83-90
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)   # option_new.py:83-90 (one multi-tensor kernel)
     B, N = args.batch, args.points
     pts, nrm = synth_clouds(range(rank * B, rank * B + B), N, dev)
 

@@ -173,3 +173,21 @@ def test_segment_diameter_matches_cdist(dev):
         a, b = int(offs[s]), int(offs[s + 1])
         ref = 0.0 if (cls[s] < 0 or b - a < 2) else float(torch.cdist(fc[a:b], fc[a:b]).max() ** 2)
         np.testing.assert_allclose(got[s], ref, rtol=2e-5, atol=1e-6)
+
+
+def test_forward_grouping_device_edge_cases(dev):
+    """No subset reaches min_npoint -> empty result (M4:1150 `continue` for every subset); a list buffer that is too
+    small -> the retry with the reported capacity gives the same result as a large one."""
+    from gcanet_amd.grouping import forward_grouping_device
+    B, N, P = 2, 600, 3
+    xyz, sem, off, bidx, par, feat = _blob_scene(0, B, N, P, 6)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    args = (t(sem), t(off), t(bidx), t(xyz.reshape(-1, 3)), torch.zeros(B, N, P), t(par), t(feat))
+    kw = dict(semantic_classes=P, radius=0.03, similarity_threshold_inst=0.9, similarity_threshold_para=0.0)
+    pi, po = forward_grouping_device(*args, min_npoint=100000, mean_active=50, **kw)
+    assert pi.shape == (0, 2) and po.numel() == 0 and pi.dtype == torch.int32
+    small = forward_grouping_device(*args, min_npoint=20, mean_active=1, **kw)        # forces the capacity retry
+    large = forward_grouping_device(*args, min_npoint=20, mean_active=400, **kw)
+    assert torch.equal(small[0], large[0]) and torch.equal(small[1], large[1]) and large[1].numel() > 4
+    d = forward_grouping_device(*args, min_npoint=20, mean_active=400, to_cpu=False, **kw)
+    assert d[0].is_cuda and torch.equal(d[0].cpu(), large[0])

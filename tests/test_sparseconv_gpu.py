@@ -135,3 +135,14 @@ def test_instance_head_matches_dense_unet(dev):
             scale = float(sd[name].grad.abs().max()) + 1e-12
             err = float((p.grad.cpu() - sd[name].grad).abs().max()) / scale
             assert err < 2e-3, "%s gradient: %.3g" % (name, err)      # through 14 BatchNorms: batch statistics amplify rounding
+
+
+def test_empty_and_tiny_sparse_tensors(dev):
+    """M = 0 rows and a single isolated voxel (the degenerate tensors clusters_voxelization can hand over)."""
+    from gcanet_amd import sparseconv as S
+    conv = S.SubMConv3d(64, 64, "k").to(dev)
+    x = S.SparseConvTensor(torch.zeros(0, 64, device=dev), torch.zeros(0, 4, dtype=torch.int32, device=dev), [8] * 3, 1)
+    assert conv(x).features.shape == (0, 64)
+    f = torch.randn(1, 64, device=dev)
+    y = conv(S.SparseConvTensor(f, torch.tensor([[0, 3, 4, 5]], dtype=torch.int32, device=dev), [8] * 3, 1)).features
+    _close(y.detach().cpu(), (f @ conv.weight[13]).detach().cpu(), "isolated voxel = centre tap only")
