@@ -154,8 +154,12 @@ def main():
     B, N = args.batch, args.points
     pts, nrm = synth_clouds(range(rank * B, rank * B + B), N, dev)
 
+    from gcanet_amd.layers import CastCache
+    casts = CastCache(model)             # bf16 weight copies: one multi-tensor cast per step instead of one per layer
+
     def step():
         dp.zero_grad()
+        casts.refresh()
         with torch.autocast("cuda", dtype=torch.bfloat16):
             out = model(pts, nrm)
         loss = loss_of(out)

@@ -59,15 +59,51 @@ def group_norm_relu(x, gn, relu=True):
     return GroupNormReLUFunction.apply(x, gn.weight, gn.bias, gn.num_groups, gn.eps, relu)
 
 
-def tall_skinny_tn(a, b, chunks=32):
+def tall_skinny_tn(a, b, chunks=32, out_dtype=None):
     """a^T @ b for a (M,P), b (M,Q) with M >> P,Q (weight-gradient shape).  The library picks a tile
     config with a few dozen workgroups for the direct call (each looping over all M rows: 150-350 us at
-    M=65536 on MI355X); splitting the long reduction into `chunks` batched GEMMs + a sum fills the chip."""
+    M=65536 on MI355X); splitting the long reduction into `chunks` batched GEMMs + a sum fills the chip.
+    out_dtype: the partial sums are added up directly into that type (no separate cast kernel)."""
     M = a.shape[0]
     if M % chunks != 0 or M // chunks < 64:
-        return a.t() @ b
+        r = a.t() @ b
+        return r if out_dtype is None else r.to(out_dtype)
     part = torch.bmm(a.view(chunks, M // chunks, -1).transpose(1, 2), b.view(chunks, M // chunks, -1))
-    return part.sum(0)
+    return part.sum(0, dtype=out_dtype)
+
+
+class CastCache:
+    """bf16 (autocast-dtype) copies of a model's floating-point parameters, refreshed by ONE multi-tensor copy per
+    step instead of one cast kernel per layer and call (a training step had ~40 of them, 5 us each).  LinearPMFunction
+    looks a weight up by identity and version; anything not registered (weight slices, ...) is cast as before."""
+    _live = None
+
+    def __init__(self, module, dtype=torch.bfloat16):
+        self.params = [p for p in module.parameters() if p.dtype == torch.float32 and p.dim() >= 1]
+        self.copies = [torch.empty_like(p, dtype=dtype) for p in self.params]
+        self.dtype = dtype
+        self.version = {}
+        self.by_id = {id(p): i for i, p in enumerate(self.params)}
+
+    def refresh(self):
+        """Call once per step after the optimizer update (or before the first forward)."""
+        with torch.no_grad():
+            torch._foreach_copy_(self.copies, self.params)
+        self.version = {id(p): p._version for p in self.params}
+        CastCache._live = self
+
+    @staticmethod
+    def lookup(t, dtype):
+        """A current low-precision copy of parameter (or flatten(1) view of a parameter) `t`, or None."""
+        c = CastCache._live
+        if c is None or c.dtype != dtype:
+            return None
+        base = t._base if t._base is not None else t
+        i = c.by_id.get(id(base))
+        if (i is None or c.version.get(id(base)) != base._version or base.numel() != t.numel() or not t.is_contiguous()
+                or t.storage_offset() != base.storage_offset()):      # only whole-tensor reshapes of the parameter
+            return None
+        return c.copies[i].view(t.shape)
 
 
 class LinearPMFunction(torch.autograd.Function):
@@ -77,12 +113,18 @@ class LinearPMFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
         dt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else x.dtype
-        xc, wc = x.to(dt), weight.to(dt)
+        xc = x.to(dt)
+        wc = (CastCache.lookup(weight, dt) if weight.dtype != dt else None)
+        wc = weight.to(dt) if wc is None else wc
+        bc = None
+        if bias is not None:
+            bc = CastCache.lookup(bias, dt) if bias.dtype != dt else None
+            bc = bias.to(dt) if bc is None else bc
         ctx.save_for_backward(xc, wc)
         ctx.has_bias = bias is not None
         ctx.in_dtypes = (x.dtype, weight.dtype)
         with torch.autocast("cuda", enabled=False):
-            return torch.nn.functional.linear(xc, wc, None if bias is None else bias.to(dt))
+            return torch.nn.functional.linear(xc, wc, bc)
 
     @staticmethod
     def backward(ctx, dy):
@@ -91,7 +133,7 @@ class LinearPMFunction(torch.autograd.Function):
         with torch.autocast("cuda", enabled=False):
             dx = (dy @ wc).to(ctx.in_dtypes[0])
             rows = dy.reshape(-1, dy.shape[-1])
-            dw = tall_skinny_tn(rows, xc.reshape(-1, xc.shape[-1])).to(ctx.in_dtypes[1])
+            dw = tall_skinny_tn(rows, xc.reshape(-1, xc.shape[-1]), out_dtype=ctx.in_dtypes[1])
             db = rows.sum(0, dtype=torch.float32) if ctx.has_bias else None   # f32 accumulation, no f32 copy of dy
         return dx, dw, db
 
