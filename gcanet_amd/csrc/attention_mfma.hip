@@ -128,8 +128,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma_kernel(const unsigned sh
 
   const int lane = lane_id(), wave = wave_id();
   const int lr = lane & 31, lh = lane >> 5;
-  const int bh = blockIdx.y;
-  const int qrow = blockIdx.x * 128 + wave * 32 + lr;     // < Lqp by construction
+  int tile_, bh;
+  xcd_major_tile_cloud(tile_, bh);
+  const int qrow = tile_ * 128 + wave * 32 + lr;     // < Lqp by construction
   const unsigned short *kimg = kb + (long)bh * Lkp * D;
   const unsigned short *vimg = vt + (long)bh * D * Lkp;
 
@@ -296,8 +297,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const unsigned shor
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];  // 2 x (K | V | K^T)
   const int lane = lane_id(), wave = wave_id();
   const int lr = lane & 31, lh = lane >> 5;
-  const int bh = blockIdx.y;
-  const int qrow = blockIdx.x * 128 + wave * 32 + lr;
+  int tile_, bh;
+  xcd_major_tile_cloud(tile_, bh);
+  const int qrow = tile_ * 128 + wave * 32 + lr;
   const unsigned short *kimg = kr + (long)bh * Lkp * D, *vimg = vr + (long)bh * Lkp * D;
   const unsigned short *ktimg = ktr + (long)bh * D * Lkp;
 
@@ -392,8 +394,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const unsigned sho
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];  // 2 x (Qs | dO | Qs^T | dO^T | lse2,delta)
   const int lane = lane_id(), wave = wave_id();
   const int lr = lane & 31, lh = lane >> 5;
-  const int bh = blockIdx.y;
-  const int krow = blockIdx.x * 128 + wave * 32 + lr;      // < Lkp
+  int tile_, bh;
+  xcd_major_tile_cloud(tile_, bh);
+  const int krow = tile_ * 128 + wave * 32 + lr;      // < Lkp
   const unsigned short *qimg = qs + (long)bh * Lqp * D, *doimg = dor + (long)bh * Lqp * D;
   const unsigned short *qtimg = qst + (long)bh * D * Lqp, *dotimg = dot + (long)bh * D * Lqp;
   const float *l2 = lse2 + (long)bh * Lqp, *dl = delta + (long)bh * Lqp;

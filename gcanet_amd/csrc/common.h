@@ -67,6 +67,18 @@ __device__ __forceinline__ void xcd_tile_cloud(int &tile, int &cloud) {
   tile = lin / (int)gridDim.y;
 }
 
+// Same idea when there are many more "clouds" (attention: batch x heads) than XCDs: XCD x = linear id % 8 works through
+// clouds x, x+8, ... one after the other, all tiles of a cloud consecutively, so that one cloud's streamed operand
+// (K/V: 1-2 MB) is what that XCD's L2 holds at a time.  Falls back to the plain (x, y) grid when clouds % 8 != 0.
+__device__ __forceinline__ void xcd_major_tile_cloud(int &tile, int &cloud) {
+  const int T = gridDim.x, Cn = gridDim.y;
+  if (Cn % 8 != 0) { tile = blockIdx.x; cloud = blockIdx.y; return; }
+  const int lin = blockIdx.x + T * blockIdx.y;
+  const int xcd = lin & 7, slot = lin >> 3;                 // slot: this XCD's running workgroup number
+  cloud = (slot / T) * 8 + xcd;
+  tile = slot % T;
+}
+
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---- device-wide exclusive scan of int32 rows (three small launches; every access coalesced) ----
