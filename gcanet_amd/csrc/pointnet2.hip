@@ -110,8 +110,9 @@ template <int CT, int BS>
 __global__ __launch_bounds__(BS) void group_points_lds_kernel(int c, int n, long E, const float *__restrict__ points,
                                                               const int32_t *__restrict__ idx, float *__restrict__ out) {
   extern __shared__ float rows[];  // CT * n
-  const int b = blockIdx.y;
-  const int c0 = blockIdx.x * CT;
+  int tile_, b;                                     // one batch element's id list (E ints) per XCD L2: common.h
+  xcd_tile_cloud(tile_, b);
+  const int c0 = tile_ * CT;
   for (int i = threadIdx.x; i < CT * n; i += BS) {
     const int ch = c0 + i / n;
     rows[i] = ch < c ? points[((long)b * c + ch) * n + (i % n)] : 0.f;
@@ -153,8 +154,9 @@ __global__ __launch_bounds__(1024) void scatter_rows_lds_kernel(int c, int n, lo
                                                                 float *__restrict__ grad_points) {
   extern __shared__ unsigned long long qrow[];  // CT * n
   __shared__ unsigned int rowmax[CT];
-  const int b = blockIdx.y;
-  const int c0 = blockIdx.x * CT;
+  int tile_, b;                                     // one batch element's id list (E ints) per XCD L2: common.h
+  xcd_tile_cloud(tile_, b);
+  const int c0 = tile_ * CT;
   for (int i = threadIdx.x; i < CT * n; i += blockDim.x) qrow[i] = 0ull;
   if (threadIdx.x < CT) rowmax[threadIdx.x] = 0u;
   __syncthreads();
