@@ -96,16 +96,22 @@ __global__ __launch_bounds__(256) void sc_gather_gemm_kernel(int Mout, int K, in
   float *stg = stage[wave];
   const int myrow = r0 + lane;
   const unsigned long long lt = (1ull << lane) - 1ull;
-  const int nc = Cin / 64, P = K * nc;
+  // blockIdx.z selects a contiguous group of offsets (small launches are split so that enough workgroups exist and the
+  // latency of a workgroup's offset loop shrinks); group z writes its partial sums to out + z * Mout * Cout
+  const int ksplit = gridDim.z;
+  const int k_begin = (int)((long)blockIdx.z * K / ksplit), k_end = (int)((long)(blockIdx.z + 1) * K / ksplit);
+  const int nc = Cin / 64, P = (k_end - k_begin) * nc;
+  out += (long)blockIdx.z * Mout * Cout;
   float acc[64];
 #pragma unroll
   for (int j = 0; j < 64; ++j) acc[j] = 0.f;
 
   auto load_rule = [&](int kk) -> int {
-    return (myrow < Mout && kk < K) ? rule[(long)myrow * K + (KREV ? K - 1 - kk : kk)] : -1;
+    const int ka = k_begin + kk;
+    return (myrow < Mout && ka < k_end) ? rule[(long)myrow * K + (KREV ? K - 1 - ka : ka)] : -1;
   };
   auto load_w = [&](int ph, float4 (&r)[4]) {
-    const int k = ph / nc, c0 = (ph % nc) * 64;
+    const int k = k_begin + ph / nc, c0 = (ph % nc) * 64;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int i = threadIdx.x + 256 * u, row = i >> 4, c4 = (i & 15) * 4;
@@ -205,6 +211,18 @@ __global__ __launch_bounds__(256) void sc_gather_gemm_kernel(int Mout, int K, in
 #pragma unroll
     for (int j = 0; j < 16; ++j) op[j] = float4{acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]};
   }
+}
+
+// out[i] = sum_z part[z][i] (fixed order: deterministic), float4 per thread
+__global__ void sc_sum_parts_kernel(long n4, int parts, const float4 *__restrict__ part, float4 *__restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  float4 a = part[i];
+  for (int z = 1; z < parts; ++z) {
+    const float4 b = part[(long)z * n4 + i];
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+  }
+  out[i] = a;
 }
 
 // ---------------------------------------------------------------- dW[k] = sum_o gather(in, rule[o,k])^T (x) dOut[o]
@@ -334,17 +352,39 @@ GCN_EXPORT int gcn_sparse_coarse_rules(int M, const int32_t *coords, int batch, 
   return check_launch("sc_coarse_rules_kernel");
 }
 
+// offsets are split over `parts` workgroup groups when the launch would otherwise have fewer than ~512 workgroups
+static int sc_parts(int Mout, int K, int Cout) {
+  const long wgs = (long)cdiv(Mout, 256) * (Cout / 64);
+  int parts = 1;
+  while (parts * 3 <= K && K % (parts * 3) == 0 && wgs * parts < 512) parts *= 3;      // 27 -> 1, 3, 9
+  while (parts * 2 <= K && K % (parts * 2) == 0 && wgs * parts < 512) parts *= 2;      // 8 -> 1, 2, 4
+  return parts;
+}
+
+GCN_EXPORT long gcn_sparse_gather_gemm_ws_floats(int Mout, int K, int Cout) {
+  if (Mout < 0 || K < 1 || Cout < 64) return -1;
+  const int parts = sc_parts(Mout, K, Cout);
+  return parts > 1 ? (long)parts * Mout * Cout : 0;
+}
+
 GCN_EXPORT int gcn_sparse_gather_gemm(int Mout, int K, int Cin, int Cout, const float *in, const int32_t *rule, const float *W,
-                                      int w_transposed, int k_reversed, float *out, void *stream) {
+                                      int w_transposed, int k_reversed, float *out, float *ws, void *stream) {
   GCN_REQUIRE(Mout >= 0 && K >= 1 && Cin > 0 && Cout > 0 && Cin % 64 == 0 && Cout % 64 == 0,
               "gcn_sparse_gather_gemm: channels must be multiples of 64 (Cin=%d, Cout=%d)", Cin, Cout);
   if (Mout == 0) return GCN_OK;
   GCN_REQUIRE(in && rule && W && out, "gcn_sparse_gather_gemm: null pointer");
-  hipStream_t st = (hipStream_t)stream;
   GCN_REQUIRE(!w_transposed, "gcn_sparse_gather_gemm: pass the weight as (K, Cin, Cout) of THIS product (transpose on the caller's side)");
-  const dim3 grid(cdiv(Mout, 256), Cout / 64);
-  if (k_reversed) sc_gather_gemm_kernel<true><<<grid, 256, 0, st>>>(Mout, K, Cin, Cout, in, rule, W, out);
-  else sc_gather_gemm_kernel<false><<<grid, 256, 0, st>>>(Mout, K, Cin, Cout, in, rule, W, out);
+  hipStream_t st = (hipStream_t)stream;
+  const int parts = sc_parts(Mout, K, Cout);
+  GCN_REQUIRE(parts == 1 || ws, "gcn_sparse_gather_gemm: this shape needs gcn_sparse_gather_gemm_ws_floats() floats of scratch");
+  float *dst = parts > 1 ? ws : out;
+  const dim3 grid(cdiv(Mout, 256), Cout / 64, parts);
+  if (k_reversed) sc_gather_gemm_kernel<true><<<grid, 256, 0, st>>>(Mout, K, Cin, Cout, in, rule, W, dst);
+  else sc_gather_gemm_kernel<false><<<grid, 256, 0, st>>>(Mout, K, Cin, Cout, in, rule, W, dst);
+  if (parts > 1) {
+    const long n4 = (long)Mout * Cout / 4;
+    sc_sum_parts_kernel<<<cdiv(n4, 256), 256, 0, st>>>(n4, parts, reinterpret_cast<const float4 *>(ws), reinterpret_cast<float4 *>(out));
+  }
   return check_launch("sc_gather_gemm_kernel");
 }
 

@@ -80,6 +80,12 @@ def coarse_rules(x: SparseConvTensor):
     return coords2[:M2].contiguous(), child[:M2].contiguous(), parent
 
 
+def _scratch(Mout, K, Cout, device):
+    """Partial-sum scratch of a gather-GEMM launch whose offsets are split over workgroup groups (small Mout)."""
+    n = _lib.lib().gcn_sparse_gather_gemm_ws_floats(Mout, K, Cout)
+    return torch.empty(n, dtype=torch.float32, device=device) if n > 0 else None
+
+
 class GatherGemmFunction(torch.autograd.Function):
     """out = sum_k in[rule[:,k]] @ W[k].  `rule_t` / `k_rev_t` describe the transposed gather (the input gradient);
     `rule_cols` = rule.t().contiguous() (K, Mout), the layout the weight-gradient kernel reads."""
@@ -92,7 +98,7 @@ class GatherGemmFunction(torch.autograd.Function):
         Mout = rule.shape[0]
         out = torch.empty(Mout, Cout, dtype=torch.float32, device=feats.device)
         _call("gcn_sparse_gather_gemm", feats, Mout, K, Cin, Cout, _lib.ptr(feats), _lib.ptr(rule), _lib.ptr(weight), 0, 0,
-              _lib.ptr(out))
+              _lib.ptr(out), _lib.ptr(_scratch(Mout, K, Cout, feats.device)))
         ctx.save_for_backward(feats, weight, rule_cols, rule_t)
         ctx.k_rev_t = bool(k_rev_t)
         return out
@@ -108,7 +114,7 @@ class GatherGemmFunction(torch.autograd.Function):
             din = torch.empty(Min, Cin, dtype=torch.float32, device=dout.device)
             wt = weight.transpose(1, 2).contiguous()              # (K, Cout, Cin): the weight of the transposed product
             _call("gcn_sparse_gather_gemm", dout, Min, K, Cout, Cin, _lib.ptr(dout), _lib.ptr(rule_t), _lib.ptr(wt), 0,
-                  int(ctx.k_rev_t), _lib.ptr(din))
+                  int(ctx.k_rev_t), _lib.ptr(din), _lib.ptr(_scratch(Min, K, Cin, dout.device)))
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(weight)
             _call("gcn_sparse_wgrad", dout, rule_cols.shape[1], K, Cin, Cout, _lib.ptr(feats), _lib.ptr(rule_cols),

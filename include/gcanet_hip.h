@@ -194,7 +194,10 @@ int gcn_sparse_coarse_rules(int M, const int32_t *coords, int batch, int D, void
  * k_reversed pairs rule column K-1-k with W[k] (input gradient of a submanifold convolution, with the per-offset
  * transposed weight).  w_transposed must be 0 (reserved).  Cin, Cout multiples of 64.  f32 on v_mfma_f32_16x16x4_f32. */
 int gcn_sparse_gather_gemm(int Mout, int K, int Cin, int Cout, const float *in, const int32_t *rule, const float *W,
-                           int w_transposed, int k_reversed, float *out, void *stream);
+                           int w_transposed, int k_reversed, float *out, float *ws, void *stream);
+/* Small launches split the offsets over several workgroup groups and add the partial sums afterwards (fixed order):
+ * floats of scratch `ws` the call above needs for this shape (0: none, ws may be NULL). */
+long gcn_sparse_gather_gemm_ws_floats(int Mout, int K, int Cout);
 /* dW (K,Cin,Cout) = sum_o in[rule[o,k], :]^T (x) dout[o, :]  (zeroed here first).  ruleT (K,Mout): the rule table
  * transposed, so that one offset's column is contiguous. */
 int gcn_sparse_wgrad(int Mout, int K, int Cin, int Cout, const float *in, const int32_t *ruleT, const float *dout, float *dW,

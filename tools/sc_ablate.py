@@ -21,7 +21,7 @@ def run(M, K, C, fill, rand, reps=10):
     st = _lib.stream_of(x)
     pairs = int(keep.sum())
     res = []
-    for name, fn in (("gather_gemm", lambda: _lib.call("gcn_sparse_gather_gemm", M, K, C, C, _lib.ptr(x), _lib.ptr(rule), _lib.ptr(W), 0, 0, _lib.ptr(out), st)),
+    for name, fn in (("gather_gemm", lambda: _lib.call("gcn_sparse_gather_gemm", M, K, C, C, _lib.ptr(x), _lib.ptr(rule), _lib.ptr(W), 0, 0, _lib.ptr(out), None, st)),
                      ("wgrad", lambda: _lib.call("gcn_sparse_wgrad", M, K, C, C, _lib.ptr(x), _lib.ptr(ruleT), _lib.ptr(out), _lib.ptr(dW), st))):
         fn(); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
