@@ -402,3 +402,185 @@ GCN_EXPORT int gcn_sparse_wgrad(int Mout, int K, int Cin, int Cout, const float 
   sc_wgrad_kernel<<<dim3(cdiv(Mout, rows), K, (Cin / 64) * (Cout / 64)), 256, 0, st>>>(Mout, K, Cin, Cout, rows, in, ruleT, dout, dW);
   return check_launch("sc_wgrad_kernel");
 }
+
+// ---------------------------------------------------------------- BatchNorm1d (+ReLU) over the voxel rows
+// blocks.py's norm_fn = BatchNorm1d(eps 1e-4, momentum 0.1) is always followed by ReLU; in training mode the statistics
+// run over the M active voxels.  Two launches each way instead of torch's five (statistics are f32 per thread, f64 across
+// threads and workgroups); the running statistics are updated by the apply kernel's first workgroup.
+namespace gcn {
+
+// sums (2C doubles, zero on entry): [sum x, sum x^2] per channel.  Thread = one float4 channel group of a row slab.
+__global__ __launch_bounds__(256) void bn_stats_kernel(int M, int C, int rows_per_block, const float *__restrict__ x,
+                                                       double *__restrict__ sums) {
+  __shared__ float part[256][8];                       // per-thread partial sums; reduced over the row slots below
+  const int c4n = C / 4, rstep = 256 / c4n;            // C/4 divides 256 (C = 64: 16 rows per pass, C = 128: 8)
+  const int c4 = threadIdx.x % c4n;
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, M);
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int r = r0 + threadIdx.x / c4n; r < r1; r += rstep) {
+    const float4 v = *reinterpret_cast<const float4 *>(x + (long)r * C + 4 * c4);
+    s1[0] += v.x; s1[1] += v.y; s1[2] += v.z; s1[3] += v.w;
+    s2[0] = fmaf(v.x, v.x, s2[0]); s2[1] = fmaf(v.y, v.y, s2[1]); s2[2] = fmaf(v.z, v.z, s2[2]); s2[3] = fmaf(v.w, v.w, s2[3]);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { part[threadIdx.x][e] = s1[e]; part[threadIdx.x][4 + e] = s2[e]; }
+  __syncthreads();
+  // thread -> (which sum, channel): add the rstep row slots in double, one global atomic per channel and workgroup
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    const int which = i / C, c = i % C;
+    double a = 0.0;
+    for (int sl = 0; sl < rstep; ++sl) a += (double)part[sl * c4n + c / 4][4 * which + (c & 3)];
+    atomicAdd(sums + i, a);
+  }
+}
+
+// y = [relu]((x - mean) * rstd * gamma + beta); mean_rstd (C,2) saved for backward; running statistics as nn.BatchNorm1d
+__global__ __launch_bounds__(256) void bn_apply_kernel(int M, int C, const float *__restrict__ x, const double *__restrict__ sums,
+                                                       const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
+                                                       int relu, float momentum, float *__restrict__ y,
+                                                       float *__restrict__ mean_rstd, float *__restrict__ running_mean,
+                                                       float *__restrict__ running_var) {
+  __shared__ float s_scale[1024], s_shift[1024];          // y = x * scale + shift per channel (C <= 1024)
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const double m = sums[c] / M;
+    const double var = fmax(sums[C + c] / M - m * m, 0.0);
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    s_scale[c] = rstd * gamma[c];
+    s_shift[c] = beta[c] - (float)m * rstd * gamma[c];
+  }
+  __syncthreads();
+  const long per = (long)M * C / 4;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < per; e += (long)gridDim.x * 256) {
+    const int c = (int)((e * 4) % C);
+    const float4 v = reinterpret_cast<const float4 *>(x)[e];
+    float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float z = fmaf(o[i], s_scale[c + i], s_shift[c + i]);
+      o[i] = relu ? fmaxf(z, 0.f) : z;
+    }
+    reinterpret_cast<float4 *>(y)[e] = float4{o[0], o[1], o[2], o[3]};
+  }
+  if (blockIdx.x == 0) {
+    for (int c = threadIdx.x; c < C; c += 256) {
+      const double m = sums[c] / M;
+      const double var = fmax(sums[C + c] / M - m * m, 0.0);
+      mean_rstd[2 * c] = (float)m;
+      mean_rstd[2 * c + 1] = (float)(1.0 / sqrt(var + (double)eps));
+      if (running_mean) {
+        const double unb = M > 1 ? var * M / (M - 1) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+      }
+    }
+  }
+}
+
+// acc (2C doubles, zero on entry): [sum g, sum g*xhat] with g = dy * [z > 0]
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(int M, int C, int rows_per_block, const float *__restrict__ dy,
+                                                            const float *__restrict__ x, const float *__restrict__ mean_rstd,
+                                                            const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                            int relu, double *__restrict__ acc) {
+  __shared__ float part[256][8];
+  const int c4n = C / 4, rstep = 256 / c4n;
+  const int c4 = threadIdx.x % c4n;
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, M);
+  float mean[4], rstd[4], ga[4], be[4], s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    mean[e] = mean_rstd[2 * (4 * c4 + e)]; rstd[e] = mean_rstd[2 * (4 * c4 + e) + 1];
+    ga[e] = gamma[4 * c4 + e]; be[e] = beta[4 * c4 + e];
+  }
+  for (int r = r0 + threadIdx.x / c4n; r < r1; r += rstep) {
+    const float4 xv = *reinterpret_cast<const float4 *>(x + (long)r * C + 4 * c4);
+    const float4 gv = *reinterpret_cast<const float4 *>(dy + (long)r * C + 4 * c4);
+    const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float xh = (xs[e] - mean[e]) * rstd[e];
+      const float z = fmaf(xs[e], rstd[e] * ga[e], be[e] - mean[e] * rstd[e] * ga[e]);     // as bn_apply_kernel forms it
+      const float g = (relu && !(z > 0.f)) ? 0.f : gs[e];
+      s1[e] += g;
+      s2[e] = fmaf(g, xh, s2[e]);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { part[threadIdx.x][e] = s1[e]; part[threadIdx.x][4 + e] = s2[e]; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    const int which = i / C, c = i % C;
+    double a = 0.0;
+    for (int sl = 0; sl < rstep; ++sl) a += (double)part[sl * c4n + c / 4][4 * which + (c & 3)];
+    atomicAdd(acc + i, a);
+  }
+}
+
+// dx = gamma * rstd * (g - mean(g) - xhat * mean(g * xhat)); dgamma = sum g*xhat, dbeta = sum g (first workgroup)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(int M, int C, const float *__restrict__ dy, const float *__restrict__ x,
+                                                           const float *__restrict__ mean_rstd, const float *__restrict__ gamma,
+                                                           const float *__restrict__ beta, int relu, const double *__restrict__ acc,
+                                                           float *__restrict__ dx, float *__restrict__ dgamma,
+                                                           float *__restrict__ dbeta) {
+  __shared__ float s_mean[1024], s_rstd[1024], s_sc[1024], s_sh[1024], s_mg[1024], s_mgx[1024];
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float mean = mean_rstd[2 * c], rstd = mean_rstd[2 * c + 1], ga = gamma[c];
+    s_mean[c] = mean; s_rstd[c] = rstd;
+    s_sc[c] = rstd * ga; s_sh[c] = beta[c] - mean * rstd * ga;
+    s_mg[c] = (float)(acc[c] / M); s_mgx[c] = (float)(acc[C + c] / M);
+  }
+  __syncthreads();
+  const long per = (long)M * C / 4;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < per; e += (long)gridDim.x * 256) {
+    const int c = (int)((e * 4) % C);
+    const float4 xv = reinterpret_cast<const float4 *>(x)[e], gv = reinterpret_cast<const float4 *>(dy)[e];
+    const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {gv.x, gv.y, gv.z, gv.w};
+    float o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float xh = (xs[i] - s_mean[c + i]) * s_rstd[c + i];
+      const float g = (relu && !(fmaf(xs[i], s_sc[c + i], s_sh[c + i]) > 0.f)) ? 0.f : gs[i];
+      o[i] = s_sc[c + i] * (g - s_mg[c + i] - xh * s_mgx[c + i]);
+    }
+    reinterpret_cast<float4 *>(dx)[e] = float4{o[0], o[1], o[2], o[3]};
+  }
+  if (blockIdx.x == 0)
+    for (int c = threadIdx.x; c < C; c += 256) { dbeta[c] = (float)acc[c]; dgamma[c] = (float)acc[C + c]; }
+}
+
+}  // namespace gcn
+
+static int bn_check(int M, int C, const char *who) {
+  GCN_REQUIRE(M >= 1 && C >= 4 && C % 4 == 0 && C / 4 <= 256 && 256 % (C / 4) == 0 && C <= 1024, "%s: M=%d, C=%d unsupported (C/4 must divide 256)", who, M, C);
+  return GCN_OK;
+}
+
+GCN_EXPORT int gcn_bn_relu_fwd(int M, int C, const float *x, const float *gamma, const float *beta, float eps, int relu,
+                               float momentum, float *y, float *mean_rstd, float *running_mean, float *running_var,
+                               double *sums_ws, void *stream) {
+  int rc = bn_check(M, C, "gcn_bn_relu_fwd");
+  if (rc) return rc;
+  GCN_REQUIRE(x && gamma && beta && y && mean_rstd && sums_ws, "gcn_bn_relu_fwd: null pointer");
+  GCN_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "gcn_bn_relu_fwd: pass both running buffers or neither");
+  hipStream_t st = (hipStream_t)stream;
+  GCN_HIP(hipMemsetAsync(sums_ws, 0, sizeof(double) * 2 * C, st));
+  const int rows = 256;
+  bn_stats_kernel<<<cdiv(M, rows), 256, 0, st>>>(M, C, rows, x, sums_ws);
+  const int blocks = (int)fmin(4096.0, (double)cdiv((long)M * C / 4, 256));
+  bn_apply_kernel<<<blocks, 256, 0, st>>>(M, C, x, sums_ws, gamma, beta, eps, relu, momentum, y, mean_rstd, running_mean, running_var);
+  return check_launch("bn_apply_kernel");
+}
+
+GCN_EXPORT int gcn_bn_relu_bwd(int M, int C, const float *dy, const float *x, const float *gamma, const float *beta,
+                               const float *mean_rstd, int relu, float *dx, float *dgamma, float *dbeta, double *acc_ws,
+                               void *stream) {
+  int rc = bn_check(M, C, "gcn_bn_relu_bwd");
+  if (rc) return rc;
+  GCN_REQUIRE(dy && x && gamma && beta && mean_rstd && dx && dgamma && dbeta && acc_ws, "gcn_bn_relu_bwd: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  GCN_HIP(hipMemsetAsync(acc_ws, 0, sizeof(double) * 2 * C, st));
+  const int rows = 256;
+  bn_bwd_reduce_kernel<<<cdiv(M, rows), 256, 0, st>>>(M, C, rows, dy, x, mean_rstd, gamma, beta, relu, acc_ws);
+  const int blocks = (int)fmin(4096.0, (double)cdiv((long)M * C / 4, 256));
+  bn_bwd_apply_kernel<<<blocks, 256, 0, st>>>(M, C, dy, x, mean_rstd, gamma, beta, relu, acc_ws, dx, dgamma, dbeta);
+  return check_launch("bn_bwd_apply_kernel");
+}

@@ -122,6 +122,50 @@ class GatherGemmFunction(torch.autograd.Function):
         return din, dw, None, None, None, None
 
 
+class BatchNormReLUFunction(torch.autograd.Function):
+    """[ReLU](BatchNorm1d(x)) with batch statistics over the rows (csrc/sparseconv.hip: bn_* kernels)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, relu):
+        _lib.require_cuda(x)
+        x = x.float().contiguous()
+        M, C = x.shape
+        ga, be = gamma.float().contiguous(), beta.float().contiguous()
+        y = torch.empty_like(x)
+        mean_rstd = torch.empty(C, 2, dtype=torch.float32, device=x.device)
+        ws = torch.empty(2 * C, dtype=torch.float64, device=x.device)
+        _call("gcn_bn_relu_fwd", x, M, C, _lib.ptr(x), _lib.ptr(ga), _lib.ptr(be), float(eps), int(relu), float(momentum),
+              _lib.ptr(y), _lib.ptr(mean_rstd), _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(ws))
+        ctx.save_for_backward(x, ga, be, mean_rstd)
+        ctx.relu = int(relu)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, ga, be, mean_rstd = ctx.saved_tensors
+        M, C = x.shape
+        dy = dy.float().contiguous()
+        dx = torch.empty_like(x)
+        dgamma, dbeta = torch.empty(C, device=x.device), torch.empty(C, device=x.device)
+        ws = torch.empty(2 * C, dtype=torch.float64, device=x.device)
+        _call("gcn_bn_relu_bwd", x, M, C, _lib.ptr(dy), _lib.ptr(x), _lib.ptr(ga), _lib.ptr(be), _lib.ptr(mean_rstd), ctx.relu,
+              _lib.ptr(dx), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ws))
+        return dx, dgamma, dbeta, None, None, None, None, None
+
+
+def batch_norm_relu(x, bn: nn.BatchNorm1d, relu=True):
+    """bn(x) [+ ReLU] for features (M,C).  Training mode with >= 2 rows: the fused kernels (running statistics and
+    num_batches_tracked updated as the module would); otherwise the module itself."""
+    if not (bn.training and x.is_cuda and x.shape[0] >= 2 and bn.momentum is not None and bn.affine
+            and x.shape[1] % 4 == 0 and 256 % (x.shape[1] // 4) == 0):
+        y = bn(x)
+        return torch.relu(y) if relu else y
+    if bn.track_running_stats:
+        bn.num_batches_tracked.add_(1)
+    return BatchNormReLUFunction.apply(x, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
+                                       bn.running_var if bn.track_running_stats else None, bn.momentum, bn.eps, relu)
+
+
 class _SparseConvBase(nn.Module):
     K = 27
 
@@ -174,13 +218,21 @@ class SparseSequential(nn.Sequential):
     """spconv.SparseSequential: dense modules act on .features."""
 
     def forward(self, x):
-        for m in self:
+        mods = list(self)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
             if isinstance(m, (_SparseConvBase, SparseSequential, ResidualBlock, UBlock, Custom1x1Subm3d)):
                 x = m(x)
             elif isinstance(m, nn.Identity):
                 pass
+            elif isinstance(m, nn.BatchNorm1d):                 # norm_fn is always followed by ReLU in blocks.py: fused
+                fuse = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+                x = x.replace_feature(batch_norm_relu(x.features, m, relu=fuse))
+                i += int(fuse)
             else:
                 x = x.replace_feature(m(x.features))
+            i += 1
         return x
 
 

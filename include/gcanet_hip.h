@@ -202,6 +202,13 @@ long gcn_sparse_gather_gemm_ws_floats(int Mout, int K, int Cout);
  * transposed, so that one offset's column is contiguous. */
 int gcn_sparse_wgrad(int Mout, int K, int Cin, int Cout, const float *in, const int32_t *ruleT, const float *dout, float *dW,
                      void *stream);
+/* BatchNorm1d(+ReLU) in training mode over the M rows of a sparse tensor's features (blocks.py norm_fn, eps 1e-4,
+ * momentum 0.1, every instance followed by nn.ReLU).  y, mean_rstd (C,2) out; running_mean/var (C) updated as
+ * nn.BatchNorm1d does (unbiased variance) or both NULL.  sums_ws / acc_ws: 2C doubles.  C/4 must divide 256. */
+int gcn_bn_relu_fwd(int M, int C, const float *x, const float *gamma, const float *beta, float eps, int relu, float momentum,
+                    float *y, float *mean_rstd, float *running_mean, float *running_var, double *sums_ws, void *stream);
+int gcn_bn_relu_bwd(int M, int C, const float *dy, const float *x, const float *gamma, const float *beta,
+                    const float *mean_rstd, int relu, float *dx, float *dgamma, float *dbeta, double *acc_ws, void *stream);
 /* Device scratch for the uniform-grid path of gcn_ballquery_batch_p (easy form, n >= 2048): pass it as grid_ws
  * (NULL selects the brute-force scan).  nbatch = number of batch segments (len(batch_offsets) - 1). */
 long gcn_ballquery_grid_ws_bytes(int n);

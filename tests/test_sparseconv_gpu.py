@@ -146,3 +146,33 @@ def test_empty_and_tiny_sparse_tensors(dev):
     f = torch.randn(1, 64, device=dev)
     y = conv(S.SparseConvTensor(f, torch.tensor([[0, 3, 4, 5]], dtype=torch.int32, device=dev), [8] * 3, 1)).features
     _close(y.detach().cpu(), (f @ conv.weight[13]).detach().cpu(), "isolated voxel = centre tap only")
+
+
+@pytest.mark.parametrize("C,relu", [(64, True), (128, True), (64, False)])
+def test_batch_norm_relu_matches_torch(dev, C, relu):
+    """Fused BatchNorm1d(+ReLU) (csrc/sparseconv.hip bn_* kernels) vs nn.BatchNorm1d in training mode: output, input and
+    parameter gradients, running statistics."""
+    from gcanet_amd.sparseconv import batch_norm_relu
+    g = torch.Generator().manual_seed(11)
+    M = 3001
+    x = torch.randn(M, C, generator=g) * 2 + 0.5
+    gy = torch.randn(M, C, generator=g)
+    bn_a, bn_b = torch.nn.BatchNorm1d(C, eps=1e-4, momentum=0.1), torch.nn.BatchNorm1d(C, eps=1e-4, momentum=0.1)
+    with torch.no_grad():
+        bn_a.weight.copy_(torch.randn(C, generator=g)); bn_a.bias.copy_(torch.randn(C, generator=g))
+    bn_b.load_state_dict(bn_a.state_dict())
+    bn_a = bn_a.to(dev)
+    xa = x.to(dev).requires_grad_(True)
+    ya = batch_norm_relu(xa, bn_a, relu=relu)
+    ya.backward(gy.to(dev))
+    xb = x.clone().requires_grad_(True)
+    yb = bn_b(xb)
+    yb = torch.relu(yb) if relu else yb
+    yb.backward(gy)
+    _close(ya.detach().cpu(), yb.detach(), "output")
+    _close(xa.grad.cpu(), xb.grad, "input gradient")
+    _close(bn_a.weight.grad.cpu(), bn_b.weight.grad, "dgamma")
+    _close(bn_a.bias.grad.cpu(), bn_b.bias.grad, "dbeta")
+    _close(bn_a.running_mean.cpu(), bn_b.running_mean, "running mean")
+    _close(bn_a.running_var.cpu(), bn_b.running_var, "running var")
+    assert int(bn_a.num_batches_tracked) == 1

@@ -40,7 +40,8 @@ def main():
         _, cls, iou, mask = head(S.SparseConvTensor(x, idx, [D] * 3, P), inst_map)
         (cls.pow(2).mean() + iou.pow(2).mean() + mask.pow(2).mean()).backward()
 
-    step()
+    for _ in range(3):
+        step()
     torch.cuda.synchronize()
     _lib.enable_timing(False)
     t0 = time.perf_counter()

@@ -14,7 +14,8 @@ from grouping_bench import scene  # noqa: E402
 
 
 def timed(fn, reps):
-    out = fn()
+    for _ in range(3):
+        out = fn()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(reps):
