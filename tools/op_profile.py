@@ -14,12 +14,15 @@ dev = torch.device("cuda:0")
 torch.manual_seed(0)
 model = dgcnn.PrimitivesEmbeddingDGCNGn(nn_nb=64, dtype="bf16").to(dev)
 dp = parallel.FlatGradDP(model, 1)
-opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)
+from gcanet_amd.layers import CastCache  # noqa: E402
+casts = CastCache(model)
 pts, nrm = bench.synth_clouds(range(8), 8192, dev)
 
 
 def step():
     dp.zero_grad()
+    casts.refresh()
     with torch.autocast("cuda", dtype=torch.bfloat16):
         out = model(pts, nrm)
     loss = bench.loss_of(out)
