@@ -156,7 +156,7 @@ def main():
 
     torch.manual_seed(0)
     model = dgcnn.PrimitivesEmbeddingDGCNGn(nn_nb=args.k, dtype="bf16").to(dev)
-    dp = parallel.FlatGradDP(model, world)
+    dp = parallel.FlatGradDP(model, world, late=model.encoder.parameters())   # heads' all-reduce overlaps the encoder's backward
     dp.sync_params()
     opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)   # option_new.py:83-90 (one multi-tensor kernel)
     B, N = args.batch, args.points
@@ -229,7 +229,8 @@ def main():
         "config": {"workload": "BASELINE configs[1]: %d clouds/GPU, N=%d, k=%d, GCANet hot path (DGCNN encoder 3x"
                                "[kNN+EdgeConv], heads, normal EdgeConv, embedding, offset module; M4:634-747) fwd+bwd"
                                "+Adam; stops before forward_grouping/spconv (third-party, SURVEY 8f)" % (B, N, args.k),
-                   "global_batch": world * B, "points": N, "k": args.k, "parallelism": "dp%d" % world},
+                   "global_batch": world * B, "points": N, "k": args.k, "parallelism": "dp%d" % world,
+                   "allreduce_overlapped_steps": dp.early_started_in_backward},
         "knn_mpts_per_s": round(3 * B * N / knn_ms / 1e3, 2) if knn_ms > 0 else None,
         "roofline": roofline, "kernels": kernels, "loss": float(loss.detach()),
     }

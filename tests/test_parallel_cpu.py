@@ -56,6 +56,52 @@ def test_flat_grad_allreduce_matches_single_process():
     torch.testing.assert_close(res[0][1], ref, rtol=1e-5, atol=1e-6)
 
 
+def _worker_overlap(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from gcanet_amd import parallel
+    r, l, w = parallel.init_distributed("gloo")
+    torch.manual_seed(0)
+    model = nn.Sequential(nn.Linear(6, 5), nn.ReLU(), nn.Linear(5, 7), nn.ReLU(), nn.Linear(7, 2))
+    dp = parallel.FlatGradDP(model, late=model[0].parameters())       # layer 0 is upstream: its gradients come last
+    dp.sync_params()
+    data = torch.arange(8 * 6, dtype=torch.float32).view(8, 6) / 10.0
+    lo, hi = parallel.shard_range(8, r, w)
+    out = []
+    for it in range(2):                                                # twice: the per-step state must reset
+        dp.zero_grad()
+        model(data[lo:hi]).pow(2).mean().backward()
+        dp.all_reduce_grads()
+        out.append(torch.cat([p.grad.reshape(-1) for p in model.parameters()]).clone())
+    q.put((r, out, dp.early_started_in_backward))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_early_segment_allreduce_overlaps_backward():
+    """The early (downstream) segment is packed and its all-reduce started from inside backward, when the first late
+    gradient arrives; the result equals the single-process gradient in module.parameters() order."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_overlap, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    torch.manual_seed(0)
+    model = nn.Sequential(nn.Linear(6, 5), nn.ReLU(), nn.Linear(5, 7), nn.ReLU(), nn.Linear(7, 2))
+    data = torch.arange(8 * 6, dtype=torch.float32).view(8, 6) / 10.0
+    model(data).pow(2).mean().backward()
+    ref = torch.cat([p.grad.view(-1) for p in model.parameters()])
+    for r, outs, started in res:
+        assert started == 2, "the early all-reduce must start during backward in both steps"
+        for o in outs:
+            torch.testing.assert_close(o, ref, rtol=1e-5, atol=1e-6)
+
+
 def test_shard_range_covers_everything():
     from gcanet_amd.parallel import shard_range
     for n in (0, 1, 7, 8, 64):
