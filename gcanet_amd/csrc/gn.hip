@@ -70,7 +70,18 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const void *__restrict__ 
   for (int rep = 0; rep < s.reps; ++rep) {
     const int c = s.c4 + rep * 1024;
     float a1 = 0.f, a2 = 0.f;
-    for (int r = r0 + s.row0; r < r1; r += s.rstep) {
+    // four rows in flight per thread (8-byte loads: one row at a time leaves the memory system idle -- 3 TB/s)
+    int r = r0 + s.row0;
+    for (; r + 3 * s.rstep < r1; r += 4 * s.rstep) {
+      float v[4][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) load4<BF16>(x, ((long)b * N + r + u * s.rstep) * C + c, v[u]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { a1 += v[u][i]; a2 = fmaf(v[u][i], v[u][i], a2); }
+    }
+    for (; r < r1; r += s.rstep) {
       float v[4];
       load4<BF16>(x, ((long)b * N + r) * C + c, v);
 #pragma unroll
@@ -149,9 +160,7 @@ __global__ __launch_bounds__(256) void gn_apply_max_kernel(const void *__restric
     const float gg[4] = {ga.x, ga.y, ga.z, ga.w}, bb[4] = {be.x, be.y, be.z, be.w};
     float bv[4] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
     int br[4] = {0, 0, 0, 0};
-    for (int r = r0 + s.row0; r < r1; r += s.rstep) {
-      float v[4];
-      load4<BF16>(x, ((long)b * N + r) * C + c, v);
+    auto take = [&](const float (&v)[4], int r) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         float z = (v[i] - mean) * rstd * gg[i] + bb[i];
@@ -159,6 +168,19 @@ __global__ __launch_bounds__(256) void gn_apply_max_kernel(const void *__restric
         if (BF16) z = bf2f(f2bf(z));                    // the value the (B,N,C) bf16 tensor would have held
         if (z > bv[i]) { bv[i] = z; br[i] = r; }
       }
+    };
+    int r = r0 + s.row0;
+    for (; r + 3 * s.rstep < r1; r += 4 * s.rstep) {    // four rows in flight per thread, consumed in row order
+      float v[4][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) load4<BF16>(x, ((long)b * N + r + u * s.rstep) * C + c, v[u]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) take(v[u], r + u * s.rstep);
+    }
+    for (; r < r1; r += s.rstep) {
+      float v[4];
+      load4<BF16>(x, ((long)b * N + r) * C + c, v);
+      take(v, r);
     }
     if (r0 + s.row0 < r1) {
 #pragma unroll
@@ -209,11 +231,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const void *__restri
     const float gg[4] = {ga.x, ga.y, ga.z, ga.w}, bb[4] = {be.x, be.y, be.z, be.w};
     float dg[4] = {0.f, 0.f, 0.f, 0.f}, db[4] = {0.f, 0.f, 0.f, 0.f};
     float s1 = 0.f, s2 = 0.f;
-    for (int r = r0 + s.row0; r < r1; r += s.rstep) {
-      float xv[4], gv[4];
-      const long o = ((long)b * N + r) * C + c;
-      load4<BF16>(x, o, xv);
-      load4<BF16>(dy, o, gv);
+    auto accum = [&](const float (&xv)[4], const float (&gv)[4]) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const float xh = (xv[i] - mean) * rstd;
@@ -224,6 +242,25 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const void *__restri
         s1 = fmaf(gg[i], gz, s1);
         s2 = fmaf(gg[i] * gz, xh, s2);
       }
+    };
+    int r = r0 + s.row0;
+    for (; r + 3 * s.rstep < r1; r += 4 * s.rstep) {           // four rows (eight loads) in flight per thread
+      float xv[4][4], gv[4][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long o = ((long)b * N + r + u * s.rstep) * C + c;
+        load4<BF16>(x, o, xv[u]);
+        load4<BF16>(dy, o, gv[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) accum(xv[u], gv[u]);
+    }
+    for (; r < r1; r += s.rstep) {
+      float xv[4], gv[4];
+      const long o = ((long)b * N + r) * C + c;
+      load4<BF16>(x, o, xv);
+      load4<BF16>(dy, o, gv);
+      accum(xv, gv);
     }
     // per-channel partials: combine the row slices of the workgroup in LDS, then ONE global atomic per
     // (workgroup, channel) -- per-thread global atomics on C addresses were 14x contended
