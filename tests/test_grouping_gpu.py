@@ -191,3 +191,34 @@ def test_forward_grouping_device_edge_cases(dev):
     assert torch.equal(small[0], large[0]) and torch.equal(small[1], large[1]) and large[1].numel() > 4
     d = forward_grouping_device(*args, min_npoint=20, mean_active=400, to_cpu=False, **kw)
     assert d[0].is_cuda and torch.equal(d[0].cpu(), large[0])
+
+
+@pytest.mark.parametrize("npts,expect_literal", [(2600, False), (3400, True)])
+def test_forward_grouping_device_crowded_neighbourhoods(dev, npts, expect_literal):
+    """One tiny blob: every point has npts-1 neighbours.  2599 > the 2048-entry LDS hit buffer -> the kernel's
+    whole-segment scan path; 3399 > the reference's 3000-entry cap (bfs_cluster.cu:54) -> truncated, asymmetric lists,
+    for which the device path hands over to the literal one.  Both must equal the CPU restatement."""
+    from gcanet_amd import grouping
+    rng = np.random.default_rng(7)
+    B, N, P = 1, npts, 2
+    xyz = (0.5 + 0.001 * rng.standard_normal((B, N, 3))).astype(np.float32)
+    sem = np.tile(np.array([[5.0, -5.0]], np.float32), (B * N, 1))
+    off = np.zeros((B * N, 3), np.float32)
+    bidx = np.zeros(B * N, np.int64)
+    par = (rng.standard_normal((B, N, 22)) * 0.01).astype(np.float32)
+    feat = (1.0 + 0.01 * rng.standard_normal((B, N, 16))).astype(np.float32)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    calls = []
+    orig = grouping.forward_grouping
+    grouping.forward_grouping = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        pi, po = grouping.forward_grouping_device(t(sem), t(off), t(bidx), t(xyz.reshape(-1, 3)), torch.zeros(B, N, P), t(par),
+                                                  t(feat), semantic_classes=P, radius=0.03, similarity_threshold_inst=0.0,
+                                                  similarity_threshold_para=0.0, mean_active=300, min_npoint=50)
+    finally:
+        grouping.forward_grouping = orig
+    assert bool(calls) == expect_literal
+    rpi, rpo = _oracle_forward_grouping(sem, off, bidx, xyz.reshape(-1, 3), B, N, par, feat, P, 0.03, 0.0, 0.0, 300, 50)
+    assert rpo.size >= 2
+    np.testing.assert_array_equal(po.numpy(), rpo)
+    np.testing.assert_array_equal(pi.numpy(), rpi)

@@ -176,3 +176,34 @@ def test_batch_norm_relu_matches_torch(dev, C, relu):
     _close(bn_a.running_mean.cpu(), bn_b.running_mean, "running mean")
     _close(bn_a.running_var.cpu(), bn_b.running_var, "running var")
     assert int(bn_a.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("M,Cin,Cout", [(70001, 64, 128), (3000, 128, 64)])
+def test_gather_gemm_and_wgrad_on_random_rule_tables(dev, M, Cin, Cout):
+    """The two kernels on a synthetic rule table (30 % filled, random sources) against a float64 gather + matmul on the
+    same device: the large case runs unsplit (>= 512 workgroups), the small one with the offsets split 9 ways."""
+    from gcanet_amd import _lib
+    K = 27
+    g = torch.Generator(device=dev).manual_seed(0)
+    x = torch.randn(M, Cin, device=dev, generator=g)
+    W = torch.randn(K, Cin, Cout, device=dev, generator=g) / (K * Cin) ** 0.5
+    dy = torch.randn(M, Cout, device=dev, generator=g)
+    src = torch.randint(0, M, (M, K), device=dev, generator=g)
+    rule = torch.where(torch.rand(M, K, device=dev, generator=g) < 0.3, src, torch.full_like(src, -1)).int().contiguous()
+    out = torch.empty(M, Cout, device=dev)
+    n_ws = _lib.lib().gcn_sparse_gather_gemm_ws_floats(M, K, Cout)
+    assert (n_ws == 0) == (M > 60000)
+    ws = torch.empty(max(n_ws, 1), device=dev)
+    st = _lib.stream_of(x)
+    _lib.call("gcn_sparse_gather_gemm", M, K, Cin, Cout, _lib.ptr(x), _lib.ptr(rule), _lib.ptr(W), 0, 0, _lib.ptr(out), _lib.ptr(ws), st)
+    dW = torch.empty_like(W)
+    _lib.call("gcn_sparse_wgrad", M, K, Cin, Cout, _lib.ptr(x), _lib.ptr(rule.t().contiguous()), _lib.ptr(dy), _lib.ptr(dW), st)
+    ref = torch.zeros(M, Cout, dtype=torch.float64, device=dev)
+    refw = torch.zeros(K, Cin, Cout, dtype=torch.float64, device=dev)
+    for k in range(K):
+        ok = rule[:, k] >= 0
+        xs = x[rule[ok, k].long()].double()
+        ref[ok] += xs @ W[k].double()
+        refw[k] = xs.t() @ dy[ok].double()
+    _close(out.cpu().double(), ref.cpu(), "gather-GEMM")
+    _close(dW.cpu().double(), refw.cpu(), "weight gradient")
