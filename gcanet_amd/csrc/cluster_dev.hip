@@ -82,7 +82,7 @@ __global__ void cc_flatten_kernel(int n, int32_t *parent, int32_t *__restrict__ 
 // vals (4, n+1): [kept size, primary size, kept count, primary count] of the roots; entry n = 0 (scan total slot)
 __global__ void cluster_classify_kernel(int n, const int32_t *__restrict__ comp, const int32_t *__restrict__ csize,
                                         const int32_t *__restrict__ seg_of, const int32_t *__restrict__ seg_cls,
-                                        int32_t *__restrict__ vals) {
+                                        float size_threshold, int32_t *__restrict__ vals) {
   // hierarchical_aggregation.cpp:7-8
   const float class_mean[10] = {-1.f, -1.f, 3917.f, 12056.f, 2303.f, 8331.f, 3948.f, 3166.f, 5629.f, 11719.f};
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -92,10 +92,14 @@ __global__ void cluster_classify_kernel(int n, const int32_t *__restrict__ comp,
     const int cls = seg_cls[seg_of[i]];
     if (cls >= 0) {
       const int sz = csize[i];
-      const float mean = class_mean[cls];
-      const float low = (float)(0.05 * mean), high = (float)(0.3 * mean);    // hierarchical_aggregation.cpp:60-61
-      if (sz < high) { if (sz >= low) ks = sz; }
-      else ps = sz;
+      if (size_threshold >= 0.f) {                       // bfs_cluster.cpp:86-115: one list, clusters of >= threshold points
+        if (sz >= size_threshold) ks = sz;
+      } else {
+        const float mean = class_mean[cls];
+        const float low = (float)(0.05 * mean), high = (float)(0.3 * mean);    // hierarchical_aggregation.cpp:60-61
+        if (sz < high) { if (sz >= low) ks = sz; }
+        else ps = sz;
+      }
     }
   }
   const long W = n + 1;
@@ -240,7 +244,7 @@ GCN_EXPORT long gcn_cluster_components_ws_bytes(int n) {
 
 GCN_EXPORT int gcn_cluster_components(int n, const int32_t *nbr, const int32_t *start_len, const int32_t *seg_of,
                                       const int32_t *seg_offsets, const int32_t *seg_cls, int S,
-                                      const int32_t *point_index, void *ws, int32_t *cluster_idxs,
+                                      const int32_t *point_index, float size_threshold, void *ws, int32_t *cluster_idxs,
                                       int32_t *cluster_offsets, int32_t *counts, void *stream) {
   GCN_REQUIRE(counts, "gcn_cluster_components: counts is null");
   GCN_REQUIRE(n >= 0 && n < (1 << 20) && S >= 1, "gcn_cluster_components: n=%d must be below 2^20 (queue rank is a 20-bit key field)", n);
@@ -259,7 +263,7 @@ GCN_EXPORT int gcn_cluster_components(int n, const int32_t *nbr, const int32_t *
   cc_init_kernel<<<cdiv(n, 256), 256, 0, st>>>(n, nbr, start_len, parent, csize, key, visited, counters);
   cc_union_kernel<<<cdiv(n, 4), 256, 0, st>>>(n, nbr, start_len, parent);
   cc_flatten_kernel<<<cdiv(n, 256), 256, 0, st>>>(n, parent, comp, csize);
-  cluster_classify_kernel<<<cdiv(n + 1, 256), 256, 0, st>>>(n, comp, csize, seg_of, seg_cls, vals);
+  cluster_classify_kernel<<<cdiv(n + 1, 256), 256, 0, st>>>(n, comp, csize, seg_of, seg_cls, size_threshold, vals);
   GCN_HIP(hipMemcpyAsync(scan, vals, sizeof(int32_t) * 4 * (size_t)(n + 1), hipMemcpyDeviceToDevice, st));
   exscan_rows(st, 4, n + 1, scan, bsum);
   cluster_offsets_kernel<<<cdiv(n, 256), 256, 0, st>>>(n, comp, csize, seg_of, seg_offsets, vals, scan, cluster_offsets, out,

@@ -155,7 +155,7 @@ def forward_grouping_device(semantic_scores, pt_offsets, batch_idxs, coords_floa
                       _lib.ptr(fp), fp.shape[1], _lib.ptr(dm[1]), float(similarity_threshold_para), _lib.ptr(nbr),
                       capacity, _lib.ptr(start_len), _lib.ptr(status), _lib.ptr(grid_ws), st)
             _lib.call("gcn_cluster_components", n, _lib.ptr(nbr), _lib.ptr(start_len), _lib.ptr(seg_of),
-                      _lib.ptr(seg_offsets), _lib.ptr(seg_cls), S, _lib.ptr(point_index), _lib.ptr(ws),
+                      _lib.ptr(seg_offsets), _lib.ptr(seg_cls), S, _lib.ptr(point_index), -1.0, _lib.ptr(ws),
                       _lib.ptr(cluster_idxs), _lib.ptr(cluster_offsets), _lib.ptr(status[4:]), st)
             total, capped, overflow, _, nsum, ncl = status.cpu().tolist()[:6]       # the one host synchronisation
             if not overflow:

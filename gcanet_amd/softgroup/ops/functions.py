@@ -66,6 +66,27 @@ class BFSCluster(Function):
         assert ball_query_idxs.is_contiguous()
         assert start_len.is_contiguous()
         cm = cluster_numpoint_mean.to(torch.float32).contiguous()
+        if ball_query_idxs.is_cuda and start_len.is_cuda and 0 < start_len.size(0) < (1 << 20):
+            # device path (csrc/cluster_dev.hip: union-find components + the reference's BFS member order) for complete,
+            # i.e. symmetric, neighbour lists; a list that hit a cap (1000 easy / 3000) may be truncated -> host BFS below
+            sl32, bq32 = start_len.int().contiguous(), ball_query_idxs.int().contiguous()
+            n = sl32.size(0)
+            mean = float(cm.reshape(-1)[int(class_id)])
+            thr = float(threshold) if mean == -1 else float(threshold) * mean          # bfs_cluster.cpp:86-91
+            if int(sl32[:, 1].max()) < 1000 and thr >= 0:
+                dev = sl32.device
+                z = torch.zeros(n, dtype=torch.int32, device=dev)
+                seg_offsets = torch.tensor([0, n], dtype=torch.int32, device=dev)
+                seg_cls = torch.zeros(1, dtype=torch.int32, device=dev)
+                pidx = torch.arange(n, dtype=torch.int32, device=dev)
+                ws = torch.empty(_lib.lib().gcn_cluster_components_ws_bytes(n), dtype=torch.uint8, device=dev)
+                idxs = torch.empty(n, 2, dtype=torch.int32, device=dev)
+                offs = torch.empty(n + 1, dtype=torch.int32, device=dev)
+                counts = torch.empty(2, dtype=torch.int32, device=dev)
+                _run("gcn_cluster_components", sl32, n, _lib.ptr(bq32), _lib.ptr(sl32), _lib.ptr(z), _lib.ptr(seg_offsets),
+                     _lib.ptr(seg_cls), 1, _lib.ptr(pidx), thr, _lib.ptr(ws), _lib.ptr(idxs), _lib.ptr(offs), _lib.ptr(counts))
+                nsum, ncl = counts.tolist()
+                return idxs[:nsum].cpu(), offs[:ncl + 1].cpu()
         bq, sl = _cpu_i32(ball_query_idxs), _cpu_i32(start_len)
         N = sl.size(0)
         s, c = C.c_int(0), C.c_int(0)

@@ -170,11 +170,14 @@ int gcn_ballquery_sim(int n, float radius, const float *xyz, const int32_t *seg_
  * using_set_aggr = False) for all segments on the device: components of the (symmetric) neighbour lists, members in the
  * reference's BFS dequeue order, segment by segment, kept fragments before primaries.  cluster_idxs (n,2) gets
  * (cluster id, point_index[member]) rows, cluster_offsets (n+1); counts (2 ints, device) = (rows, clusters) that are
- * valid.  No host synchronisation.  seg_cls (S): semantic class 0..9 of the segment or < 0 to skip it.  n < 2^20. */
+ * valid.  No host synchronisation.  seg_cls (S): semantic class 0..9 of the segment or < 0 to skip it.  n < 2^20.
+ * size_threshold < 0: the kept/primary rule above; >= 0: `bfs_cluster` (bfs_cluster.cpp:48-143) -- every component of at
+ * least size_threshold points, in discovery order (one segment: S = 1, seg_cls[0] = 0). */
 long gcn_cluster_components_ws_bytes(int n);
 int gcn_cluster_components(int n, const int32_t *nbr, const int32_t *start_len, const int32_t *seg_of,
                            const int32_t *seg_offsets, const int32_t *seg_cls, int S, const int32_t *point_index,
-                           void *ws, int32_t *cluster_idxs, int32_t *cluster_offsets, int32_t *counts, void *stream);
+                           float size_threshold, void *ws, int32_t *cluster_idxs, int32_t *cluster_offsets,
+                           int32_t *counts, void *stream);
 /* ---- sparse 3-D convolutions of the instance "tiny U-Net" (softgroup/model/blocks.py:44-143; M4:611-616,1379-1392;
  * the reference calls the un-vendored third-party spconv package: SubMConv3d / SparseConv3d(k=2,s=2) /
  * SparseInverseConv3d).  Sparse tensor = features (M,C) f32 + coords (M,4) int32 [sample,x,y,z] with 0 <= x,y,z < D,

@@ -222,3 +222,27 @@ def test_voxelization_idx_device_rejects_out_of_range(dev):
     coords = torch.tensor([[0, 1, 2, 70000]], dtype=torch.int64, device=dev)
     with pytest.raises(RuntimeError):
         _ops().voxelization_idx(coords, 1, 4)
+
+
+@pytest.mark.parametrize("class_id,threshold", [(0, 5.0), (4, 0.01)])
+def test_bfs_cluster_device_matches_oracle(dev, class_id, threshold):
+    """bfs_cluster (K16) on CUDA neighbour lists: device components + the reference's BFS member order
+    (csrc/cluster_dev.hip) against the CPU restatement of bfs_cluster.cpp:48-143."""
+    ops = _ops()
+    rng = np.random.default_rng(31)
+    centers = rng.random((12, 3)).astype(np.float32)
+    which = rng.integers(0, 12, 4000)
+    t_ = rng.random((4000, 1)).astype(np.float32)
+    dirs = rng.standard_normal((12, 3)).astype(np.float32)
+    xyz = (centers[which] + 0.2 * t_ * dirs[which] / np.linalg.norm(dirs[which], axis=1, keepdims=True)
+           + 0.003 * rng.standard_normal((4000, 3))).astype(np.float32)          # thin rods: many BFS levels
+    bidx = np.zeros(4000, np.int32)
+    offs = np.array([0, 4000], np.int32)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    idx, sl = ops.ball_query_easy(t(xyz), t(bidx), t(offs), 0.02, 50)
+    mean = np.array([-1., -1., 3917., 12056., 2303., 8331., 3948., 3166., 5629., 11719.], np.float32)
+    ci, co = ops.bfs_cluster(torch.from_numpy(mean), idx, sl, threshold, class_id)
+    rci, rco = oracle.bfs_cluster(mean, idx.cpu().numpy(), sl.cpu().numpy(), threshold, class_id)
+    assert rco.size > 3 and not ci.is_cuda
+    np.testing.assert_array_equal(co.numpy(), rco)
+    np.testing.assert_array_equal(ci.numpy(), rci)
