@@ -20,15 +20,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# Library GEMMs of the per-point heads: PyTorch's TunableOp picks the rocBLAS / hipBLASLt solution per shape.  The
-# selections were tuned once on an MI355X with this image (PYTORCH_TUNABLEOP_ENABLED=1 python bench.py, ~25 s) and are
-# committed; here they are only looked up (no tuning time, nothing written).  A file recorded for other library
-# versions fails PyTorch's validators and is ignored, i.e. the defaults apply.
-os.environ.setdefault("PYTORCH_TUNABLEOP_ENABLED", "1")
-os.environ.setdefault("PYTORCH_TUNABLEOP_TUNING", "0")
-os.environ.setdefault("PYTORCH_TUNABLEOP_RECORD_UNTUNED", "0")
-os.environ.setdefault("PYTORCH_TUNABLEOP_FILENAME", os.path.join(ROOT, "gcanet_amd", "tunableop_gfx950.csv"))
-
 import torch  # noqa: E402
 
 PEAK_TFLOPS = {"bf16_mfma": 2500.0, "f32_mfma": 157.3}   # MI355X_MICROARCH.md dense peaks
@@ -148,7 +139,6 @@ def main():
 
     from gcanet_amd import _lib, dgcnn, parallel
     rank, local, world = parallel.init_distributed()
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     local = local % torch.cuda.device_count()      # one rank per GPU; the modulo only matters when ranks are over-subscribed in a rehearsal
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
