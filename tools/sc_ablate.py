@@ -18,10 +18,11 @@ def run(M, K, C, fill, rand, reps=10):
     rule = torch.where(keep, src, torch.full_like(src, -1)).int().contiguous()
     ruleT = rule.t().contiguous()
     out = torch.empty(M, C, device=dev); dW = torch.empty_like(W)
+    ws = torch.empty(max(_lib.lib().gcn_sparse_gather_gemm_ws_floats(M, K, C), 1), device=dev)
     st = _lib.stream_of(x)
     pairs = int(keep.sum())
     res = []
-    for name, fn in (("gather_gemm", lambda: _lib.call("gcn_sparse_gather_gemm", M, K, C, C, _lib.ptr(x), _lib.ptr(rule), _lib.ptr(W), 0, 0, _lib.ptr(out), None, st)),
+    for name, fn in (("gather_gemm", lambda: _lib.call("gcn_sparse_gather_gemm", M, K, C, C, _lib.ptr(x), _lib.ptr(rule), _lib.ptr(W), 0, 0, _lib.ptr(out), _lib.ptr(ws), st)),
                      ("wgrad", lambda: _lib.call("gcn_sparse_wgrad", M, K, C, C, _lib.ptr(x), _lib.ptr(ruleT), _lib.ptr(out), _lib.ptr(dW), st))):
         fn(); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
