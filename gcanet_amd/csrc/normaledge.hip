@@ -18,6 +18,7 @@ __global__ __launch_bounds__(256) void normal_edge_fwd_kernel(const float *__res
                                                               float *__restrict__ ymin, unsigned char *__restrict__ amax,
                                                               unsigned char *__restrict__ amin, double *__restrict__ gsum) {
   __shared__ double red[128];                 // (group, stat) partial sums of this workgroup, G <= 64
+  __shared__ float4 efs[4][256];              // per wave: the k edge features [angle, dn] of the current point
   const int lane = lane_id(), wave = wave_id();
   int tile, b;
   xcd_tile_cloud(tile, b);
@@ -47,19 +48,23 @@ __global__ __launch_bounds__(256) void normal_edge_fwd_kernel(const float *__res
         d0[q] = a0 - ni0; d1[q] = a1 - ni1; d2[q] = a2 - ni2;
         if (q * 64 + 64 >= k) break;                                  // wave-uniform
       }
+      // The k edge features go through LDS and come back as ONE broadcast read per neighbour (four v_readlane per
+      // neighbour before: the loop is VALU-bound), and the centre-normal taps, constant over the neighbours, are
+      // summed once per (point, channel).
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (q * 64 + lane < k) efs[wave][q * 64 + lane] = float4{ang[q], d0[q], d1[q], d2[q]};
+        if (q * 64 + 64 >= k) break;
+      }
+      __builtin_amdgcn_wave_barrier();
+      const float base = fmaf(w[6], ni2, fmaf(w[5], ni1, w[4] * ni0));
       float mx = -__builtin_inff(), mn = __builtin_inff();
       int ax = 0, an = 0;
       for (int j = 0; j < k; ++j) {
-        float e0 = 0.f, e1 = 0.f, e2 = 0.f, e3 = 0.f;
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if ((j >> 6) == q) {
-            e0 = readlane_f(ang[q], j & 63); e1 = readlane_f(d0[q], j & 63);
-            e2 = readlane_f(d1[q], j & 63); e3 = readlane_f(d2[q], j & 63);
-          }
-        float y = w[0] * e0;
-        y = fmaf(w[1], e1, y); y = fmaf(w[2], e2, y); y = fmaf(w[3], e3, y);
-        y = fmaf(w[4], ni0, y); y = fmaf(w[5], ni1, y); y = fmaf(w[6], ni2, y);
+        const float4 e = efs[wave][j];
+        float y = fmaf(w[0], e.x, base);
+        y = fmaf(w[1], e.y, y); y = fmaf(w[2], e.z, y); y = fmaf(w[3], e.w, y);
         if (y > mx) { mx = y; ax = j; }
         if (y < mn) { mn = y; an = j; }
         s1 += y;
