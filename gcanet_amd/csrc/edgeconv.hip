@@ -687,12 +687,13 @@ __global__ __launch_bounds__(1024) void keyedge_fwd_kernel(const float *__restri
                                                           float *__restrict__ ymax, float *__restrict__ ymin,
                                                           unsigned char *__restrict__ amax, unsigned char *__restrict__ amin,
                                                           double *__restrict__ gsum) {
-  extern __shared__ float u_lds[];  // NK * Cout
+  extern __shared__ float u_lds[];  // NK * Cout, then 16 waves x 64 (weight, key id) slots
   const int lane = lane_id(), wave = wave_id();
   const int b = blockIdx.y;
   const float *Ub = U + (long)b * NK * Cout;
   for (int i = threadIdx.x; i < NK * Cout; i += blockDim.x) u_lds[i] = Ub[i];
   __syncthreads();
+  float2 *slot = reinterpret_cast<float2 *>(u_lds + (long)NK * Cout) + wave * 64;
   const int n_lo = blockIdx.x * pts_per_block;
   const int n_hi = min(n_lo + pts_per_block, N);
   const int cpg = Cout / G;
@@ -700,27 +701,51 @@ __global__ __launch_bounds__(1024) void keyedge_fwd_kernel(const float *__restri
     const int c = c0 + lane;
     const bool cv = c < Cout;
     float s1 = 0.f, s2 = 0.f;
-    for (int n = n_lo + wave; n < n_hi; n += (int)(blockDim.x >> 6)) {
-      const long pn = (long)b * N + n;
-      const float v = V[pn * Cout + min(c, Cout - 1)];
-      // the point's k weights / key ids: one lane-parallel load each (lane = slot), read back as scalars in the
-      // loop -- loading att[pn*k+j] inside it costs a dependent global round trip per iteration (347 -> ~100 us)
-      float a_l[4];
-      int m_l[4];
+    // the point's k weights / key ids: one lane-parallel load each (lane = slot), read back in the loop -- loading
+    // att[pn*k+j] inside it costs a dependent global round trip per iteration (347 -> ~100 us); the NEXT point's
+    // operands are fetched while the current point is processed
+    const int nstep = (int)(blockDim.x >> 6);
+    float v_n = 0.f, a_n[4] = {0.f, 0.f, 0.f, 0.f};
+    int m_n[4] = {0, 0, 0, 0};
+    auto fetch = [&](int n) {
+      const long pn = (long)b * N + min(n, n_hi - 1);
+      v_n = V[pn * Cout + min(c, Cout - 1)];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int jj = min(q * 64 + lane, k - 1);
-        a_l[q] = att[pn * k + jj];
-        m_l[q] = (int)kidx[pn * k + jj];
+        a_n[q] = att[pn * k + jj];
+        m_n[q] = (int)kidx[pn * k + jj];
+        if (q * 64 + 64 >= k) break;                   // wave-uniform
       }
+    };
+    if (n_lo + wave < n_hi) fetch(n_lo + wave);
+    for (int n = n_lo + wave; n < n_hi; n += nstep) {
+      const long pn = (long)b * N + n;
+      const float v = v_n;
+      float a_l[4];
+      int m_l[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { a_l[q] = a_n[q]; m_l[q] = m_n[q]; }
+      if (n + nstep < n_hi) fetch(n + nstep);
       float mx = -__builtin_inff(), mn = __builtin_inff();
       int ax = 0, an = 0;
+      const bool via_lds = k <= 64;                    // one broadcast LDS read per neighbour instead of v_readlane pairs
+      if (via_lds) {
+        __builtin_amdgcn_wave_barrier();
+        if (lane < k) slot[lane] = float2{a_l[0], __int_as_float(m_l[0])};
+        __builtin_amdgcn_wave_barrier();
+      }
       for (int j = 0; j < k; ++j) {
         float a = 0.f;
         int m = 0;
+        if (via_lds) {
+          const float2 am = slot[j];
+          a = am.x; m = __float_as_int(am.y);
+        } else {
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if ((j >> 6) == q) { a = readlane_f(a_l[q], j & 63); m = readlane_i(m_l[q], j & 63); }
+          for (int q = 0; q < 4; ++q)
+            if ((j >> 6) == q) { a = readlane_f(a_l[q], j & 63); m = readlane_i(m_l[q], j & 63); }
+        }
         const float y = a * (u_lds[m * Cout + min(c, Cout - 1)] - v);
         if (y > mx) { mx = y; ax = j; }
         if (y < mn) { mn = y; an = j; }
@@ -1026,7 +1051,7 @@ GCN_EXPORT int gcn_keyedge_fwd(const float *att, const int64_t *kidx, const floa
   GCN_REQUIRE(att && kidx && U && V && ymax && ymin && gsum, "gcn_keyedge_fwd: null pointer");
   GCN_REQUIRE((amax == nullptr) == (amin == nullptr), "gcn_keyedge_fwd: pass both amax and amin or neither");
   GCN_REQUIRE(B >= 0 && N >= 1 && k >= 1 && k <= 255 && NK >= 1 && Cout >= 1 && G >= 1 && Cout % G == 0, "gcn_keyedge_fwd: bad shape");
-  const size_t lds = sizeof(float) * (size_t)NK * Cout;
+  const size_t lds = sizeof(float) * (size_t)NK * Cout + 16 * 64 * sizeof(float2);    // key table + per-wave (weight, id) slots
   GCN_REQUIRE(lds <= 150 * 1024, "gcn_keyedge_fwd: key table %zu B exceeds LDS", lds);
   if (B == 0) return GCN_OK;
   hipStream_t st = (hipStream_t)stream;
