@@ -388,7 +388,7 @@ static int launch_knn(const KnnArgs &a, int B, hipStream_t st) {
 typedef __attribute__((ext_vector_type(4))) float knn_f32x4;
 
 template <int CC, int TC, int KPL>   // KPL list registers per query: k <= 64 * KPL
-__global__ __launch_bounds__(256, KPL == 1 ? 4 : 3) void knn_mfma16_kernel(const float *__restrict__ x, const float *__restrict__ xxg,
+__global__ __launch_bounds__(KPL == 1 ? 512 : 256, KPL == 1 ? 4 : 3) void knn_mfma16_kernel(const float *__restrict__ x, const float *__restrict__ xxg,
                                                             int N, int k, int step, int kout,
                                                             int64_t *__restrict__ ind, float *__restrict__ val) {
   constexpr int ROWS = CC + 1;           // + one row of squared norms
@@ -404,7 +404,8 @@ __global__ __launch_bounds__(256, KPL == 1 ? 4 : 3) void knn_mfma16_kernel(const
   // C = 64) in ONE XCD's L2 when B is a multiple of 8 instead of streaming every cloud through all eight.
   const int lin = blockIdx.x + gridDim.x * blockIdx.y;
   const int b = lin % (int)gridDim.y;
-  const int q0 = ((lin / (int)gridDim.y) * 4 + wave) * 16;
+  const int NW = (int)(blockDim.x >> 6);             // waves (16 queries each) sharing a candidate tile
+  const int q0 = ((lin / (int)gridDim.y) * NW + wave) * 16;
   const float *xb = x + (long)b * CC * N;
   const float *xxb = xxg + (long)b * N;
 
@@ -430,7 +431,7 @@ __global__ __launch_bounds__(256, KPL == 1 ? 4 : 3) void knn_mfma16_kernel(const
   auto issue_tile = [&](int t, int buf) {
     int j0 = t * TC;
     if (j0 + TC > N) j0 = N - TC;                   // tail tile: shifted back (N >= TC, N % 4 == 0 by dispatch)
-    for (int p = wave; p < PIECES; p += 4) {
+    for (int p = wave; p < PIECES; p += NW) {
       const int row = p * RPP + lane / CPR;
       const int chunk = lane % CPR;
       const int sc = TC == 64 ? (chunk ^ ((row & 3) << 2)) : chunk;
@@ -543,7 +544,7 @@ static int launch_knn_mfma16(const float *x, const float *xx, int B, int N, int 
   const int lds = 2 * PIECES * 1024;
   if (k <= 64) {
     GCN_HIP(hipFuncSetAttribute((const void *)knn_mfma16_kernel<CC, TC, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    knn_mfma16_kernel<CC, TC, 1><<<dim3(cdiv(N, 64), B), 256, lds, st>>>(x, xx, N, k, step, kout, ind, val);
+    knn_mfma16_kernel<CC, TC, 1><<<dim3(cdiv(N, 128), B), 512, lds, st>>>(x, xx, N, k, step, kout, ind, val);
   } else {   // 64 < k <= 128 (the reference's default k = 80): two list registers per query
     GCN_HIP(hipFuncSetAttribute((const void *)knn_mfma16_kernel<CC, TC, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     knn_mfma16_kernel<CC, TC, 2><<<dim3(cdiv(N, 64), B), 256, lds, st>>>(x, xx, N, k, step, kout, ind, val);
