@@ -78,9 +78,9 @@ __device__ __forceinline__ int rm_swz(int row) {
 }
 template <int D>
 __device__ __forceinline__ void dma_rm_tile(const unsigned short *__restrict__ img_row0, unsigned char *lds, int wave,
-                                            int lane) {
+                                            int lane, int nwaves = 4) {
   constexpr int RB = 2 * D, CPR = RB / 16, RPP = 1024 / RB, PIECES = 64 * RB / 1024;
-  for (int p = wave; p < PIECES; p += 4) {
+  for (int p = wave; p < PIECES; p += nwaves) {
     const int row = p * RPP + lane / CPR, pos = lane % CPR;
     const int chunk = pos ^ rm_swz<D>(row);
     const unsigned char *src = reinterpret_cast<const unsigned char *>(img_row0) + (long)row * RB + chunk * 16;
@@ -91,9 +91,9 @@ __device__ __forceinline__ void dma_rm_tile(const unsigned short *__restrict__ i
 // Transposed image tile: D rows (channels) x 64 positions bf16 = 128-B rows, row stride Lp elements in global.
 template <int D>
 __device__ __forceinline__ void dma_t_tile(const unsigned short *__restrict__ img_col0, long Lp, unsigned char *lds,
-                                           int wave, int lane) {
+                                           int wave, int lane, int nwaves = 4) {
   constexpr int PIECES = D / 8;
-  for (int p = wave; p < PIECES; p += 4) {
+  for (int p = wave; p < PIECES; p += nwaves) {
     const int row = p * 8 + lane / 8, pos = lane % 8;
     const int chunk = pos ^ ((row >> 1) & 7);
     const unsigned char *src = reinterpret_cast<const unsigned char *>(img_col0 + (long)row * Lp) + chunk * 16;
@@ -115,7 +115,7 @@ __device__ __forceinline__ a_bf16x8 lds_t_frag(const unsigned char *lds, int row
 // qb (BH,Lqp,D) bf16 pre-scaled by scale*log2(e); kb (BH,Lkp,D); vt (BH,D,Lkp) permuted; mask bytes
 // (1 = masked out) (Lq,Lk) [+ bh stride]; out (BH,Lq,D) f32; lse (BH,Lq) f32 natural-log units.
 template <int D, bool MASK>
-__global__ __launch_bounds__(256, 2) void attn_fwd_mfma_kernel(const unsigned short *__restrict__ qb,
+__global__ __launch_bounds__(512, 2) void attn_fwd_mfma_kernel(const unsigned short *__restrict__ qb,
                                                                const unsigned short *__restrict__ kb,
                                                                const unsigned short *__restrict__ vt,
                                                                const unsigned char *__restrict__ mask, long mask_bh_stride,
@@ -130,7 +130,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma_kernel(const unsigned sh
   const int lr = lane & 31, lh = lane >> 5;
   int tile_, bh;
   xcd_major_tile_cloud(tile_, bh);
-  const int qrow = tile_ * 128 + wave * 32 + lr;     // < Lqp by construction
+  const int nwaves = (int)(blockDim.x >> 6);          // 4 or 8 waves (32 query rows each) share the streamed K / V tiles
+  const int qrow = tile_ * (32 * nwaves) + wave * 32 + lr;     // < Lqp by construction
   const unsigned short *kimg = kb + (long)bh * Lkp * D;
   const unsigned short *vimg = vt + (long)bh * D * Lkp;
 
@@ -149,8 +150,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma_kernel(const unsigned sh
   const int ntiles = Lkp / 64;
   auto issue = [&](int t, int buf) {
     unsigned char *base = smem + buf * 2 * KT_BYTES;
-    dma_rm_tile<D>(kimg + (long)t * 64 * D, base, wave, lane);
-    dma_t_tile<D>(vimg + (long)t * 64, Lkp, base + KT_BYTES, wave, lane);
+    dma_rm_tile<D>(kimg + (long)t * 64 * D, base, wave, lane, nwaves);
+    dma_t_tile<D>(vimg + (long)t * 64, Lkp, base + KT_BYTES, wave, lane, nwaves);
   };
   issue(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -537,11 +538,13 @@ static int run_fwd(const float *q, const float *k, const float *v, const uint8_t
   attn_pack_kernel<D><<<dim3(Lkp / 64, BH), 256, 0, st>>>(v, Lk, Lkp, 1.f, nullptr, vt);
   const int lds = 2 * 2 * 64 * D * 2;
   const long ms = mask_per_bh ? (long)Lq * Lk : 0;
-  const dim3 grid(Lqp / 128, BH);
+  // eight waves (256 query rows) per streamed tile when the padded length allows it: half the LDS-DMA work per row
+  const int threads = (Lqp % 256 == 0) ? 512 : 256;
+  const dim3 grid(Lqp / (threads / 2), BH);
   if (mask)
-    attn_fwd_mfma_kernel<D, true><<<grid, 256, lds, st>>>(qb, kb, vt, mask, ms, Lq, Lk, Lqp, Lkp, out, lse);
+    attn_fwd_mfma_kernel<D, true><<<grid, threads, lds, st>>>(qb, kb, vt, mask, ms, Lq, Lk, Lqp, Lkp, out, lse);
   else
-    attn_fwd_mfma_kernel<D, false><<<grid, 256, lds, st>>>(qb, kb, vt, nullptr, 0, Lq, Lk, Lqp, Lkp, out, lse);
+    attn_fwd_mfma_kernel<D, false><<<grid, threads, lds, st>>>(qb, kb, vt, nullptr, 0, Lq, Lk, Lqp, Lkp, out, lse);
   return check_launch("attn_fwd_mfma_kernel");
 }
 
