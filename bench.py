@@ -20,6 +20,62 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="clouds per GPU (BASELINE config 2)")
+    ap.add_argument("--points", type=int, default=8192)
+    ap.add_argument("--k", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-cpu", action="store_true",
+                    help="launcher/collective rehearsal on a box WITHOUT a GPU: gloo ranks, a tiny torch stand-in "
+                         "module instead of the HIP hot path; the JSON line is marked invalid as a measurement")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="rehearsal only: allow more ranks than GPUs (ranks share devices)")
+    return ap.parse_args(argv)
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` outside torchrun: start N ranks (one per GPU) as CHILD processes of a parent that has
+    not touched the GPU (nothing here imports torch), relay rank 0's JSON line, exit non-zero if any rank failed.
+    The reference's multi-device entry is single-process nn.DataParallel (trainer_new.py:94-96)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line)
+    sys.stdout.flush()
+    if proc.returncode != 0 or line is None:
+        print("bench.py: %d-rank launch failed (rc %d, json %s)" % (args.gpus, proc.returncode, line is not None),
+              file=sys.stderr)
+        sys.exit(proc.returncode or 1)
+    sys.exit(0)
+
+
+if __name__ == "__main__" and "WORLD_SIZE" not in os.environ:
+    _a = parse_args()
+    if _a.gpus > 1:
+        launch_ranks(_a)          # never returns
+
 import torch  # noqa: E402
 
 PEAK_TFLOPS = {"bf16_mfma": 2500.0, "f32_mfma": 157.3}   # MI355X_MICROARCH.md dense peaks
@@ -126,20 +182,77 @@ def grouping_times(model, pts, nrm, reps=5):
     return res
 
 
+def rehearse_cpu(args):
+    """Launcher + FlatGradDP + JSON-contract rehearsal over gloo on a box without a GPU (tests/test_parallel_cpu.py).
+    The module is a tiny torch stand-in with the hot path's segment structure (an upstream "encoder" whose gradients
+    arrive last + downstream "heads"); it is NOT the product path and the line says so."""
+    import torch.nn as nn
+    from gcanet_amd import parallel
+    rank, local, world = parallel.init_distributed("gloo")
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.manual_seed(0)
+    enc = nn.Sequential(nn.Linear(6, 32), nn.ReLU())
+    heads = nn.Sequential(nn.Linear(32, 64), nn.ReLU(), nn.Linear(64, 10))
+    model = nn.Sequential(enc, heads)
+    dp = parallel.FlatGradDP(model, world, late=enc.parameters())
+    dp.sync_params()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    B, N = args.batch, args.points
+    pts, nrm = synth_clouds(range(rank * B, rank * B + B), N, "cpu")
+    x = torch.cat([pts, nrm], -1)
+
+    def step():
+        dp.zero_grad()
+        loss = model(x).pow(2).mean()
+        loss.backward()
+        dp.all_reduce_grads()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        torch.distributed.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+        flat = dp.flat.clone()
+        torch.distributed.all_reduce(flat, op=torch.distributed.ReduceOp.MAX)
+        assert torch.equal(flat, dp.flat), "replicas hold different reduced gradients"
+    if rank == 0:
+        print(json.dumps({
+            "metric": "point-clouds/sec fwd+bwd (N=%d,k=%d)" % (N, args.k), "value": round(world * B * args.steps / dt, 3),
+            "unit": "clouds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "REHEARSAL (cpu stand-in module, gloo) -- not a measurement",
+            "config": {"workload": "launcher rehearsal", "global_batch": world * B, "points": N, "k": args.k,
+                       "parallelism": "dp%d" % world, "allreduce_overlapped_steps": dp.early_started_in_backward}}))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=8, help="clouds per GPU (BASELINE config 2)")
-    ap.add_argument("--points", type=int, default=8192)
-    ap.add_argument("--k", type=int, default=64)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.rehearse_cpu:
+        return rehearse_cpu(args)
 
     from gcanet_amd import _lib, dgcnn, parallel
     rank, local, world = parallel.init_distributed()
-    local = local % torch.cuda.device_count()      # one rank per GPU; the modulo only matters when ranks are over-subscribed in a rehearsal
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
+    ndev = torch.cuda.device_count()
+    if world > ndev and not args.oversubscribe:
+        raise SystemExit("bench.py: %d ranks but only %d GPUs visible (one rank per GPU; --oversubscribe only for a "
+                         "rehearsal)" % (world, ndev))
+    local = local % ndev
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     _lib.lib()  # fail loudly if the HIP library is missing

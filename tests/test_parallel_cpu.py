@@ -109,3 +109,40 @@ def test_shard_range_covers_everything():
             spans = [shard_range(n, r, w) for r in range(w)]
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+
+
+def _run_bench(*extra):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                           "--batch", "2", "--points", "64"] + list(extra), env=env, stdout=subprocess.PIPE,
+                          stderr=subprocess.PIPE, text=True, timeout=300)
+
+
+def test_bench_gpus2_launches_two_ranks():
+    """`python bench.py --gpus 2` (no torchrun around it) must start two ranks itself, exchange gradients (early
+    segment from inside backward) and print ONE JSON line with n_gpus == 2 (--gpus was a no-op).  No GPU
+    here: --rehearse-cpu swaps the HIP hot path for a tiny torch stand-in; launcher, FlatGradDP, barrier/max timing
+    and the JSON contract are the real ones."""
+    import json
+    r = _run_bench("--rehearse-cpu")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 4 and j["config"]["parallelism"] == "dp2"
+    assert j["config"]["allreduce_overlapped_steps"] > 0
+    assert j["steps"] == 3 and j["warmup"] == 1 and j["scaling"] == "weak"
+
+
+def test_bench_gpus2_fails_loudly_without_gpus():
+    """Without the rehearsal flag the product path runs: on a box with fewer GPUs than ranks every rank refuses,
+    and the parent exits non-zero instead of reporting an N=1 number."""
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("two GPUs present")
+    r = _run_bench()
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
