@@ -25,11 +25,27 @@ FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=h
          "-Wall", "-Wno-unused-function", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
 
+STAMP = os.path.join(OBJDIR, "flags.stamp")
+
+
+def _stamp_text():
+    return " ".join([HIPCC] + FLAGS)
+
+
 def _newer(target, deps):
     if not os.path.exists(target):
         return False
     t = os.path.getmtime(target)
     return all(os.path.getmtime(d) <= t for d in deps)
+
+
+def stale():
+    """True when libgcanet_hip.so is missing or older than any source/header (or was built with other flags)."""
+    deps = glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h")) + \
+        glob.glob(os.path.join(ROOT, "include", "*.h"))
+    if not _newer(SO, deps):
+        return True
+    return not os.path.exists(STAMP) or open(STAMP).read() != _stamp_text()
 
 
 def _compile(src, force):
@@ -43,6 +59,8 @@ def _compile(src, force):
 
 def build(force=False, verbose=True):
     os.makedirs(OBJDIR, exist_ok=True)
+    if not os.path.exists(STAMP) or open(STAMP).read() != _stamp_text():
+        force = True                      # compiler or flags changed: every object is stale
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     with cf.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
         res = list(ex.map(lambda s: _compile(s, force), srcs))
@@ -53,6 +71,8 @@ def build(force=False, verbose=True):
             print("linked", SO)
     elif verbose:
         print("up to date:", SO)
+    with open(STAMP, "w") as f:
+        f.write(_stamp_text())
     return SO
 
 

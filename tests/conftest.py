@@ -29,9 +29,12 @@ def dev():
     import torch
     if not torch.cuda.is_available():
         pytest.skip("no GPU in this container")
-    from gcanet_amd import _lib
-    if not os.path.exists(_lib.SO_PATH):      # a source-only checkout: compile the HIP library (a build step,
-        from gcanet_amd import build          # not a fallback -- there is no other implementation to fall back to)
+    from gcanet_amd import _lib, build
+    # mtime-incremental (no-op when current): a .hip edit can never be tested against a stale library.  A build step,
+    # not a fallback -- there is no other implementation to fall back to.
+    if os.path.exists(build.HIPCC):
         build.build(verbose=False)
+    elif build.stale():
+        pytest.fail("libgcanet_hip.so is older than its sources and hipcc is not available to rebuild it")
     _lib.lib()  # raises if libgcanet_hip.so is absent -> loud failure, no silent fallback
     return torch.device("cuda:0")
