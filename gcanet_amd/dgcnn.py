@@ -520,18 +520,24 @@ class DGCNNEncoderGn(nn.Module):
         self.bnmlp1 = nn.GroupNorm(8, 1024)
         self.last_idx = None
 
-    def forward_pm(self, x_cm, x_pm=None):
+    def forward_pm(self, x_cm, x_pm=None, idxs=None):
         """Point-major core: x_cm (B,Cin,N) feeds the kNN, x_pm (B,N,Cin) the row gathers.
-        Returns (x_features (B,N,256) f32, x4 (B,1024))."""
+        Returns (x_features (B,N,256) f32, x4 (B,1024)).  idxs: optional (idx1, idx2, idx3) neighbour lists to use
+        instead of searching (parity tests isolate the feature math from near-tie flips this way)."""
         from .layers import conv1x1, group_norm_relu_max
         k = self.k
         if x_pm is None:
             x_pm = x_cm.transpose(1, 2).contiguous()
-        idx1 = knn_points_normals(x_cm, k, k) if self.mode == 5 else knn(x_cm, k, k)
+        if idxs is not None:
+            idx1, idx2, idx3 = [i.contiguous() for i in idxs]
+        else:
+            idx1 = knn_points_normals(x_cm, k, k) if self.mode == 5 else knn(x_cm, k, k)
         x1, x1_cm = edge_conv_pm(x_pm, idx1, self.conv1._modules["0"].weight, self.bn1, self.dtype)
-        idx2 = knn(x1_cm, k, k)
+        if idxs is None:
+            idx2 = knn(x1_cm, k, k)
         x2, x2_cm = edge_conv_pm(x1, idx2, self.conv2._modules["0"].weight, self.bn2, self.dtype)
-        idx3 = knn(x2_cm, k, k)
+        if idxs is None:
+            idx3 = knn(x2_cm, k, k)
         x3, _ = edge_conv_pm(x2, idx3, self.conv3._modules["0"].weight, self.bn3, self.dtype, want_cm=False)
         self.last_idx = (idx1, idx2, idx3)
         x_features = torch.cat((x1, x2, x3), dim=2)                            # (B,N,256)
@@ -641,13 +647,17 @@ class OFFSET_PRED_MODULE(nn.Module):
         self.attention = KPAM(nn_nb)
         self.mlp_offset = nn.Conv1d(256, 3, 1)
 
-    def forward(self, points, feature, instance_feature, pm_out=False):
+    def forward(self, points, feature, instance_feature, pm_out=False, topk_idx=None):
         """points (B,N,3), feature (B,N,128), instance_feature (B,N,64) -> offsets (B,3,N) [(B,N,3) if pm_out]."""
         B, N, _ = points.shape
         sub = key_point_indices(N, self.sampling_ratio, points.device)
         key_pts, key_feat, key_emb = points[:, sub], feature[:, sub], instance_feature[:, sub]
         dist = cos_dist(instance_feature, key_emb)                             # (B,N,120)
-        topk_dist, topk_idx = topk_rows(dist, self.k)                          # once, not twice (M4:421-422)
+        if topk_idx is None:
+            topk_dist, topk_idx = topk_rows(dist, self.k)                      # once, not twice (M4:421-422)
+        else:                                                                  # forced selection (parity tests)
+            topk_dist = torch.gather(dist, 2, topk_idx)
+        self.last_topk_idx = topk_idx
         att = self.attention.weights(topk_dist)                                # (B,N,k)
         W = self.conv1[0].weight.flatten(1)                                    # (128,131) view of the 1x1 kernel
         Wf, Wp = W[:, :128], W[:, 128:]
@@ -697,7 +707,7 @@ class PrimitivesEmbeddingDGCNGn(nn.Module):
     def _unit(v):
         return v / (torch.norm(v, dim=-1, keepdim=True) + 1e-12)
 
-    def forward(self, points, normals):
+    def forward(self, points, normals, idxs=None, topk_idx=None):
         """points, normals (B,N,3) -> dict(type_per_point (B,N,P), param_per_point (B,N,22), semantic_scores
         (B*N,P), pt_offsets (B*N,3), output_feats (B,N,emb)) -- the reference's shapes (M4:634-747).
         Activations are point-major (B,N,C) end to end; the reference's (B,C,N) Conv1d tensors are the same
@@ -707,7 +717,7 @@ class PrimitivesEmbeddingDGCNGn(nn.Module):
         B, N, _ = points.shape
         pts = torch.cat([points, normals], dim=-1).contiguous() if self.mode == 5 else points.contiguous()   # (B,N,6)
         pts_cm = pts.transpose(1, 2).contiguous()
-        xf, x4 = self.encoder.forward_pm(pts_cm, pts)
+        xf, x4 = self.encoder.forward_pm(pts_cm, pts, idxs=idxs)
         w1 = self.conv1.weight.flatten(1)
         h = linear_pm(xf, w1[:, 1024:]) + F.linear(x4, w1[:, :1024], self.conv1.bias).unsqueeze(1)
         x = group_norm_relu(h, self.bn1)
@@ -742,7 +752,8 @@ class PrimitivesEmbeddingDGCNGn(nn.Module):
         feat_plus = torch.cat([x_all, pts.to(x_all.dtype)], dim=2)                             # (B,N,262)
         feat_plus = group_norm_relu(conv1x1(feat_plus, self.conv3), self.bn3)                  # (B,N,128)
         semantic_scores = type_forgroup.reshape(-1, type_forgroup.shape[-1])
-        pt_offsets = self.offset_pred_block(pts[:, :, 0:3], feat_plus.float(), output_feats, pm_out=True)
+        pt_offsets = self.offset_pred_block(pts[:, :, 0:3], feat_plus.float(), output_feats, pm_out=True,
+                                            topk_idx=topk_idx)
         pt_offsets = pt_offsets.reshape(-1, 3)
         return dict(type_per_point=type_per_point, param_per_point=param_per_point,
                     semantic_scores=semantic_scores, pt_offsets=pt_offsets, output_feats=output_feats)

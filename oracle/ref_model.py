@@ -141,7 +141,7 @@ def kpam(x, att, w1, w2):
     return a * x
 
 
-def offset_pred_module(points, feature, emb, sd, nn_nb=30, n_keys=120, prefix=""):
+def offset_pred_module(points, feature, emb, sd, nn_nb=30, n_keys=120, prefix="", topk_idx=None, info=None):
     """OFFSET_PRED_MODULE.forward (M4:398-452).  points (B,N,3), feature (B,N,128), emb (B,N,64)
     -> offsets (B,3,N).  Layout quirk kept: the conv runs on (B,131,k,N) and the max is over dim -2."""
     g = lambda n: torch.as_tensor(sd[prefix + n])
@@ -149,7 +149,12 @@ def offset_pred_module(points, feature, emb, sd, nn_nb=30, n_keys=120, prefix=""
     sub = key_point_indices(N, n_keys)
     key_pts, key_feat, key_emb = points[:, sub], feature[:, sub], emb[:, sub]
     dist = cos_dist(emb, key_emb)                                  # (B,N,120)
-    topk_dist, topk_idx = torch.topk(dist, nn_nb, dim=2, largest=True)
+    if topk_idx is None:
+        topk_dist, topk_idx = torch.topk(dist, nn_nb, dim=2, largest=True)
+    else:       # a caller-chosen selection (parity tests feed the device's, after checking it against `dist`)
+        topk_dist = torch.gather(dist, 2, topk_idx)
+    if info is not None:
+        info["cos_dist"] = dist
     bi = torch.arange(B).view(B, 1, 1)
     f = torch.cat([key_feat[bi, topk_idx], key_pts[bi, topk_idx] - points.unsqueeze(2)], 3)   # (B,N,k,131)
     f = kpam(f, topk_dist, g("attention.conv1.0.weight")[:, :, 0], g("attention.conv1.2.weight")[:, :, 0])
@@ -287,7 +292,7 @@ def knn_torch(x, k, metric=0):
     return torch.cat(out, 0)
 
 
-def hot_path(sd, points, normals, k, knn_fn=None, idxs=None):
+def hot_path(sd, points, normals, k, knn_fn=None, idxs=None, topk_idx=None, info=None):
     """forward_train of PrimitivesEmbeddingDGCNGn up to pt_offsets (M4:634-747), functional, fp32.
     sd: state dict with the reference's parameter names.  knn_fn(x, k, metric) -> idx."""
     g = lambda n: sd[n]
@@ -328,7 +333,9 @@ def hot_path(sd, points, normals, k, knn_fn=None, idxs=None):
     output_feats = F.conv1d(x, g("mlp_seg_prob2.weight"), g("mlp_seg_prob2.bias")).permute(0, 2, 1)
     fp = cgr(torch.cat([x_all, pts], 1), "conv3", "bn3", 4).permute(0, 2, 1)
     off_sd = {kk[len("offset_pred_block."):]: v for kk, v in sd.items() if kk.startswith("offset_pred_block.")}
-    off = offset_pred_module(pts[:, 0:3].permute(0, 2, 1), fp, output_feats, off_sd)
+    off = offset_pred_module(pts[:, 0:3].permute(0, 2, 1), fp, output_feats, off_sd, topk_idx=topk_idx, info=info)
+    if info is not None:
+        info.update(x1=x1, x2=x2, x3=x3, x_all=x_all)
     return dict(type_per_point=type_per_point, param_per_point=param,
                 semantic_scores=type_forgroup.reshape(-1, type_forgroup.shape[-1]),
                 pt_offsets=off.permute(0, 2, 1).reshape(-1, 3), output_feats=output_feats), used

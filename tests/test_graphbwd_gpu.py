@@ -14,11 +14,9 @@ def _graph(B, N, k, C, dev, seed):
     return x, idx
 
 
-@pytest.mark.parametrize("B,N,k,C", [(2, 256, 16, 64), (1, 1000, 30, 6), (3, 333, 7, 128), (2, 2048, 64, 64), (1, 64, 80, 13)])
+@pytest.mark.parametrize("B,N,k,C", [(2, 256, 16, 64), (1, 1000, 30, 6), (3, 333, 7, 128), (2, 2048, 64, 64), (1, 96, 80, 13)])
 def test_reverse_and_neighbor_sum(dev, B, N, k, C):
     from gcanet_amd import _lib
-    if k > N:
-        pytest.skip("k > N")
     x, idx = _graph(B, N, k, C, dev, B * 100 + N + k + C)
     x[0, 0] *= 1e3                                    # wide dynamic range inside one tensor
     r = torch.empty_like(x)

@@ -41,7 +41,7 @@ def test_encoder_matches_reference_golden(dev, golden, mode, cin):
         eq &= (enc.last_idx[li].cpu().numpy() == golden[p + key]).all(-1)
     assert eq.mean() > 0.9
     d = np.abs(xf - ref).transpose(0, 2, 1)[eq]
-    assert d.max() < 2e-4, d.max()
+    assert d.max() < 1e-4, d.max()
 
 
 def test_offset_module_matches_reference_golden(dev, golden):
@@ -54,9 +54,9 @@ def test_offset_module_matches_reference_golden(dev, golden):
     o = off(pts, feat, emb)
     np.testing.assert_allclose(o.detach().cpu().numpy(), g["off_out"], rtol=1e-4, atol=1e-4)
     (o * torch.from_numpy(g["off_gout"]).to(dev)).sum().backward()
-    np.testing.assert_allclose(pts.grad.cpu().numpy(), g["off_dpoints"], rtol=1e-3, atol=2e-4)
-    np.testing.assert_allclose(feat.grad.cpu().numpy(), g["off_dfeat"], rtol=1e-3, atol=2e-4)
-    np.testing.assert_allclose(emb.grad.cpu().numpy(), g["off_demb"], rtol=1e-3, atol=3e-4)
+    for got, key in ((pts.grad, "off_dpoints"), (feat.grad, "off_dfeat"), (emb.grad, "off_demb")):
+        ref = g[key]                                   # gradients are sums over N (and k) terms: scale-relative atol
+        np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max(), err_msg=key)
 
 
 def test_hot_path_model_fwd_bwd_runs_and_is_finite(dev):
@@ -96,16 +96,17 @@ def test_hot_path_model_matches_cpu_oracle(dev):
     with torch.no_grad():
         out = m(pts.to(dev), nrm.to(dev))
         idxs = [i.cpu() for i in m.encoder.last_idx]
-        ref, _ = R.hot_path(sd, pts, nrm, 16, idxs=idxs)
+        sel = m.offset_pred_block.last_topk_idx.cpu()
+        info = {}
+        ref, _ = R.hot_path(sd, pts, nrm, 16, idxs=idxs, topk_idx=sel, info=info)
+    # the offset module takes a top-30 of 120 cosine similarities: the oracle is handed the device's selection after it
+    # has been checked against the oracle's own similarity matrix (every pick within 2e-6 of the oracle's 30th largest,
+    # no duplicates), so every row of every output compares at the north star's 1e-4 -- no tie allowance
+    from test_fullsize_gpu import check_topk_selection
+    check_topk_selection(info["cos_dist"], sel)
     for k_ in ref:
         a, b = out[k_].cpu().numpy(), ref[k_].numpy()
-        if k_ == "pt_offsets":
-            # the offset module takes a top-30 of 120 cosine similarities: a near-tie flipped by fp32
-            # summation order swaps one key point for a point -> allow a handful of such rows
-            ok = np.isclose(a, b, rtol=1e-3, atol=2e-4).all(-1)
-            assert ok.mean() > 0.97, ok.mean()
-            continue
-        np.testing.assert_allclose(a, b, rtol=1e-3, atol=1e-4 * max(1.0, np.abs(b).max()), err_msg=k_)
+        np.testing.assert_allclose(a, b, rtol=1e-4, atol=1e-4, err_msg=k_)
 
 
 def test_full_forward_train_runs_end_to_end(dev):
