@@ -53,8 +53,16 @@ def _compile(src, force):
     deps = [src] + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
     if not force and _newer(obj, deps):
         return obj, False
-    subprocess.check_call([HIPCC] + FLAGS + ["-c", src, "-o", obj])
+    subprocess.check_call([HIPCC] + FLAGS + _file_flags(src) + ["-c", src, "-o", obj])
     return obj, True
+
+
+def _file_flags(src):
+    """Extra compiler flags a source asks for in a `// hipcc-flags: ...` line of its header comment."""
+    for line in open(src).read(4096).splitlines():
+        if line.startswith("// hipcc-flags:"):
+            return line.split(":", 1)[1].split()
+    return []
 
 
 def build(force=False, verbose=True):

@@ -26,6 +26,7 @@
 //               t+1 is gathered by global_load_lds_dwordx4 while tile t is on the MFMAs
 //   centre rows x_i are staged once per point and read as LDS broadcasts.
 #include "common.h"
+#include "edgeconv_fwd.h"
 
 namespace gcn {
 
@@ -922,7 +923,7 @@ static int launch_fwd_bf16(EcArgs &a, bool with_arg, hipStream_t st) {
 using namespace gcn;
 
 static int padded_channels(int C) {
-  int cp = 8;
+  int cp = 16;                                     // one MFMA k-step (16 bf16) per row at least
   while (cp < C) cp <<= 1;
   return cp;
 }
@@ -947,9 +948,10 @@ GCN_EXPORT int gcn_edgeconv_pack_w(const float *w, int Cout, int C, void *wp_bf1
 }
 
 GCN_EXPORT int gcn_edgeconv_fwd(const void *x_pm, const void *w, const int64_t *idx, int dtype, int B, int N, int NX,
-                                int C, int k, int Cout, int G, float *ymax, float *ymin, uint8_t *amax, uint8_t *amin,
-                                double *gsum, const float *gamma_route, void *stream) {
+                                int C, int k, int Cout, int G, const float *q, float *ymax, float *ymin, uint8_t *amax,
+                                uint8_t *amin, double *gsum, const float *gamma_route, void *stream) {
   GCN_REQUIRE(x_pm && w && idx && ymax && gsum, "gcn_edgeconv_fwd: null pointer");
+  GCN_REQUIRE(dtype == 1 || q == nullptr, "gcn_edgeconv_fwd: q belongs to the bf16 path (dtype 1) only");
   GCN_REQUIRE(gamma_route || ymin, "gcn_edgeconv_fwd: ymin may be NULL only in routed mode (gamma_route given)");
   GCN_REQUIRE(gamma_route || (amax == nullptr) == (amin == nullptr), "gcn_edgeconv_fwd: pass both amax and amin or neither");
   GCN_REQUIRE(dtype == 0 || dtype == 1, "gcn_edgeconv_fwd: dtype must be 0 (f32) or 1 (bf16)");
@@ -975,11 +977,19 @@ GCN_EXPORT int gcn_edgeconv_fwd(const void *x_pm, const void *w, const int64_t *
   a.B = B; a.N = N; a.NX = NX; a.k = k; a.kp = (k + 31) / 32 * 32; a.Cout = Cout; a.G = G;
   a.ymax = ymax; a.ymin = ymin; a.amax = amax; a.amin = amin; a.gsum = gsum; a.gamma_route = gamma_route;
   const bool wa = amax != nullptr;
+  if (a.kp <= 128) {      // the normal case: x_j half on the matrix cores, centre term q precomputed per point
+    EcqArgs e{};
+    e.x = a.x; e.wp = a.wp; e.idx = idx; e.q = q;
+    e.B = B; e.N = N; e.NX = NX; e.k = k; e.Cout = Cout; e.G = G;
+    e.ymax = ymax; e.ymin = ymin; e.amax = amax; e.amin = amin; e.gsum = gsum; e.gamma_route = gamma_route;
+    return launch_edgeconv_fwd_q(e, Cp, wa, st);
+  }
+  // 128 < k <= 255: two 128-row groups per point, full [x_j ; x_i] rows (q is not needed)
   const int ks = Cp / 8;
 #define EC_CASE(KS, CWV) \
-  if (ks == KS && Cout == CWV * 32) return a.kp <= 128 ? launch_fwd_bf16<KS, CWV, 1>(a, wa, st) : launch_fwd_bf16<KS, CWV, 2>(a, wa, st);
-  EC_CASE(1, 2) EC_CASE(2, 2) EC_CASE(4, 2) EC_CASE(8, 2) EC_CASE(16, 2)
-  EC_CASE(1, 4) EC_CASE(2, 4) EC_CASE(4, 4) EC_CASE(8, 4) EC_CASE(16, 4)
+  if (ks == KS && Cout == CWV * 32) return launch_fwd_bf16<KS, CWV, 2>(a, wa, st);
+  EC_CASE(2, 2) EC_CASE(4, 2) EC_CASE(8, 2) EC_CASE(16, 2)
+  EC_CASE(2, 4) EC_CASE(4, 4) EC_CASE(8, 4) EC_CASE(16, 4)
 #undef EC_CASE
   set_error("gcn_edgeconv_fwd(bf16): unsupported configuration");
   return GCN_EINVAL;

@@ -52,6 +52,16 @@ def _run(name, like, *args, tag=None):
         _lib.call(name, *args, _lib.stream_of(like), tag=tag)
 
 
+def _center_term(x_bf, wp, rows, C, Cout, k):
+    """q (rows, Cout) f32 = x . (W2 - W1)^T, the per-point half of the EdgeConv contraction (csrc/edgeconv_fwd.hip);
+    None for k > 128, where the kernel contracts full [x_j ; x_i] rows."""
+    if k > 128:
+        return None
+    q = torch.empty(rows, Cout, dtype=torch.float32, device=x_bf.device)
+    _run("gcn_edgeconv_center", x_bf, _lib.ptr(x_bf), _lib.ptr(wp), rows, C, Cout, _lib.ptr(q))
+    return q
+
+
 def edgeconv_forward_raw(x, idx, weight, gamma, beta, groups, dtype="bf16", eps=1e-5, slope=0.2, need_arg=False):
     """Low-level fused forward (csrc/edgeconv.hip).  x (B,C,N) f32, idx (B,N,k) int64,
     weight (Cout,2C) f32 [the Conv2d 1x1 weight of M4:463-465], gamma/beta (Cout).
@@ -79,13 +89,14 @@ def edgeconv_forward_raw(x, idx, weight, gamma, beta, groups, dtype="bf16", eps=
         wp = torch.empty(Cout, 2 * Cp, dtype=torch.bfloat16, device=dev)
         _run("gcn_edgeconv_pack_x", x, _lib.ptr(x), B, C, N, _lib.ptr(x_bf), _lib.ptr(x_pm))
         _run("gcn_edgeconv_pack_w", x, _lib.ptr(w), Cout, C, _lib.ptr(wp))
+        q = _center_term(x_bf, wp, B * N, C, Cout, k)
         _run("gcn_edgeconv_fwd", x, _lib.ptr(x_bf), _lib.ptr(wp), _lib.ptr(idx), 1, B, N, N, C, k, Cout, groups,
-             _lib.ptr(ymax), _lib.ptr(ymin), _lib.ptr(amax), _lib.ptr(amin), _lib.ptr(gsum), None,
+             _lib.ptr(q), _lib.ptr(ymax), _lib.ptr(ymin), _lib.ptr(amax), _lib.ptr(amin), _lib.ptr(gsum), None,
              tag="edgeconv_fwd[B=%d,N=%d,k=%d,C=%d,Cout=%d]" % (B, N, k, C, Cout))
     elif dtype == "f32":
         _run("gcn_edgeconv_pack_x", x, _lib.ptr(x), B, C, N, None, _lib.ptr(x_pm))
         _run("gcn_edgeconv_fwd", x, _lib.ptr(x_pm), _lib.ptr(w), _lib.ptr(idx), 0, B, N, N, C, k, Cout, groups,
-             _lib.ptr(ymax), _lib.ptr(ymin), _lib.ptr(amax), _lib.ptr(amin), _lib.ptr(gsum), None)
+             None, _lib.ptr(ymax), _lib.ptr(ymin), _lib.ptr(amax), _lib.ptr(amin), _lib.ptr(gsum), None)
     else:
         raise ValueError("dtype must be 'bf16' or 'f32'")
     out = torch.empty(B, Cout, N, **f32)
@@ -253,11 +264,11 @@ class GroupedBlockFunction(torch.autograd.Function):
             _run("gcn_edgeconv_pack_x", ef, _lib.ptr(rows), B, F, N * k, _lib.ptr(x_bf), None)
             _run("gcn_edgeconv_pack_w", ef, _lib.ptr(w2.contiguous()), Cout, F, _lib.ptr(wp))   # W' = [W | 0]
             _run("gcn_edgeconv_fwd", ef, _lib.ptr(x_bf), _lib.ptr(wp), _lib.ptr(ident), 1, B, N, N * k, F, k, Cout,
-                 groups, _lib.ptr(ymax), _lib.ptr(ymin), _lib.ptr(amax), _lib.ptr(amin), _lib.ptr(gsum), None)
+                 groups, None, _lib.ptr(ymax), _lib.ptr(ymin), _lib.ptr(amax), _lib.ptr(amin), _lib.ptr(gsum), None)
         else:   # exact path: W.(x_j - x_i) + W.x_i
             flat = ef.reshape(B, N * k, F)
             _run("gcn_edgeconv_fwd", ef, _lib.ptr(flat), _lib.ptr(w2.contiguous()), _lib.ptr(ident), 0, B, N, N * k, F,
-                 k, Cout, groups, _lib.ptr(ymax), _lib.ptr(ymin), _lib.ptr(amax), _lib.ptr(amin), _lib.ptr(gsum), None)
+                 k, Cout, groups, None, _lib.ptr(ymax), _lib.ptr(ymin), _lib.ptr(amax), _lib.ptr(amin), _lib.ptr(gsum), None)
         out_cm, out_pm, mean_rstd = _finish(ymax, ymin, gsum, gamma.float().contiguous(), beta.float().contiguous(),
                                             B, N, k, Cout, groups, eps, slope, not pm_out, pm_out)
         ctx.save_for_backward(ef, weight, gamma, beta, ymax, ymin, amax, amin, mean_rstd)
@@ -799,12 +810,13 @@ class EdgeConvPMFunction(torch.autograd.Function):
             wp = torch.empty(Cout, 2 * Cp, dtype=torch.bfloat16, device=dev)
             _run("gcn_cast_pad_bf16", x, _lib.ptr(x), B * N, C, _lib.ptr(x_bf))
             _run("gcn_edgeconv_pack_w", x, _lib.ptr(w), Cout, C, _lib.ptr(wp))
+            q = _center_term(x_bf, wp, B * N, C, Cout, k)
             _run("gcn_edgeconv_fwd", x, _lib.ptr(x_bf), _lib.ptr(wp), _lib.ptr(idx), 1, B, N, N, C, k, Cout, groups,
-                 _lib.ptr(ymax), None, _lib.ptr(amax), None, _lib.ptr(gsum), _lib.ptr(ga),
+                 _lib.ptr(q), _lib.ptr(ymax), None, _lib.ptr(amax), None, _lib.ptr(gsum), _lib.ptr(ga),
                  tag="edgeconv_fwd[B=%d,N=%d,k=%d,C=%d,Cout=%d]" % (B, N, k, C, Cout))
         else:
             _run("gcn_edgeconv_fwd", x, _lib.ptr(x), _lib.ptr(w), _lib.ptr(idx), 0, B, N, N, C, k, Cout, groups,
-                 _lib.ptr(ymax), None, _lib.ptr(amax), None, _lib.ptr(gsum), _lib.ptr(ga))
+                 None, _lib.ptr(ymax), None, _lib.ptr(amax), None, _lib.ptr(gsum), _lib.ptr(ga))
         out_cm, out_pm, mean_rstd = _finish(ymax, ymin, gsum, ga, be, B, N, k, Cout, groups, eps, slope, want_cm, True)
         empty = torch.empty(0, device=dev)
         ctx.save_for_backward(x, idx, w, ga, be, ymax, empty, amax, empty, mean_rstd)

@@ -289,7 +289,7 @@ int gcn_hierarchical_aggregation_host(const int32_t *semantic_label_host, const 
  * operands, f32 accumulate) or as an exact k-ordered f32 fmaf chain (dtype 0, parity path).
  * Operands are point-major so that one neighbour is one contiguous row:
  *   dtype 1: x_pm (B,N,Cp) bf16 and w = W' (Cout,2Cp) bf16 from gcn_edgeconv_pack_x / _pack_w,
- *            Cp = gcn_edgeconv_padded_channels(C); Cout in {64,128}, C <= 128, (Cout/G) % 32 == 0
+ *            Cp = gcn_edgeconv_padded_channels(C) (power of two >= 16); Cout in {64,128}, C <= 128, (Cout/G) % 32 == 0
  *   dtype 0: x_pm (B,N,C) f32, w (Cout,2C) f32 (the reference's own Conv2d weight)
  *   idx    (B,N,k) int64 neighbour ids within the cloud (what knn()/topk returns), 1 <= k <= 255;
  *          ids index the NX rows per cloud of x_pm (NX == N for EdgeConv; a generic grouped block
@@ -308,8 +308,17 @@ int gcn_edgeconv_pack_x(const float *x_cm, int B, int C, int N, void *x_pm_bf16,
                         void *stream);
 int gcn_edgeconv_pack_w(const float *w, int Cout, int C, void *wp_bf16, void *stream);
 int gcn_edgeconv_fwd(const void *x_pm, const void *w, const int64_t *idx, int dtype, int B, int N,
-                     int NX, int C, int k, int Cout, int G, float *ymax, float *ymin, uint8_t *amax,
-                     uint8_t *amin, double *gsum, const float *gamma_route, void *stream);
+                     int NX, int C, int k, int Cout, int G, const float *q, float *ymax, float *ymin,
+                     uint8_t *amax, uint8_t *amin, double *gsum, const float *gamma_route, void *stream);
+
+/* Centre term of the grouped contraction (dtype 1): y[n,j] = W1.x_j + (W2 - W1).x_n, and the second summand is the
+ * same for the k rows of point n.  q (rows, Cout) f32 = x_pm_bf16 (rows, Cp) . (W2 - W1)^T from the [W1 | W2 - W1]
+ * image of gcn_edgeconv_pack_w -- a per-point (rows x C x Cout) MFMA GEMM, k-fold cheaper than the grouped part.
+ * gcn_edgeconv_fwd takes it as `q` (NULL = no centre term, e.g. a generic grouped block with W' = [W | 0]) and adds it
+ * after the reduction over k (adding a per-point constant commutes with max/min bitwise; the GroupNorm sums are
+ * corrected in closed form), so the matrix cores contract K = Cp instead of 2 Cp.  Needed for k <= 128 only. */
+int gcn_edgeconv_center(const void *x_pm_bf16, const void *wp_bf16, long rows, int C, int Cout, float *q,
+                        void *stream);
 
 /* Point-major operand preparation when activations are already (rows, C) f32: cast to bf16 and zero-pad
  * the channel axis to gcn_edgeconv_padded_channels(C) (no transpose, unlike gcn_edgeconv_pack_x). */
