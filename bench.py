@@ -129,8 +129,9 @@ def pmc_traffic(tag):
     return None
 
 
-def cpu_baseline(N, k, seconds_budget=25.0):
-    """The same hot-path step (fwd+bwd, fp32) through the CPU oracle on ONE cloud; all host cores."""
+def cpu_baseline(N, k, seconds_budget=30.0):
+    """The same hot-path step (fwd+bwd, fp32) through the CPU oracle on ONE cloud; all host cores.  One untimed
+    warm-up, then best of up to 5 timed runs inside a ~30-s budget so that the default run stays short."""
     from gcanet_amd import dgcnn
     from oracle import ref_model as R
     torch.manual_seed(0)
@@ -139,17 +140,93 @@ def cpu_baseline(N, k, seconds_budget=25.0):
     pts, nrm = synth_clouds([0], N, "cpu")
     threads = torch.get_num_threads()
     knn_fn = lambda x, kk, metric: R.knn_torch(x, kk, metric)
-    best, runs, t_all = None, 0, time.time()
-    while runs < 2 and (time.time() - t_all) < seconds_budget:
+
+    def one():
         t0 = time.time()
         out, _ = R.hot_path(sd, pts, nrm, k, knn_fn=knn_fn)
         loss_of(out).backward()
-        dt = time.time() - t0
+        return time.time() - t0
+
+    t_all = time.time()
+    one()                                                   # warm-up (allocator, thread pool, oneDNN primitives)
+    best, runs = None, 0
+    while runs < 5 and (runs == 0 or (time.time() - t_all) < seconds_budget):
+        dt = one()
         best = dt if best is None else min(best, dt)
         runs += 1
     return {"value": round(1.0 / best, 5), "unit": "clouds/s", "cores": threads, "kind": "port",
             "sample": "1 cloud N=%d k=%d, full hot path fwd+bwd fp32 via oracle/ref_model.hot_path "
-                      "(torch CPU restatement of M4:634-747), best of %d" % (N, k, runs)}
+                      "(torch CPU restatement of M4:634-747), 1 warm-up + best of %d" % (N, k, runs)}
+
+
+def _event_ms(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def north_star_rooflines(dev, B=8, N=8192, k=64, C=128):
+    """The two rooflines BASELINE.json's north_star names, at its shape (B=8, N=8192, k=64, C=128), timed with HIP
+    events on the launch stream OUTSIDE the timed step (this model's layers are 6/64/64 channels wide, so the C=128
+    shape does not occur inside the step):
+      knn_gather : KNN(k)(xyz, xyz) [KNN_CUDA signature] + grouping_operation of C=128 features with those lists,
+                   against the HBM roofline; algorithmic bytes per SURVEY 8d:
+                   kNN 4*B*3*N + 8*B*N*k, group 4*B*C*N + 4*B*N*k + 4*B*C*N*k (= 2.198 GB).
+      grouped_mlp: the EdgeConv grouped (N*k, 2C) x (2C, C) contraction, training variant (routed extreme + arg),
+                   against the dense bf16 MFMA peak; algorithmic FLOPs 2*(B*N*k)*2C*C = 274.9 G.  The kernel pair
+                   executes half of them on the matrix cores (the centre half is contracted once per point)."""
+    from gcanet_amd import _lib
+    from gcanet_amd.knn_cuda import KNN
+    from gcanet_amd.pointnet2_ops.pointnet2_utils import grouping_operation
+    g = torch.Generator().manual_seed(7)
+    xyz = torch.rand(B, 3, N, generator=g).to(dev)
+    feat = torch.randn(B, C, N, generator=g).to(dev)
+    knn_mod = KNN(k, transpose_mode=False)
+    with torch.no_grad():
+        _, I = knn_mod(xyz, xyz)
+        idx32 = I.permute(0, 2, 1).to(torch.int32).contiguous()
+        ms_knn = _event_ms(lambda: knn_mod(xyz, xyz))
+        ms_grp = _event_ms(lambda: grouping_operation(feat, idx32))
+    by_knn = 4.0 * B * 3 * N + 8.0 * B * N * k
+    by_grp = 4.0 * B * C * N + 4.0 * B * N * k + 4.0 * B * C * N * k
+    gbs = (by_knn + by_grp) / (ms_knn + ms_grp) / 1e6
+    knn_gather = {"shape": "B=%d,N=%d,k=%d,C=%d" % (B, N, k, C), "knn_ms": round(ms_knn, 4), "group_ms": round(ms_grp, 4),
+                  "bytes": by_knn + by_grp, "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                  "frac": round(gbs / PEAK_HBM_GBS, 4), "group_only_frac": round(by_grp / ms_grp / 1e6 / PEAK_HBM_GBS, 4)}
+    # grouped MLP at C = Cout = 128
+    lib = _lib.lib()
+    x = torch.randn(B, N, C, generator=g).to(dev)
+    w = (torch.randn(C, 2 * C, generator=g) / (2 * C) ** 0.5).to(dev)
+    ga = torch.randn(C, generator=g).to(dev)
+    Cp = lib.gcn_edgeconv_padded_channels(C)
+    x_bf = torch.empty(B, N, Cp, dtype=torch.bfloat16, device=dev)
+    wp = torch.empty(C, 2 * Cp, dtype=torch.bfloat16, device=dev)
+    q = torch.empty(B * N, C, device=dev)
+    ymax = torch.empty(B, N, C, device=dev)
+    amax = torch.empty(B, N, C, dtype=torch.uint8, device=dev)
+    gsum = torch.empty(B, 2, 2, dtype=torch.float64, device=dev)
+    st = _lib.stream_of(x)
+    _lib.call("gcn_cast_pad_bf16", _lib.ptr(x), B * N, C, _lib.ptr(x_bf), st)
+    _lib.call("gcn_edgeconv_pack_w", _lib.ptr(w), C, C, _lib.ptr(wp), st)
+    ms_c = _event_ms(lambda: _lib.call("gcn_edgeconv_center", _lib.ptr(x_bf), _lib.ptr(wp), B * N, C, C, _lib.ptr(q), st))
+    ms_f = _event_ms(lambda: _lib.call("gcn_edgeconv_fwd", _lib.ptr(x_bf), _lib.ptr(wp), _lib.ptr(I), 1, B, N, N, C, k, C, 2,
+                                       _lib.ptr(q), _lib.ptr(ymax), None, _lib.ptr(amax), None, _lib.ptr(gsum), _lib.ptr(ga), st))
+    flops = 2.0 * B * N * k * 2 * C * C
+    executed = 2.0 * B * N * k * C * C + 2.0 * B * N * C * C
+    tf = flops / (ms_c + ms_f) / 1e9
+    grouped_mlp = {"shape": "B=%d,N=%d,k=%d,C=%d->%d, routed+arg (training)" % (B, N, k, C, C), "flops": flops,
+                   "center_ms": round(ms_c, 4), "grouped_ms": round(ms_f, 4), "achieved": round(tf, 1),
+                   "peak": PEAK_TFLOPS["bf16_mfma"], "unit": "TFLOP/s", "frac": round(tf / PEAK_TFLOPS["bf16_mfma"], 4),
+                   "executed_tflops": round(executed / (ms_c + ms_f) / 1e9, 1),
+                   "executed_frac": round(executed / (ms_c + ms_f) / 1e9 / PEAK_TFLOPS["bf16_mfma"], 4)}
+    return {"knn_gather": knn_gather, "grouped_mlp": grouped_mlp}
 
 
 def grouping_times(model, pts, nrm, reps=5):
@@ -337,6 +414,8 @@ def main():
         "knn_mpts_per_s": round(3 * B * N / knn_ms / 1e3, 2) if knn_ms > 0 else None,
         "roofline": roofline, "kernels": kernels, "loss": float(loss.detach()),
     }
+    if world == 1:
+        res["north_star"] = north_star_rooflines(dev)
     if world == 1 and not args.no_cpu_baseline:
         res["forward_grouping"] = grouping_times(model, pts, nrm)
         res["cpu_baseline"] = cpu_baseline(N, args.k)

@@ -10,7 +10,13 @@ from .attention import sdpa
 
 
 def _mha(attn, q_in, k_in, v_in, attn_mask=None, precision="f32"):
-    """nn.MultiheadAttention(batch_first=True).forward with the fused core (eval: no dropout)."""
+    """nn.MultiheadAttention(batch_first=True).forward with the fused core.  The fused kernel never forms the
+    attention probabilities, so dropout ON them (nn.MultiheadAttention(dropout=p) in training mode) cannot be
+    applied: that configuration is refused rather than silently run without dropout (the reference's default is
+    dropout=0.0, models/query_decoder.py:7,49)."""
+    if attn.dropout > 0.0 and attn.training:
+        raise RuntimeError("gcanet_amd.query_decoder: attention dropout p=%g in training mode is not supported by the "
+                           "fused attention kernel; use dropout=0.0 (the reference default) or eval()" % attn.dropout)
     d, h = attn.embed_dim, attn.num_heads
     w, b = attn.in_proj_weight, attn.in_proj_bias
     q = F.linear(q_in, w[:d], b[:d])

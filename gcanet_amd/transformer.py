@@ -58,6 +58,12 @@ class Attention(nn.Module):
             mask = F.pad(mask.flatten(1), (1, 0), value=True)
             assert mask.shape[-1] == n, 'mask has incorrect dimensions'
             keep = mask[:, None, :] * mask[:, :, None]                       # (b,n,n)
+            # The reference fills masked scores with the FINITE -finfo.max, so a padded query token (a fully masked
+            # row) soft-maxes to the uniform distribution over all n keys, i.e. mean(V) -- not to zeros.  Same
+            # result here: such rows are un-masked and their query is zeroed (all scores equal -> uniform).
+            dead = ~mask                                                     # (b,n) padded query tokens
+            keep = keep | dead[:, :, None]
+            q = q.masked_fill(dead.repeat_interleave(h, 0).unsqueeze(-1), 0.0)
             am = (~keep).unsqueeze(1).expand(-1, h, -1, -1).reshape(b * h, n, n)
         out = sdpa(q, k, v, am, self.scale, self.precision)
         out = out.view(b, h, n, -1).transpose(1, 2).reshape(b, n, -1)

@@ -166,8 +166,10 @@ def offset_pred_module(points, feature, emb, sd, nn_nb=30, n_keys=120, prefix=""
 
 
 # ----------------------------------------------------------------------------- attention stacks
-def transformer(x, sd, depth, heads, prefix=""):
-    """models/transformer.py:36-91: pre-norm MHSA (scale = dim**-0.5, NOT dim_head) + GELU FFN, residuals."""
+def transformer(x, sd, depth, heads, prefix="", mask=None):
+    """models/transformer.py:36-91: pre-norm MHSA (scale = dim**-0.5, NOT dim_head) + GELU FFN, residuals.
+    mask (b, n-1) bool: padded with a leading True, outer product, masked scores filled with the FINITE -finfo.max
+    (:57-62) -- a fully masked row therefore attends uniformly."""
     g = lambda n: torch.as_tensor(sd[prefix + n])
     dim = x.shape[-1]
     scale = dim ** -0.5
@@ -177,7 +179,12 @@ def transformer(x, sd, depth, heads, prefix=""):
         qkv = F.linear(h, g(p + "0.fn.fn.to_qkv.weight"))
         b, n, _ = qkv.shape
         q, k, v = [t.view(b, n, heads, -1).transpose(1, 2) for t in qkv.chunk(3, dim=-1)]
-        att = torch.softmax(q @ k.transpose(-1, -2) * scale, dim=-1)
+        dots = q @ k.transpose(-1, -2) * scale
+        if mask is not None:
+            m = F.pad(mask.flatten(1), (1, 0), value=True)
+            m = m[:, None, :] * m[:, :, None]
+            dots = dots.masked_fill(~m.unsqueeze(1), -torch.finfo(dots.dtype).max)
+        att = torch.softmax(dots, dim=-1)
         o = (att @ v).transpose(1, 2).reshape(b, n, -1)
         x = F.linear(o, g(p + "0.fn.fn.to_out.0.weight"), g(p + "0.fn.fn.to_out.0.bias")) + x
         h = F.layer_norm(x, (dim,), g(p + "1.fn.norm.weight"), g(p + "1.fn.norm.bias"))
@@ -469,3 +476,32 @@ def instance_loss(cls_scores, mask_scores, iou_scores, proposals_idx, proposals_
     sl = iou_scores[torch.arange(n), labels]
     iou_loss = (F.mse_loss(sl, gt_ious, reduction='none') * iw).sum() / (iw.sum() + 1)
     return cls_loss + mask_loss + iou_loss
+
+
+# ------------------------------------------------------------------------------------------
+# Offset module of the reference's variant M2 (models/dgcnn-hais-concat-direct-2.py:296-462): native kNN among the key
+# points + grouping_operation gathers + sigmoid KPAM.  Pinned by tests/golden/m2_offset_golden.npz (the reference's own
+# source text run on the oracle's KNN / gather, tests/golden/make_golden_m2.py).
+# ------------------------------------------------------------------------------------------
+def offset_pred_module_m2(points, feature, semantic_feature, instance_feature, sd, nn_nb=60, n_keys=120, prefix=""):
+    """points (B,N,3), feature (B,N,128), semantic_feature (B,N,Cs), instance_feature (B,N,Ci) -> offsets (B,3,N)."""
+    from . import KNN_forward
+    g = lambda n: torch.as_tensor(sd[prefix + n])
+    B, N, _ = points.shape
+    sub = key_point_indices(N, n_keys)
+    key_pts, key_feat = points[:, sub], feature[:, sub]                       # (B,120,3), (B,120,128)
+    _, I = KNN_forward(key_pts.detach().permute(0, 2, 1).contiguous().numpy(),
+                       points.detach().permute(0, 2, 1).contiguous().numpy(), nn_nb, False)    # (B,k,N) search_knn.py:11-14
+    idx = torch.from_numpy(I).permute(0, 2, 1)                                # (B,N,k) ranks among the key points
+    bi = torch.arange(B).view(B, 1, 1)
+    direction = key_pts[bi, idx] - points.unsqueeze(2)                        # M2:429
+    f = torch.cat([key_feat[bi, idx], direction], 3)                          # (B,N,k,131)
+    ins_knn = instance_feature[bi, idx]                                       # FULL cloud indexed with key ranks (M2:415)
+    dist = torch.cdist(instance_feature.unsqueeze(2), ins_knn, p=2).squeeze(2)    # (B,N,k)  M2:321
+    a = F.conv1d(F.relu(F.conv1d(dist.permute(0, 2, 1), g("attention_inst.conv1.0.weight"))),
+                 g("attention_inst.conv1.2.weight")).permute(0, 2, 1)
+    f = torch.sigmoid(a).unsqueeze(-1) * f                                    # M2:340-347
+    y = F.conv2d(f.permute(0, 3, 2, 1), g("conv1.0.weight"))                  # (B,128,k,N)
+    y = F.leaky_relu(F.group_norm(y, 2, g("bn1.weight"), g("bn1.bias")), 0.2).max(dim=-2)[0]
+    y = torch.cat([y, feature.permute(0, 2, 1)], dim=1)
+    return F.conv1d(y, g("mlp_offset.weight"), g("mlp_offset.bias"))

@@ -61,3 +61,28 @@ def test_query_decoder_matches_reference_golden(dev, att_golden, tag, kw):
     if kw["iter_pred"]:
         for li, aux in enumerate(o["aux_outputs"]):
             np.testing.assert_allclose(aux["labels"].cpu().numpy(), g[tag + "_aux%d_labels" % li], rtol=1e-4, atol=1e-4)
+
+
+def test_transformer_masked_matches_reference_golden(dev):
+    """Mask with padded tokens (fully masked query rows attend uniformly in the reference: finite -finfo.max fill,
+    transformer.py:57-67), forward and input gradient vs the reference's own module."""
+    import os
+    from gcanet_amd.transformer import Transformer
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "transformer_mask_golden.npz"))
+    T = Transformer(dim=32, depth=2, heads=4, dim_head=8, mlp_dim=64, dropout=0.0)
+    T.load_state_dict({k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd_")})
+    T = T.to(dev)
+    x = torch.from_numpy(g["x"]).to(dev).requires_grad_()
+    y = T(x, mask=torch.from_numpy(g["mask"]).to(dev))
+    np.testing.assert_allclose(y.detach().cpu().numpy(), g["y"], rtol=1e-4, atol=1e-5)
+    (y * torch.from_numpy(g["gy"]).to(dev)).sum().backward()
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g["dx"], rtol=1e-4, atol=1e-4 * np.abs(g["dx"]).max())
+
+
+def test_mha_refuses_attention_dropout_in_training(dev):
+    from gcanet_amd.query_decoder import SelfAttentionLayer
+    layer = SelfAttentionLayer(d_model=32, nhead=4, dropout=0.1).to(dev).train()
+    with pytest.raises(RuntimeError, match="dropout"):
+        layer(torch.randn(2, 10, 32, device=dev))
+    layer.eval()
+    assert torch.isfinite(layer(torch.randn(2, 10, 32, device=dev))).all()

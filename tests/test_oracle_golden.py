@@ -168,3 +168,13 @@ def test_query_decoder(att_golden, tag, kw):
     if kw["iter_pred"]:
         for li, aux in enumerate(o["aux_outputs"]):
             np.testing.assert_allclose(aux["labels"].numpy(), g[tag + "_aux%d_labels" % li], rtol=1e-4, atol=1e-4)
+
+
+def test_transformer_masked_rows_follow_the_reference():
+    """Padded tokens: the reference's finite mask fill makes a fully masked query row attend uniformly
+    (transformer.py:57-67); golden from the reference's own module (tests/golden/make_golden_tr_mask.py)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "transformer_mask_golden.npz"))
+    sd = {k[3:]: g[k] for k in g.files if k.startswith("sd_")}
+    y = R.transformer(torch.from_numpy(g["x"]), sd, depth=2, heads=4, mask=torch.from_numpy(g["mask"]))
+    np.testing.assert_allclose(y.numpy(), g["y"], rtol=1e-5, atol=1e-5)
