@@ -27,6 +27,7 @@
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include "common.h"
+#include "knn_topb.h"
 
 namespace gcn {
 
@@ -112,64 +113,6 @@ struct TopK {
 // between merges, i.e. ~log2(N/k)+1 merges per query instead of hundreds of insertions.
 // Entries are (monotone key bits << 32 | index) so u64 order == (key asc, index asc): ties resolve
 // to the lowest index exactly as the stable insertion sort of the reference (knn.cu:125-131).
-typedef unsigned long long u64;
-#define TOPB_SENT 0xFFFFFFFF7FFFFFFFull
-
-__device__ __forceinline__ unsigned int key_f2u(float x) {
-  const unsigned int u = __float_as_uint(x + 0.0f);          // -0 -> +0
-  return u ^ ((unsigned int)((int)u >> 31) | 0x80000000u);
-}
-__device__ __forceinline__ float key_u2f(unsigned int u) {
-  return __uint_as_float(u ^ ((u >> 31) ? 0x80000000u : 0xFFFFFFFFu));
-}
-__device__ __forceinline__ u64 shfl_u64(u64 v, int src_lane) {
-  const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(unsigned int)v);
-  const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(unsigned int)(v >> 32));
-  return ((u64)(unsigned int)hi << 32) | (unsigned int)lo;
-}
-
-struct TopB {
-  u64 lst, pnd;
-
-  __device__ __forceinline__ void init() { lst = TOPB_SENT; pnd = TOPB_SENT; }
-
-  // one compare-exchange stage with partner lane^j; `asc_block` = this lane's block sorts ascending
-  __device__ __forceinline__ static u64 cex(u64 v, int lane, int j, bool asc_block) {
-    const u64 o = shfl_u64(v, lane ^ j);
-    const bool lower = (lane & j) == 0;
-    const bool take_min = lower == asc_block;
-    const bool o_lt = o < v;
-    return (o_lt == take_min) ? o : v;
-  }
-
-  // merge the first `cnt` pending entries into the sorted list
-  __device__ __forceinline__ void merge(int cnt, int lane) {
-    u64 p = lane < cnt ? pnd : TOPB_SENT;
-#pragma unroll
-    for (int sz = 2; sz <= 64; sz <<= 1)
-#pragma unroll
-      for (int j = sz >> 1; j >= 1; j >>= 1) p = cex(p, lane, j, (lane & sz) == 0);
-    const u64 r = shfl_u64(p, 63 - lane);       // descending copy of the sorted pending entries
-    u64 m = r < lst ? r : lst;                  // the 64 smallest of the union, as a bitonic sequence
-#pragma unroll
-    for (int j = 32; j >= 1; j >>= 1) m = cex(m, lane, j, true);
-    lst = m;
-  }
-
-  // append the candidates of the lanes in `mask` (key, idx); returns the new pending count
-  __device__ __forceinline__ int append(unsigned long long mask, bool pass, float key, int idx, int cnt, int lane) {
-    const int p = __popcll(mask);
-    const int rank = __builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0));
-    // full permutation: passing lanes -> [cnt, cnt+p), the others -> the complement (their data is ignored)
-    const int dest = pass ? cnt + rank : ((cnt + p + lane - rank) & 63);
-    const int lo = __builtin_amdgcn_ds_permute(dest << 2, idx);
-    const int hi = __builtin_amdgcn_ds_permute(dest << 2, (int)key_f2u(key));
-    const bool in = (unsigned int)(lane - cnt) < (unsigned int)p;
-    pnd = in ? (((u64)(unsigned int)hi << 32) | (unsigned int)lo) : pnd;
-    return cnt + p;
-  }
-};
-
 struct KnnArgs {
   const float *ref;    // candidates
   const float *query;
@@ -180,6 +123,7 @@ struct KnnArgs {
   float *dist;   // may be null
   int64_t *ind;
   long o_sb, o_sk, o_sq;  // output element (b,t,q) at b*sb + t*sk + q*sq
+  const unsigned char *only;  // (B, nq) or null: when given, only queries with a non-zero byte are searched and written
 };
 
 // METRIC 0: KNN_CUDA direct sum of squared differences (knn.cu:73-77), out dist = sqrt
@@ -201,6 +145,12 @@ __global__ __launch_bounds__(256) void knn_select_kernel(KnnArgs a) {
   int qi[QW];  // clamped query ids (uniform)
 #pragma unroll
   for (int q = 0; q < QW; ++q) qi[q] = min(q0 + q, a.nq - 1);
+  if (a.only) {  // flagged-only mode: nearly every wave leaves here
+    bool any = false;
+#pragma unroll
+    for (int q = 0; q < QW; ++q) any |= a.only[(long)b * a.nq + qi[q]] != 0;
+    if (!any) return;
+  }
 
   TopK<KPL> top[QW];
   TopB topb[QW];     // k <= 64: buffered bitonic selection (KPL == 1)
@@ -317,6 +267,7 @@ __global__ __launch_bounds__(256) void knn_select_kernel(KnnArgs a) {
 #pragma unroll
   for (int q = 0; q < QW; ++q) {
     if (q0 + q >= a.nq) break;
+    if (a.only && a.only[(long)b * a.nq + q0 + q] == 0) continue;
 #pragma unroll
     for (int s = 0; s < KPL; ++s) {
       const int t = s * 64 + lane;
@@ -914,6 +865,20 @@ GCN_EXPORT int gcn_knn_cuda(const float *ref, const float *query, int B, int dim
   if (dim == 3) return launch_knn<0, 3>(a, B, st);
   return launch_knn<0, 0>(a, B, st);
 }
+
+namespace gcn {
+int launch_knn_flagged(const float *x_pm, const float *xx, const unsigned char *flag, int B, int N, int C, int k, int step,
+                       int kout, int64_t *idx, hipStream_t st) {
+  KnnArgs a{};
+  a.ref = x_pm; a.query = x_pm; a.xx = xx; a.only = flag;
+  a.dim = C; a.nr = N; a.nq = N; a.k = k; a.step = step;
+  a.ref_sb = a.q_sb = (long)C * N;
+  a.ref_sd = a.q_sd = 1; a.ref_sn = a.q_sn = C;          // point-major rows
+  a.o_sb = (long)N * kout; a.o_sk = 1; a.o_sq = kout;
+  a.dist = nullptr; a.ind = idx;
+  return launch_knn<1, 0>(a, B, st);
+}
+}  // namespace gcn
 
 GCN_EXPORT long gcn_knn_tiles_ws_bytes(int B, int C, int N) {
   if (B < 0 || C < 1 || N < 1) return -1;

@@ -1,0 +1,687 @@
+// knn_filter.hip -- feature-space kNN (models/dgcnn-hais-concat-direct-4.py:30-47, C in {32,64,128}) as
+// bf16 PREFILTER on the matrix cores + EXACT f32 re-rank of the survivors, for gfx950.
+//
+// Why.  The indices must equal the reference's bit for bit, so the distances that decide them must be the
+// reference's f32 arithmetic -- and an exact N x N distance matrix costs 2*N^2*C f32 flops at the f32 MFMA rate
+// (1/16 of the bf16 rate), plus a sorted-list insert for every candidate that beats the running k-th key
+// (knn.hip: knn_mfma16_kernel, 1.4 ms at B=8, N=8192, C=64, k=64).  But only ~k candidates per query matter.
+// Here the N^2 work runs in bf16 and merely FILTERS:
+//   1. prep      x -> u = x - mean (distances are translation invariant; centring minimises the norms that bound
+//                the rounding error), ut = bf16(u) point-major, hn = |ut|^2 / 2, the oracle's squared norms xx,
+//                per-cloud maxima of |ut| and |x|.
+//   2. threshold (knnf_stream_kernel<MODE 0>) for every query a value tau that (almost surely) has at least k
+//                APPROXIMATE squared distances a(q,j) = |ut_q - ut_j|^2 under it, from a 1-in-8 strided sample of
+//                the candidates: the m-th smallest sample value with m ~ k/8 + 6 sqrt(k/8).
+//   3. filter    (knnf_stream_kernel<MODE 1>) a(q,j) <= tau for ALL pairs, one bit per pair (B*N*N/8 bytes).
+//   4. re-rank   (knnf_rerank_kernel) one wave per query: expand the bits (~3k candidates), gather their f32 rows,
+//                evaluate the reference's arithmetic exactly (ascending-channel fmaf chain, fl(fl(2 dot - xx_j) -
+//                xx_q), the same expression as knn_mfma16 / oracle/gcanet_oracle.c:model_pd), sort by (key, index)
+//                -> the lowest index wins ties, as in the oracle -- and VERIFY a posteriori, with the exact k-th key
+//                d_k in hand, that no pair the filter dropped can beat it (bound below).  Fewer than k or more than
+//                CAP candidates, or a failed verification -> the query goes on the fallback list and
+//   5. fallback  knnf_fallback_kernel searches the listed queries exhaustively in the same exact arithmetic.
+// The result is therefore ALWAYS the exact one; the sample statistics only decide how long the fallback list is.
+//
+// Verification bound.  Let D = |x_q - x_j| (reals), Dt = |ut_q - ut_j|.  ut = bf16(fl(x - mu)) = u (1 + d) with
+// |d| <= 2^-9 (1 + 2^-9) + 2^-24 per element, so |Dt - D| <= eta_q := 0.00198 (|ut_q| + R), R = max_j |ut_j|.  The f32
+// evaluation errors of the reference's key (expanded form: <= (C+4) 2^-24 (|x_q| + |x_j|)^2) and of the filter's
+// a(q,j) (f32 accumulation of exact bf16 products, three-piece bf16 image of the threshold, rounded hn) are each
+// below Delta_q := 4 (C+8) 2^-24 (max(|x_q|, |ut_q|) + max(X, R))^2, X = max_j |x_j|.  A dropped pair has
+// a > tau, hence Dt^2 > tau - Delta, D > sqrt(tau - Delta) - eta, and a reference key > (sqrt(tau - Delta) - eta)^2
+// - Delta =: L.  If L > d_k, every dropped pair loses against the k-th kept one: the k smallest kept keys ARE the
+// reference's k nearest.  (tau comes from a sample rank ~3k, d_k is rank k: the gap is several eta wide.)
+//
+// Geometry (wave64, v_mfma_f32_32x32x16_bf16): workgroup = 4 waves x 32 queries; candidate tiles of 128 rows
+// [row][Cp] bf16 stream through LDS (LDS-DMA, double buffered, source-side XOR swizzle as in edgeconv_fwd.hip);
+// query fragments stay in registers.  MODE 1 puts the queries on the MFMA column index, so a lane owns ONE query:
+// the threshold enters as one extra k-step (query side: -theta in three bf16 pieces, candidate side: ones), the
+// test is acc >= hn_j, and a lane collects its query's 128 bits of a tile in four registers (one 16-byte store).
+#include "common.h"
+#include "knn_topb.h"
+
+#include <type_traits>
+
+namespace gcn {
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+constexpr int KNNF_CAP = 512;        // candidates a query may keep (8 per lane)
+constexpr int KNNF_STRIDE = 8;       // sample every 8th candidate
+constexpr int KNNF_PHASE = 3;
+
+struct KnnfArgs {
+  const float *x;            // (B,N,C) f32 point-major
+  unsigned short *ut;        // (B,N,Cp) bf16 centred rows
+  float *hn;                 // (B,N) |ut|^2 / 2
+  float *xx;                 // (B,N) the oracle's squared norms (squares rounded, added in channel order)
+  float *msum;               // (B,Cp) channel sums
+  unsigned int *stat;        // (B,2) float bits: max |ut|^2, max xx
+  float *theta;              // (B,N) (|ut_q|^2 - tau_q) / 2
+  float *tau;                // (B,N) the approximate squared-distance threshold the filter applies
+  unsigned int *bitmap;      // (B,N,NW)
+  unsigned char *flag;       // (B,N)
+  unsigned int *nflag;       // [0] number of flagged queries
+  unsigned int *flist;       // (B*N) flagged queries (b*N + q), in arrival order
+  int64_t *idx;              // (B,N,kout)
+  int B, N, C, Cp, NW, k, step, kout, m_rank;
+};
+
+__device__ __forceinline__ unsigned short f2bf(float f) {
+  __bf16 h = (__bf16)f;
+  return __builtin_bit_cast(unsigned short, h);
+}
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float((unsigned int)h << 16); }
+
+// partner half-wave's value in lanes < 32 (see edgeconv_fwd.hip: both operands/results must stay opaque scalars)
+__device__ __forceinline__ unsigned int upper_half_u(unsigned int u) {
+  unsigned int w = u;
+  asm volatile("" : "+v"(w));
+  const u32x2 r = __builtin_amdgcn_permlane32_swap(u, w, false, false);
+  unsigned int r1 = r[1];
+  asm volatile("" : "+v"(r1));
+  return r1;                       // lanes 0..31: value of lane + 32 (tools/micro/permlane_swap_test.hip)
+}
+
+// ------------------------------------------------------------------ 1. prep
+__global__ __launch_bounds__(256) void knnf_colsum_kernel(KnnfArgs a) {
+  const int b = blockIdx.y;
+  const int c = threadIdx.x & 127, rl = threadIdx.x >> 7;
+  const int rows = (a.N + gridDim.x - 1) / gridDim.x;
+  const int r0 = blockIdx.x * rows, r1 = min(a.N, r0 + rows);
+  if (c >= a.C) return;
+  const float *xb = a.x + (long)b * a.N * a.C;
+  float s = 0.f;
+  for (int r = r0 + rl; r < r1; r += 2) s += xb[(long)r * a.C + c];
+  atomicAdd(a.msum + (long)b * a.Cp + c, s);
+}
+
+// 64 rows per workgroup.  Phase 1: a wave walks 16 rows, lanes across channels: centred bf16 row and hn.  Phase 2:
+// one thread per row adds the oracle's squared norm in channel order (sequential, as oracle/gcanet_oracle.c:141-149).
+// The per-cloud maxima take one atomic per workgroup.
+__global__ __launch_bounds__(256) void knnf_prep_kernel(KnnfArgs a) {
+  __shared__ float red[2][4];
+  const int lane = lane_id(), wave = wave_id();
+  const int b = blockIdx.y;
+  const int r0 = blockIdx.x * 64;
+  const float invn = 1.f / (float)a.N;
+  float mean[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int c = lane + 64 * h;
+    mean[h] = c < a.C ? a.msum[(long)b * a.Cp + c] * invn : 0.f;
+  }
+  float ntmax = 0.f;
+  for (int i = 0; i < 16; ++i) {
+    const int r = r0 + wave * 16 + i;
+    if (r >= a.N) break;
+    const float *row = a.x + ((long)b * a.N + r) * a.C;
+    float nt = 0.f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int c = lane + 64 * h;
+      if (c < a.Cp) {
+        const float u = c < a.C ? row[c] - mean[h] : 0.f;
+        const unsigned short hb = f2bf(u);
+        a.ut[((long)b * a.N + r) * a.Cp + c] = hb;
+        const float v = bf2f(hb);
+        nt = fmaf(v, v, nt);
+      }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) nt += __shfl_xor(nt, o);
+    if (lane == 0) a.hn[(long)b * a.N + r] = 0.5f * nt;
+    ntmax = fmaxf(ntmax, nt);
+  }
+  float xmax = 0.f;
+  if (threadIdx.x < 64 && r0 + (int)threadIdx.x < a.N) {
+    const float *row = a.x + ((long)b * a.N + r0 + threadIdx.x) * a.C;
+    float s = 0.f;
+    for (int c = 0; c < a.C; c += 4) {
+      const float4 v = *reinterpret_cast<const float4 *>(row + c);
+      const float s0 = v.x * v.x, s1 = v.y * v.y, s2 = v.z * v.z, s3 = v.w * v.w;
+      s = c == 0 ? s0 : s + s0;
+      s = s + s1;
+      s = s + s2;
+      s = s + s3;
+    }
+    a.xx[(long)b * a.N + r0 + threadIdx.x] = s;
+    xmax = s;
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) xmax = fmaxf(xmax, __shfl_xor(xmax, o));
+  if (lane == 0) { red[0][wave] = ntmax; red[1][wave] = xmax; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicMax(a.stat + b * 2, __float_as_uint(fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]))));
+    atomicMax(a.stat + b * 2 + 1, __float_as_uint(red[1][0]));      // rows of phase 2 live in wave 0
+  }
+}
+
+// ------------------------------------------------------------------ 2./3. streaming kernel
+template <int KS, int MODE>   // KS = Cp/16 k-steps; MODE 0 = thresholds from the strided sample, 1 = filter all pairs
+__global__ __launch_bounds__(256, 2) void knnf_stream_kernel(KnnfArgs a) {
+  constexpr int CP = KS * 16;
+  constexpr int NC = 2 * KS;
+  constexpr int ROW_BYTES = CP * 2;
+  constexpr int RPP = 64 / NC;
+  constexpr int PIECES = 128 / RPP;
+  constexpr int PPW = PIECES / 4;
+  constexpr int RPB = NC >= 16 ? 1 : 16 / NC;
+  constexpr int A_BYTES = 128 * ROW_BYTES;
+  constexpr int BUF_BYTES = A_BYTES + 512;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+
+  const int lane = lane_id(), wave = wave_id();
+  const int lr = lane & 31, lh = lane >> 5;
+  const int lin = blockIdx.x + gridDim.x * blockIdx.y;     // cloud = id % B: one cloud per XCD at 8 clouds
+  const int b = lin % (int)gridDim.y;
+  const int q0 = ((lin / (int)gridDim.y) * 4 + wave) * 32;
+  const int N = a.N;
+  const unsigned char *utb = reinterpret_cast<const unsigned char *>(a.ut) + (long)b * N * ROW_BYTES;
+  const float *hnb = a.hn + (long)b * N;
+
+  // query fragments: row q0 + lr, k-chunk 2s + lh
+  bf16x8 qf[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s)
+    qf[s] = *reinterpret_cast<const bf16x8 *>(utb + (long)(q0 + lr) * ROW_BYTES + (2 * s + lh) * 16);
+
+  // MODE 1: the extra k-step.  Query side: -theta_q in three bf16 pieces (k = 0,1,2 of the lower half-wave's chunk),
+  // candidate side: ones in the same places.
+  bf16x8 thf, onef;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { thf[i] = 0; onef[i] = 0; }
+  if (MODE == 1 && lh == 0) {
+    const float th = -a.theta[(long)b * N + q0 + lr];
+    const unsigned short p1 = f2bf(th);
+    const float r1 = th - bf2f(p1);
+    const unsigned short p2 = f2bf(r1);
+    const float r2 = r1 - bf2f(p2);
+    const unsigned short p3 = f2bf(r2);
+    thf[0] = (short)p1; thf[1] = (short)p2; thf[2] = (short)p3;
+    onef[0] = onef[1] = onef[2] = (short)0x3F80;
+  }
+
+  // per-lane constants of the DMA pieces and of the fragment reads
+  unsigned int coff[PPW];
+  int prow[PPW];
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int p = wave + i * 4;
+    const int row = p * RPP + lane / NC;
+    const int cs = lane % NC;
+    coff[i] = (unsigned int)((cs ^ ((row / RPB) & (NC - 1))) * 16);
+    prow[i] = row;
+  }
+  unsigned int arow[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) arow[s] = (unsigned int)(lr * ROW_BYTES + (((2 * s + lh) ^ ((lr / RPB) & (NC - 1))) << 4));
+
+  // candidate index of tile row `row` of tile t
+  auto src_row = [&](int t, int row) -> int {
+    if (MODE == 1) return t * 128 + row;
+    const int j = KNNF_STRIDE * (t * 128 + row) + KNNF_PHASE;
+    return j < N ? j : N - 1;
+  };
+  const int ntiles = MODE == 1 ? N / 128 : (N / KNNF_STRIDE + 127) / 128;
+
+  auto issue = [&](int t, int buf) {
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int p = wave + i * 4;
+      const unsigned char *src = utb + ((unsigned int)src_row(t, prow[i]) * (unsigned int)ROW_BYTES + coff[i]);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                       (__attribute__((address_space(3))) void *)(lds + buf * BUF_BYTES + p * 1024), 16, 0, 0);
+    }
+    if (wave < 2) {
+      const float *src = hnb + src_row(t, wave * 64 + lane);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                       (__attribute__((address_space(3))) void *)(lds + buf * BUF_BYTES + A_BYTES + wave * 256), 4, 0, 0);
+    }
+  };
+
+  // MODE 0 state: per accumulator register (= query row 4 lh + (i&3) + 8 (i>>2)) the three smallest values this lane saw
+  float t0[MODE == 0 ? 16 : 1], t1[MODE == 0 ? 16 : 1], t2[MODE == 0 ? 16 : 1];
+  if (MODE == 0) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { t0[i] = __builtin_inff(); t1[i] = __builtin_inff(); t2[i] = __builtin_inff(); }
+  }
+
+  f32x16 zero16;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) zero16[i] = 0.f;
+
+  issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  auto tile = [&](int t, auto bufc) {
+    constexpr int BUF = decltype(bufc)::value;
+    if (t + 1 < ntiles) issue(t + 1, BUF ^ 1);
+    const unsigned char *tb = lds + BUF * BUF_BYTES;
+    unsigned int words[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+      f32x16 acc;
+      bf16x8 cf[KS];
+#pragma unroll
+      for (int s = 0; s < KS; ++s) cf[s] = *reinterpret_cast<const bf16x8 *>(tb + arow[s] + cb * 32 * ROW_BYTES);
+      if (MODE == 1) {
+        // rows = candidates, columns = queries: a lane owns one query
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(onef, thf, zero16, 0, 0, 0);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cf[s], qf[s], acc, 0, 0, 0);
+        // candidate of register i: cb*32 + 4 lh + (i&3) + 8 (i>>2); their hn are four consecutive floats per group
+        const float *hl = reinterpret_cast<const float *>(tb + A_BYTES) + cb * 32 + 4 * lh;
+        unsigned int w = 0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 h4 = *reinterpret_cast<const float4 *>(hl + 8 * g);
+          w |= acc[4 * g + 0] >= h4.x ? 1u << (4 * g + 0) : 0u;
+          w |= acc[4 * g + 1] >= h4.y ? 1u << (4 * g + 1) : 0u;
+          w |= acc[4 * g + 2] >= h4.z ? 1u << (4 * g + 2) : 0u;
+          w |= acc[4 * g + 3] >= h4.w ? 1u << (4 * g + 3) : 0u;
+        }
+        words[cb] = w | (upper_half_u(w) << 16);        // lanes < 32: bits 0-15 own rows, 16-31 the upper half's
+      } else {
+        // rows = queries, columns = candidates: a query's 32 candidates of this block sit in the 32 lanes of a half
+        acc = zero16;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[s], cf[s], acc, 0, 0, 0);
+        const float hc = reinterpret_cast<const float *>(tb + A_BYTES)[cb * 32 + lr];
+        const bool valid = KNNF_STRIDE * (t * 128 + cb * 32 + lr) + KNNF_PHASE < N;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float g = valid ? hc - acc[i] : __builtin_inff();      // (a(q,j) - |ut_q|^2) / 2
+          const float x1 = fmaxf(t0[i], g);
+          t0[i] = fminf(t0[i], g);
+          const float x2 = fmaxf(t1[i], x1);
+          t1[i] = fminf(t1[i], x1);
+          t2[i] = fminf(t2[i], x2);
+        }
+      }
+    }
+    if (MODE == 1 && lh == 0) {
+      uint4 v = {words[0], words[1], words[2], words[3]};
+      *reinterpret_cast<uint4 *>(a.bitmap + ((long)b * N + q0 + lr) * a.NW + t * 4) = v;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  };
+
+  for (int t = 0; t < ntiles; t += 2) {
+    tile(t, std::integral_constant<int, 0>{});
+    if (t + 1 < ntiles) tile(t + 1, std::integral_constant<int, 1>{});
+  }
+
+  if (MODE == 0) {
+    // m-th smallest of the 96 values a query kept (32 lanes of its half x 3): MSB-first search on the monotone
+    // integer image; the result is rounded UP to the next 2^8 boundary, so at least m sample values are <= it.
+    const int m = a.m_rank;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const unsigned int k0 = key_f2u(t0[i]), k1 = key_f2u(t1[i]), k2 = key_f2u(t2[i]);
+      unsigned int p = 0;
+      for (int bit = 31; bit >= 8; --bit) {
+        const unsigned int trial = p | (1u << bit);
+        const unsigned long long m0 = __ballot(k0 < trial), m1 = __ballot(k1 < trial), m2 = __ballot(k2 < trial);
+        const int clo = __popc((unsigned int)m0) + __popc((unsigned int)m1) + __popc((unsigned int)m2);
+        const int chi = __popc((unsigned int)(m0 >> 32)) + __popc((unsigned int)(m1 >> 32)) + __popc((unsigned int)(m2 >> 32));
+        const int c = lh ? chi : clo;
+        p = c >= m ? p : trial;
+      }
+      const float G = key_u2f(p | 0xffu);
+      if (lr == 0) {
+        const int q = q0 + 4 * lh + (i & 3) + 8 * (i >> 2);
+        const float nq = 2.f * hnb[q];                              // |ut_q|^2
+        const float tau = fmaf(2.f, G, nq);                         // approximate squared-distance threshold
+        a.tau[(long)b * N + q] = tau;
+        a.theta[(long)b * N + q] = 0.5f * (nq - tau);
+      }
+    }
+  }
+}
+
+// the reference's key for (query row in LDS, candidate row in global memory): ascending-channel fmaf chain,
+// fl(fl(2 dot - xx_j) - xx_q), negated (smaller = nearer) -- oracle/gcanet_oracle.c:model_pd, metric 0
+template <int CC>
+__device__ __forceinline__ float knnf_exact_key(const float *__restrict__ row_g, const float *qrow, float xxj, float xxq) {
+  const float4 *row = reinterpret_cast<const float4 *>(row_g);
+  float dot = 0.f;
+#pragma unroll
+  for (int c4 = 0; c4 < CC / 4; ++c4) {
+    const float4 v = row[c4];
+    const float4 u = *reinterpret_cast<const float4 *>(qrow + 4 * c4);
+    dot = fmaf(u.x, v.x, dot);
+    dot = fmaf(u.y, v.y, dot);
+    dot = fmaf(u.z, v.z, dot);
+    dot = fmaf(u.w, v.w, dot);
+  }
+  const float t = 2.f * dot - xxj;
+  const float pd = t - xxq;
+  return -pd;
+}
+
+// ------------------------------------------------------------------ 4. exact re-rank of the survivors
+template <int CC>
+__global__ __launch_bounds__(256) void knnf_rerank_kernel(KnnfArgs a) {
+  __shared__ unsigned short cand_s[4][KNNF_CAP];
+  __shared__ __attribute__((aligned(16))) float qrow_s[4][CC];
+  const int lane = lane_id(), wave = wave_id();
+  const int lin = blockIdx.x + gridDim.x * blockIdx.y;
+  const int b = lin % (int)gridDim.y;
+  const int q = (lin / (int)gridDim.y) * 4 + wave;
+  const int N = a.N, NW = a.NW;
+  if (q >= N) return;
+  const unsigned int *bm = a.bitmap + ((long)b * N + q) * NW;
+  unsigned int words[8];
+  int cnt = 0;
+#pragma unroll
+  for (int w = 0; w < 8; ++w) {
+    const int wi = lane + 64 * w;
+    words[w] = wi < NW ? bm[wi] : 0u;
+    cnt += __popc(words[w]);
+  }
+  int incl = cnt;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int y = __shfl_up(incl, d);
+    if (lane >= d) incl += y;
+  }
+  const int total = __builtin_amdgcn_readlane(incl, 63);
+  const bool bad = total < a.k || total > KNNF_CAP;
+  if (bad) {                                                 // the fallback handles this query exhaustively
+    if (lane == 0) {
+      a.flag[(long)b * N + q] = 1;
+      a.flist[atomicAdd(a.nflag, 1u)] = (unsigned int)(b * N + q);
+    }
+    return;
+  }
+
+  unsigned short *cand = cand_s[wave];
+  float *qrow = qrow_s[wave];
+  const float *xb = a.x + (long)b * N * CC;
+  for (int c = lane; c < CC; c += 64) qrow[c] = xb[(long)q * CC + c];
+  int pos = incl - cnt;
+#pragma unroll
+  for (int w = 0; w < 8; ++w) {
+    unsigned int word = words[w];
+    const int base = (lane + 64 * w) * 32;
+    while (word) {
+      const int p = __ffs((int)word) - 1;
+      word &= word - 1;
+      const int i = p & 15;
+      cand[pos++] = (unsigned short)(base + 4 * (p >> 4) + (i & 3) + 8 * (i >> 2));
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+
+  const float xxq = a.xx[(long)b * N + q];
+  // exact keys of all candidates (up to 8 per lane), as monotone integers
+  unsigned int kf[8];
+  int cj[8];
+  // Row fetch: each lane reads its own candidate's row in 16-byte pieces.  The kernel runs at the rate the vector
+  // memory path accepts such scattered requests (~1 per clock and CU).  Two attempts to coalesce the fetch were slower
+  // at C = 64 (0.46 ms this form): whole rows by LDS-DMA into a 16-KB per-wave stage with lane = row reads (0.57 ms:
+  // a quarter of the occupancy and a full wait per stage), and four lanes per 64 bytes through a 4-KB LDS transposer
+  // (0.90 ms: a dependent load -> write -> read -> fmaf chain per 16 channels).
+#pragma unroll
+  for (int bt = 0; bt < 8; ++bt) {
+    kf[bt] = 0xFFFFFFFFu;
+    cj[bt] = q;
+    if (bt * 64 < total) {                                   // wave-uniform
+      const int c = bt * 64 + lane;
+      const bool valid = c < total;
+      const int j = valid ? (int)cand[c] : q;
+      const float key = knnf_exact_key<CC>(xb + (long)j * CC, qrow, a.xx[(long)b * N + j], xxq);
+      kf[bt] = valid ? key_f2u(key) : 0xFFFFFFFFu;
+      cj[bt] = j;
+    }
+  }
+  // the k-th smallest key value by an MSB-first search with wave-wide counts (scalar unit), then ONE bitonic sort of
+  // the candidates at or below it instead of a sort + merge per batch of 64
+  const int nb = (total + 63) >> 6;
+  auto kth_key = [&](auto nbc) -> unsigned int {
+    constexpr int NB = decltype(nbc)::value;
+    unsigned int pk = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+      const unsigned int trial = pk | (1u << bit);
+      int c = 0;
+#pragma unroll
+      for (int bt = 0; bt < NB; ++bt) c += __popcll(__ballot(kf[bt] < trial));
+      pk = c >= a.k ? pk : trial;
+    }
+    return pk;
+  };
+  unsigned int pk;
+  switch (nb) {
+    case 1: pk = kth_key(std::integral_constant<int, 1>{}); break;
+    case 2: pk = kth_key(std::integral_constant<int, 2>{}); break;
+    case 3: pk = kth_key(std::integral_constant<int, 3>{}); break;
+    case 4: pk = kth_key(std::integral_constant<int, 4>{}); break;
+    case 5: pk = kth_key(std::integral_constant<int, 5>{}); break;
+    case 6: pk = kth_key(std::integral_constant<int, 6>{}); break;
+    case 7: pk = kth_key(std::integral_constant<int, 7>{}); break;
+    default: pk = kth_key(std::integral_constant<int, 8>{}); break;
+  }
+  TopB tb;
+  tb.init();
+  int npend = 0;
+  int nle = 0, nlt = 0;
+#pragma unroll
+  for (int bt = 0; bt < 8; ++bt)
+    if (bt * 64 < total) {
+      nle += __popcll(__ballot(kf[bt] <= pk));
+      nlt += __popcll(__ballot(kf[bt] < pk));
+    }
+  // candidates strictly below the k-th key all belong to the result; of those EQUAL to it the lowest indices fill
+  // the remaining k - nlt places (ties -> lowest index, as the reference's stable insertion).  Usually nle == k and
+  // the index bound is the maximum.
+  int jmax = 0x7fffffff;
+  if (nle > 64) {                                            // wave-uniform, rare: an exact tie straddles the k-th place
+    const int need = a.k - nlt;
+    int pj = 0;
+    for (int bit = 15; bit >= 0; --bit) {                    // largest pj with fewer than `need` tied indices below it
+      const int trial = pj | (1 << bit);
+      int c = 0;
+#pragma unroll
+      for (int bt = 0; bt < 8; ++bt)
+        if (bt * 64 < total) c += __popcll(__ballot(kf[bt] == pk && cj[bt] < trial));
+      pj = c >= need ? pj : trial;
+    }
+    jmax = pj;                                               // the need-th smallest tied index
+  }
+  const bool overflow = false;
+#pragma unroll
+  for (int bt = 0; bt < 8; ++bt)
+    if (bt * 64 < total) {
+      const bool pass = kf[bt] < pk || (kf[bt] == pk && cj[bt] <= jmax);
+      const unsigned long long m = __ballot(pass);
+      if (m) npend = tb.append(m, pass, key_u2f(kf[bt]), cj[bt], npend, lane);
+    }
+  tb.sort_pending(npend, lane);
+  // a-posteriori check with the exact k-th key (header comment)
+  const float dk = key_u2f((unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(tb.lst >> 32), a.k - 1));
+  const float nq = 2.f * a.hn[(long)b * N + q];
+  const float Rt2 = __uint_as_float(a.stat[b * 2]), X2 = __uint_as_float(a.stat[b * 2 + 1]);
+  const float eta = 0.00198f * (sqrtf(nq) + sqrtf(Rt2)) * 1.0001f;
+  const float big = fmaxf(sqrtf(nq), sqrtf(xxq)) + fmaxf(sqrtf(Rt2), sqrtf(X2));
+  const float Delta = 4.f * (float)(CC + 8) * 5.9604645e-8f * big * big * 1.0001f;
+  const float root = sqrtf(fmaxf(a.tau[(long)b * N + q] - Delta, 0.f)) * 0.99999f - eta;
+  const bool proven = !overflow && root > 0.f && (root * root) * 0.99999f - Delta > dk;
+  if (lane == 0) {
+    a.flag[(long)b * N + q] = proven ? 0 : 1;
+    if (!proven) a.flist[atomicAdd(a.nflag, 1u)] = (unsigned int)(b * N + q);
+  }
+  if (proven && lane < a.k && (lane % a.step) == 0)
+    a.idx[((long)b * N + q) * a.kout + lane / a.step] = (int64_t)(unsigned int)tb.lst;
+}
+
+// ------------------------------------------------------------------ 5. exhaustive exact search of the listed queries
+// One workgroup per listed query; its four waves scan a quarter of the cloud each (rows are consecutive: a batch of 64
+// candidates is 64 contiguous rows), keep a buffered bitonic top-64, and wave 0 merges the four lists.
+template <int CC>
+__global__ __launch_bounds__(256) void knnf_fallback_kernel(KnnfArgs a) {
+  __shared__ u64 lists[4][64];
+  __shared__ __attribute__((aligned(16))) float qrow[CC];
+  const int lane = lane_id(), wave = wave_id();
+  const unsigned int nlist = *a.nflag;
+  const int N = a.N;
+  const int klane = (a.k - 1) & 63;
+  for (unsigned int e = blockIdx.x; e < nlist; e += gridDim.x) {
+    const unsigned int bq = a.flist[e];
+    const int b = (int)(bq / (unsigned int)N), q = (int)(bq % (unsigned int)N);
+    const float *xb = a.x + (long)b * N * CC;
+    __syncthreads();                                       // previous query's lists / row are no longer read
+    for (int c = threadIdx.x; c < CC; c += 256) qrow[c] = xb[(long)q * CC + c];
+    __syncthreads();
+    const float xxq = a.xx[(long)b * N + q];
+    TopB tb;
+    tb.init();
+    int cnt = 0;
+    float thr = __builtin_inff();
+    const int per = (N + 3) / 4;
+    const int j_end = min(N, (wave + 1) * per);
+    for (int j0 = wave * per; j0 < j_end; j0 += 64) {
+      const int j = j0 + lane;
+      const bool valid = j < j_end;
+      const int jc = valid ? j : j_end - 1;
+      const float key = knnf_exact_key<CC>(xb + (long)jc * CC, qrow, a.xx[(long)b * N + jc], xxq);
+      const bool pass = valid && key < thr;
+      const unsigned long long m = __ballot(pass);
+      if (m) {
+        if (cnt + __popcll(m) > 64) {
+          tb.merge(cnt, lane);
+          cnt = 0;
+          thr = key_u2f((unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(tb.lst >> 32), klane));
+        }
+        cnt = tb.append(m, pass, key, j, cnt, lane);
+      }
+    }
+    tb.merge(cnt, lane);
+    lists[wave][lane] = tb.lst;
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int w = 1; w < 4; ++w) {
+        tb.pnd = lists[w][lane];
+        tb.merge(64, lane);
+      }
+      if (lane < a.k && (lane % a.step) == 0)
+        a.idx[((long)b * N + q) * a.kout + lane / a.step] = (int64_t)(unsigned int)tb.lst;
+    }
+  }
+}
+
+static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct KnnfWs {
+  size_t ut, hn, xx, msum, stat, nflag, theta, tau, bitmap, flag, flist, total;
+};
+
+static KnnfWs knnf_layout(int B, int N, int Cp) {
+  KnnfWs w{};
+  size_t o = 0;
+  w.msum = o; o += align256(sizeof(float) * (size_t)B * Cp);
+  w.stat = o; o += align256(sizeof(unsigned int) * (size_t)B * 2);      // msum, stat and nflag are zeroed together
+  w.nflag = o; o += 256;
+  w.ut = o; o += align256(2 * (size_t)B * N * Cp);
+  w.hn = o; o += align256(sizeof(float) * (size_t)B * N);
+  w.xx = o; o += align256(sizeof(float) * (size_t)B * N);
+  w.theta = o; o += align256(sizeof(float) * (size_t)B * N);
+  w.tau = o; o += align256(sizeof(float) * (size_t)B * N);
+  w.flag = o; o += align256((size_t)B * N);
+  w.flist = o; o += align256(sizeof(unsigned int) * (size_t)B * N);
+  w.bitmap = o; o += align256(sizeof(unsigned int) * (size_t)B * N * (N / 32));
+  w.total = o;
+  return w;
+}
+
+static int knnf_padded(int C) { return C <= 32 ? 32 : (C <= 64 ? 64 : 128); }
+
+}  // namespace gcn
+
+using namespace gcn;
+
+GCN_EXPORT int gcn_knn_feature_supported(int B, int N, int C, int k2) {
+  return (B >= 1 && (C == 32 || C == 64 || C == 128) && N % 128 == 0 && N >= 1024 && N <= 16384 && k2 >= 1 && k2 <= 64) ? 1 : 0;
+}
+
+GCN_EXPORT long gcn_knn_feature_ws_bytes(int B, int N, int C) {
+  if (B < 1 || N < 128 || N % 128 != 0 || C < 1 || C > 128) return -1;
+  return (long)knnf_layout(B, N, knnf_padded(C)).total;
+}
+
+GCN_EXPORT int gcn_knn_feature(const float *x_pm, int B, int N, int C, int k1, int k2, int64_t *idx, void *ws,
+                               void *stream) {
+  GCN_REQUIRE(x_pm && idx && ws, "gcn_knn_feature: null pointer");
+  GCN_REQUIRE(gcn_knn_feature_supported(B, N, C, k2), "gcn_knn_feature: unsupported shape B=%d N=%d C=%d k=%d "
+              "(need C in {32,64,128}, N %% 128 == 0, 1024 <= N <= 16384, k <= 64)", B, N, C, k2);
+  GCN_REQUIRE(k1 >= 1 && k1 <= k2, "gcn_knn_feature: need 1 <= k1 <= k2");
+  GCN_REQUIRE(((uintptr_t)ws & 255) == 0 && ((uintptr_t)x_pm & 15) == 0, "gcn_knn_feature: ws must be 256-B aligned, x 16-B aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const int Cp = knnf_padded(C);
+  const KnnfWs w = knnf_layout(B, N, Cp);
+  char *base = (char *)ws;
+  KnnfArgs a{};
+  a.x = x_pm; a.ut = (unsigned short *)(base + w.ut); a.hn = (float *)(base + w.hn); a.xx = (float *)(base + w.xx);
+  a.msum = (float *)(base + w.msum); a.stat = (unsigned int *)(base + w.stat); a.theta = (float *)(base + w.theta);
+  a.bitmap = (unsigned int *)(base + w.bitmap); a.flag = (unsigned char *)(base + w.flag); a.idx = idx;
+  a.tau = (float *)(base + w.tau); a.nflag = (unsigned int *)(base + w.nflag); a.flist = (unsigned int *)(base + w.flist);
+  a.B = B; a.N = N; a.C = C; a.Cp = Cp; a.NW = N / 32; a.k = k2; a.step = k2 / k1;
+  a.kout = (k2 + a.step - 1) / a.step;
+  // rank of the sample order statistic: mean k/8 of the true neighbours fall into the 1-in-8 sample
+  const double mu = (double)k2 / KNNF_STRIDE;
+  int m = (int)(mu + 6.0 * __builtin_sqrt(mu) + 2.0);
+  if (m > 96) m = 96;
+  a.m_rank = m;
+  GCN_HIP(hipMemsetAsync(base + w.msum, 0, w.ut - w.msum, st));
+  knnf_colsum_kernel<<<dim3(64, B), 256, 0, st>>>(a);
+  knnf_prep_kernel<<<dim3(cdiv(N, 64), B), 256, 0, st>>>(a);
+  const dim3 grid(N / 128, B);
+#define KNNF_STREAM(KSV)                                                                                           \
+  {                                                                                                                 \
+    constexpr int LDSB = 2 * (128 * KSV * 32 + 512);                                                                \
+    GCN_HIP(hipFuncSetAttribute((const void *)knnf_stream_kernel<KSV, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB)); \
+    GCN_HIP(hipFuncSetAttribute((const void *)knnf_stream_kernel<KSV, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB)); \
+    knnf_stream_kernel<KSV, 0><<<grid, 256, LDSB, st>>>(a);                                                         \
+    knnf_stream_kernel<KSV, 1><<<grid, 256, LDSB, st>>>(a);                                                         \
+  }
+  if (Cp == 32) KNNF_STREAM(2) else if (Cp == 64) KNNF_STREAM(4) else KNNF_STREAM(8)
+#undef KNNF_STREAM
+  int rc = check_launch("knnf_stream_kernel");
+  if (rc) return rc;
+  const dim3 rgrid(N / 4, B);
+  if (C == 32) knnf_rerank_kernel<32><<<rgrid, 256, 0, st>>>(a);
+  else if (C == 64) knnf_rerank_kernel<64><<<rgrid, 256, 0, st>>>(a);
+  else knnf_rerank_kernel<128><<<rgrid, 256, 0, st>>>(a);
+  rc = check_launch("knnf_rerank_kernel");
+  if (rc) return rc;
+  if (C == 32) knnf_fallback_kernel<32><<<256, 256, 0, st>>>(a);
+  else if (C == 64) knnf_fallback_kernel<64><<<256, 256, 0, st>>>(a);
+  else knnf_fallback_kernel<128><<<256, 256, 0, st>>>(a);
+  return check_launch("knnf_fallback_kernel");
+}
+
+// diagnostics for tests / tools: number of flagged queries and total candidate bits of the last call (synchronises)
+GCN_EXPORT int gcn_knn_feature_stats(const void *ws, int B, int N, int C, long *flagged, long *candidates, void *stream) {
+  GCN_REQUIRE(ws && flagged && candidates, "gcn_knn_feature_stats: null pointer");
+  const KnnfWs w = knnf_layout(B, N, knnf_padded(C));
+  const size_t nb = (size_t)B * N;
+  unsigned char *hf = (unsigned char *)malloc(nb);
+  const size_t words = (size_t)B * N * (N / 32);
+  unsigned int *hb = (unsigned int *)malloc(words * 4);
+  if (!hf || !hb) { free(hf); free(hb); set_error("gcn_knn_feature_stats: out of host memory"); return GCN_EINVAL; }
+  GCN_HIP(hipStreamSynchronize((hipStream_t)stream));
+  GCN_HIP(hipMemcpy(hf, (const char *)ws + w.flag, nb, hipMemcpyDeviceToHost));
+  GCN_HIP(hipMemcpy(hb, (const char *)ws + w.bitmap, words * 4, hipMemcpyDeviceToHost));
+  long f = 0, c = 0;
+  for (size_t i = 0; i < nb; ++i) f += hf[i] != 0;
+  for (size_t i = 0; i < words; ++i) c += __builtin_popcount(hb[i]);
+  free(hf); free(hb);
+  *flagged = f; *candidates = c;
+  return GCN_OK;
+}

@@ -1,0 +1,81 @@
+// knn_topb.h -- buffered bitonic top-64 list shared by the kNN kernels (knn.hip, knn_filter.hip)
+#pragma once
+#include "common.h"
+
+namespace gcn {
+
+typedef unsigned long long u64;
+#define TOPB_SENT 0xFFFFFFFF7FFFFFFFull
+
+__device__ __forceinline__ unsigned int key_f2u(float x) {
+  const unsigned int u = __float_as_uint(x + 0.0f);          // -0 -> +0
+  return u ^ ((unsigned int)((int)u >> 31) | 0x80000000u);
+}
+__device__ __forceinline__ float key_u2f(unsigned int u) {
+  return __uint_as_float(u ^ ((u >> 31) ? 0x80000000u : 0xFFFFFFFFu));
+}
+__device__ __forceinline__ u64 shfl_u64(u64 v, int src_lane) {
+  const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(unsigned int)v);
+  const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(unsigned int)(v >> 32));
+  return ((u64)(unsigned int)hi << 32) | (unsigned int)lo;
+}
+
+struct TopB {
+  u64 lst, pnd;
+
+  __device__ __forceinline__ void init() { lst = TOPB_SENT; pnd = TOPB_SENT; }
+
+  // one compare-exchange stage with partner lane^j; `asc_block` = this lane's block sorts ascending
+  __device__ __forceinline__ static u64 cex(u64 v, int lane, int j, bool asc_block) {
+    const u64 o = shfl_u64(v, lane ^ j);
+    const bool lower = (lane & j) == 0;
+    const bool take_min = lower == asc_block;
+    const bool o_lt = o < v;
+    return (o_lt == take_min) ? o : v;
+  }
+
+  // merge the first `cnt` pending entries into the sorted list
+  __device__ __forceinline__ void merge(int cnt, int lane) {
+    u64 p = lane < cnt ? pnd : TOPB_SENT;
+#pragma unroll
+    for (int sz = 2; sz <= 64; sz <<= 1)
+#pragma unroll
+      for (int j = sz >> 1; j >= 1; j >>= 1) p = cex(p, lane, j, (lane & sz) == 0);
+    const u64 r = shfl_u64(p, 63 - lane);       // descending copy of the sorted pending entries
+    u64 m = r < lst ? r : lst;                  // the 64 smallest of the union, as a bitonic sequence
+#pragma unroll
+    for (int j = 32; j >= 1; j >>= 1) m = cex(m, lane, j, true);
+    lst = m;
+  }
+
+  // sort the first `cnt` pending entries into the (empty) list
+  __device__ __forceinline__ void sort_pending(int cnt, int lane) {
+    u64 p = lane < cnt ? pnd : TOPB_SENT;
+#pragma unroll
+    for (int sz = 2; sz <= 64; sz <<= 1)
+#pragma unroll
+      for (int j = sz >> 1; j >= 1; j >>= 1) p = cex(p, lane, j, (lane & sz) == 0);
+    lst = p;
+  }
+
+  // append the candidates of the lanes in `mask` (key, idx); returns the new pending count
+  __device__ __forceinline__ int append(unsigned long long mask, bool pass, float key, int idx, int cnt, int lane) {
+    const int p = __popcll(mask);
+    const int rank = __builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0));
+    // full permutation: passing lanes -> [cnt, cnt+p), the others -> the complement (their data is ignored)
+    const int dest = pass ? cnt + rank : ((cnt + p + lane - rank) & 63);
+    const int lo = __builtin_amdgcn_ds_permute(dest << 2, idx);
+    const int hi = __builtin_amdgcn_ds_permute(dest << 2, (int)key_f2u(key));
+    const bool in = (unsigned int)(lane - cnt) < (unsigned int)p;
+    pnd = in ? (((u64)(unsigned int)hi << 32) | (unsigned int)lo) : pnd;
+    return cnt + p;
+  }
+};
+
+
+// exact kNN in the model's expanded form for the queries whose flag byte is set (the safety net of knn_filter.hip);
+// x_pm (B,N,C) point-major, xx (B,N), flag (B,N), idx (B,N,kout).  Implemented in knn.hip on knn_select_kernel.
+int launch_knn_flagged(const float *x_pm, const float *xx, const unsigned char *flag, int B, int N, int C, int k, int step,
+                       int kout, int64_t *idx, hipStream_t st);
+
+}  // namespace gcn

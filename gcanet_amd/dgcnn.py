@@ -30,11 +30,39 @@ def _knn_model(x, k1, k2, metric):
     return idx
 
 
-def knn(x, k1, k2):
+_KNN_WS = {}
+
+
+def knn_feature_pm(x_pm, k1, k2):
+    """`knn` on POINT-major features x_pm (B,N,C) f32, C in {32,64,128}: bf16 matrix-core prefilter + exact f32
+    re-rank (csrc/knn_filter.hip) -- bit-identical indices to `knn`.  Returns None when the shape is not served."""
+    B, N, C = x_pm.shape
+    lib = _lib.lib()
+    if not (x_pm.is_cuda and lib.gcn_knn_feature_supported(B, N, C, k2)):
+        return None
+    x_pm = x_pm.float().contiguous()
+    step = k2 // k1
+    kout = len(range(0, k2, step))
+    key = (B, N, C, x_pm.device)
+    if key not in _KNN_WS:            # one scratch buffer per shape and device (calls are stream-ordered)
+        _KNN_WS[key] = torch.empty(lib.gcn_knn_feature_ws_bytes(B, N, C), dtype=torch.uint8, device=x_pm.device)
+    idx = torch.empty(B, N, kout, dtype=torch.int64, device=x_pm.device)
+    with torch.cuda.device_of(x_pm):
+        _lib.call("gcn_knn_feature", _lib.ptr(x_pm), B, N, C, k1, k2, _lib.ptr(idx), _lib.ptr(_KNN_WS[key]),
+                  _lib.stream_of(x_pm), tag="knn_model[B=%d,C=%d,N=%d,k=%d]" % (B, C, N, k2))
+    return idx
+
+
+def knn(x, k1, k2, x_pm=None):
     """M4:30-47: x (B,C,N) -> idx (B,N,k1) int64: the k2 nearest in feature space (self included),
-    every (k2//k1)-th kept.  One fused kernel per call for the whole batch; the reference loops over the
-    batch in Python and materialises N x N per cloud.  Ties -> lowest index."""
+    every (k2//k1)-th kept.  One fused launch sequence per call for the whole batch; the reference loops over the
+    batch in Python and materialises N x N per cloud.  Ties -> lowest index.
+    x_pm: the same features point-major (B,N,C), when the caller already has them."""
     with torch.no_grad():
+        if x.is_cuda and x.dim() == 3 and _lib.lib().gcn_knn_feature_supported(x.shape[0], x.shape[2], x.shape[1], k2):
+            idx = knn_feature_pm(x.transpose(1, 2) if x_pm is None else x_pm, k1, k2)
+            if idx is not None:
+                return idx
         return _knn_model(x, k1, k2, 0)
 
 
@@ -543,12 +571,16 @@ class DGCNNEncoderGn(nn.Module):
             idx1, idx2, idx3 = [i.contiguous() for i in idxs]
         else:
             idx1 = knn_points_normals(x_cm, k, k) if self.mode == 5 else knn(x_cm, k, k)
-        x1, x1_cm = edge_conv_pm(x_pm, idx1, self.conv1._modules["0"].weight, self.bn1, self.dtype)
+        # feature-space kNN reads the point-major activations directly where csrc/knn_filter.hip serves the shape;
+        # otherwise the EdgeConv finish kernel also writes the channel-major copy the generic kNN kernels read
+        B_, N_ = x_pm.shape[0], x_pm.shape[1]
+        fast = bool(x_pm.is_cuda and _lib.lib().gcn_knn_feature_supported(B_, N_, 64, k))
+        x1, x1_cm = edge_conv_pm(x_pm, idx1, self.conv1._modules["0"].weight, self.bn1, self.dtype, want_cm=not fast)
         if idxs is None:
-            idx2 = knn(x1_cm, k, k)
-        x2, x2_cm = edge_conv_pm(x1, idx2, self.conv2._modules["0"].weight, self.bn2, self.dtype)
+            idx2 = knn_feature_pm(x1.detach(), k, k) if fast else knn(x1_cm, k, k)
+        x2, x2_cm = edge_conv_pm(x1, idx2, self.conv2._modules["0"].weight, self.bn2, self.dtype, want_cm=not fast)
         if idxs is None:
-            idx3 = knn(x2_cm, k, k)
+            idx3 = knn_feature_pm(x2.detach(), k, k) if fast else knn(x2_cm, k, k)
         x3, _ = edge_conv_pm(x2, idx3, self.conv3._modules["0"].weight, self.bn3, self.dtype, want_cm=False)
         self.last_idx = (idx1, idx2, idx3)
         x_features = torch.cat((x1, x2, x3), dim=2)                            # (B,N,256)

@@ -65,6 +65,22 @@ int gcn_knn_model(const float *x, int B, int C, int N, int k1, int k2, int metri
  * against itself (ref == query, k <= 64, nr >= 512). */
 long gcn_knn_tiles_ws_bytes(int B, int C, int N);
 
+/* Feature-space kNN of the in-model `knn` (models/dgcnn-hais-concat-direct-4.py:30-47) for C in {32,64,128} as a
+ * bf16 matrix-core PREFILTER + exact f32 re-rank (csrc/knn_filter.hip): same indices as gcn_knn_model(metric 0), bit
+ * for bit (ties -> lowest index), several times faster at N >= 1024.
+ *   x_pm (B,N,C) f32 POINT-major rows (the layout the fused EdgeConv already keeps), idx (B,N,kout) int64 as
+ *   gcn_knn_model; ws: gcn_knn_feature_ws_bytes(B,N,C) bytes of device scratch, 256-B aligned (B*N*N/8 bytes of
+ *   candidate bits dominate: 67 MB at B=8, N=8192).
+ * gcn_knn_feature_supported: 1 when the shape is served (C in {32,64,128}, N % 128 == 0, 1024 <= N <= 16384,
+ * k2 <= 64); other shapes use gcn_knn_model.
+ * gcn_knn_feature_stats (diagnostics, synchronises): queries of the last call that fell back to the exact brute-force
+ * search, and the total number of prefilter candidates. */
+int gcn_knn_feature_supported(int B, int N, int C, int k2);
+long gcn_knn_feature_ws_bytes(int B, int N, int C);
+int gcn_knn_feature(const float *x_pm, int B, int N, int C, int k1, int k2, int64_t *idx, void *ws,
+                    void *stream);
+int gcn_knn_feature_stats(const void *ws, int B, int N, int C, long *flagged, long *candidates, void *stream);
+
 /* ------------------------------------------------------------ pointnet2_ops ---- */
 
 /* P2/_ext-src/src/ball_query.cpp:10-33 `ball_query(new_xyz, xyz, radius, nsample)`.

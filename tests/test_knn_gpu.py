@@ -260,3 +260,62 @@ def test_feature_knn_k_up_to_128_on_matrix_cores(dev, B, C, N, k1, k2):
         idx = dgcnn.knn(x.to(dev), k1, k2).cpu().numpy()
         ref = oracle.knn_model(x.numpy(), k1, k2, metric=0)
         np.testing.assert_array_equal(idx, ref)
+
+
+# ------------------------------------------------------------------ feature-space kNN: bf16 prefilter + exact re-rank
+def _feature_cloud(kind, B, C, N, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, C, N, generator=g)
+    if kind == "relu":                   # post-activation-like: mostly positive, a common offset
+        x = torch.nn.functional.leaky_relu(x + 0.5, 0.2)
+    elif kind == "offset":               # tiny spread around a large mean: the reference's own f32 noise decides
+        x = x * 0.05 + 4.0               # the order -> the a-posteriori check fails and the exhaustive path runs
+    elif kind == "dups":                 # exact duplicates: exact key ties straddling the k-th place
+        x[:, :, N // 2:] = x[:, :, :N // 2]
+    elif kind == "clusters":             # tight clusters of ~40 points: the k-th neighbour is far beyond the first few
+        centres = torch.randn(B, C, N // 40 + 1, generator=g) * 3
+        x = centres[:, :, torch.arange(N) // 40] + 0.01 * x
+    return x
+
+
+@pytest.mark.parametrize("kind,C,N,k1,k2", [
+    ("normal", 64, 1024, 16, 16), ("normal", 32, 2048, 20, 20), ("relu", 64, 4096, 33, 33), ("normal", 128, 2048, 64, 64),
+    ("normal", 64, 2048, 8, 64), ("dups", 64, 2048, 64, 64), ("dups", 32, 1024, 7, 7), ("offset", 64, 1024, 16, 16),
+    ("clusters", 64, 2048, 64, 64), ("normal", 64, 1152, 10, 10)])
+def test_knn_feature_prefilter_matches_exact_kernel_and_oracle(dev, kind, C, N, k1, k2):
+    """csrc/knn_filter.hip (bf16 matrix-core prefilter + exact f32 re-rank + exhaustive fallback) returns the SAME
+    indices as the exact matrix-core kernel (csrc/knn.hip) and as the CPU oracle, whatever the data does to the
+    prefilter: duplicates (exact ties -> lowest index), clusters, and clouds whose order is decided by the reference's
+    own f32 rounding (every query then takes the exhaustive path)."""
+    import ctypes
+    from gcanet_amd import _lib, dgcnn
+    x = _feature_cloud(kind, 2, C, N, 11 + C + N)
+    xd = x.to(dev)
+    assert _lib.lib().gcn_knn_feature_supported(2, N, C, k2) == 1
+    new = dgcnn.knn_feature_pm(xd.transpose(1, 2).contiguous(), k1, k2)
+    old = dgcnn._knn_model(xd, k1, k2, 0)
+    assert torch.equal(new, old)
+    np.testing.assert_array_equal(new.cpu().numpy(), oracle.knn_model(x.numpy(), k1, k2, 0))
+    assert torch.equal(dgcnn.knn(xd, k1, k2), old)                      # the drop-in entry takes the same path
+    fl, ca = ctypes.c_long(0), ctypes.c_long(0)
+    ws = dgcnn._KNN_WS[(2, N, C, xd.device)]
+    _lib.call("gcn_knn_feature_stats", _lib.ptr(ws), 2, N, C, ctypes.addressof(fl), ctypes.addressof(ca), _lib.stream_of(xd))
+    if kind in ("normal", "relu"):
+        assert fl.value <= 2, "the prefilter should prove (nearly) every query of well-spread data"
+        assert ca.value / (2 * N) < 6 * k2 + 64
+    if kind == "offset":
+        assert fl.value > 0, "this cloud is meant to exercise the exhaustive path"
+
+
+def test_knn_feature_unsupported_shapes_use_the_exact_kernel(dev):
+    from gcanet_amd import _lib, dgcnn
+    lib = _lib.lib()
+    assert lib.gcn_knn_feature_supported(2, 1000, 64, 16) == 0           # N % 128
+    assert lib.gcn_knn_feature_supported(2, 2048, 64, 80) == 0           # k > 64
+    assert lib.gcn_knn_feature_supported(2, 2048, 48, 16) == 0           # channel count
+    assert dgcnn.knn_feature_pm(torch.randn(2, 1000, 64, device=dev), 16, 16) is None
+    with pytest.raises(RuntimeError, match="unsupported shape"):
+        idx = torch.empty(2, 1000, 16, dtype=torch.int64, device=dev)
+        ws = torch.empty(1 << 20, dtype=torch.uint8, device=dev)
+        _lib.call("gcn_knn_feature", _lib.ptr(torch.randn(2, 1000, 64, device=dev)), 2, 1000, 64, 16, 16, _lib.ptr(idx),
+                  _lib.ptr(ws), _lib.stream_of(idx))
