@@ -343,7 +343,8 @@ def main():
     pts, nrm = synth_clouds(range(rank * B, rank * B + B), N, dev)
 
     from gcanet_amd.layers import CastCache
-    casts = CastCache(model)             # bf16 weight copies: one multi-tensor cast per step instead of one per layer
+    # bf16 weight copies (in the GEMM kernel's padded operand layout): one multi-tensor cast per step, not one per layer
+    casts = CastCache(model, pad_k={model.conv3.weight: (model.conv3.weight.shape[1] + 15) // 16 * 16})
 
     def step():
         dp.zero_grad()

@@ -1,0 +1,468 @@
+// gemm.hip -- the per-point 1x1 convolutions of GCANet's heads (Conv1d(kernel 1) on (B,C,N) tensors,
+// models/dgcnn-hais-concat-direct-4.py:556-603,644-699,713: 1280->512->256, 256->256->{10,22}, 832->256->64, 262->128,
+// 256->1024) as bf16 MFMA GEMMs on POINT-major activations, for gfx950.
+//
+//   out[m][n] = sum_k A[m][k] * W[n][k] (+ bias[n])      A (M,K) bf16 rows = points, W (N,K) bf16 = the Conv1d weight
+//
+// Both operands are contiguous along the contraction index, which is exactly the MFMA fragment shape (a lane holds 8
+// consecutive k of one row), so tiles go HBM -> LDS by LDS-DMA with no transposition: [rows][64 k] bf16 images,
+// 16-byte chunks XOR-swizzled on the source side (conflict-free ds_read_b128), double buffered.  The same kernel is
+// the input gradient (dX = dY . W: pass dY and W^T) -- and, with CONTRACT_ROWS, the weight gradient
+// dW[n][k] = sum_m dY[m][n] X[m][k], whose contraction index runs down the ROWS of both row-major operands: there the
+// fragments come from the same row-major LDS images through the hardware transpose read ds_read_b64_tr_b16.
+//
+// Epilogue (forward): bias, optional GroupNorm statistics -- per (cloud, group) sum and sum of squares of the f32
+// results, so the separate statistics pass over the output disappears -- and bf16 or f32 stores.  The product is
+// formed as D[n][m] (W on the MFMA row index) so that a lane owns ONE output row and four consecutive columns per
+// accumulator group: 8- or 16-byte stores instead of 2-byte ones.
+#include "common.h"
+
+#include <type_traits>
+
+namespace gcn {
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+struct GemmArgs {
+  const unsigned short *A;   // (M,K)
+  const unsigned short *W;   // (Np,K), Np = N rounded up to 32 (rows beyond N are zero)
+  const float *bias;         // (N) or null
+  void *out;                 // (M,N) bf16 or f32
+  double *gsum;              // (M/rows_per_cloud, G, 2) or null
+  double *part;              // (M/32, N/32, 2) per-wave partial sums when gsum is wanted
+  long M;
+  int N, Np, K, out_f32, rows_per_cloud, G;
+};
+
+__device__ __forceinline__ unsigned short gemm_f2bf(float f) {
+  __bf16 h = (__bf16)f;
+  return __builtin_bit_cast(unsigned short, h);
+}
+
+// BN = columns per workgroup (32, 64 or 128); workgroup = 128 rows, 4 waves.  BN = 128: waves 2 x 2, a wave owns
+// 64 rows x 64 columns (each LDS fragment feeds two MFMAs: with 32 x 128 per wave the kernel was bound by the LDS
+// reads of the four-times re-read W fragments); BN <= 64: waves 4 x 1, 32 rows x BN columns.
+// K is walked in steps of 32 through a ring of four LDS stages with THREE stages in flight (the layers are only
+// 4-26 steps deep: a two-buffer scheme pays a full memory latency per step).  Counted s_waitcnt vmcnt + raw
+// s_barrier: __syncthreads() would drain the ring.
+template <int BN>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs a) {
+  constexpr bool SQ = BN == 128;                // 2 x 2 waves
+  constexpr int RB = SQ ? 2 : 1;                // 32-row blocks per wave
+  constexpr int CB = SQ ? 2 : BN / 32;          // 32-column blocks per wave
+  constexpr int WCOLS = CB * 32;                // columns per wave
+  constexpr int NST = 4;
+  constexpr int A_BYTES = 128 * 64;             // 128 rows x 32 k x 2 B
+  constexpr int B_BYTES = BN * 64;
+  constexpr int ST_BYTES = A_BYTES + B_BYTES;
+  constexpr int WPW = BN >= 64 ? BN / 64 : 1;   // W pieces (16 rows x 64 B) per wave and stage; BN = 32: waves 2,3 repeat 0,1
+  constexpr int DPS = 2 + WPW;                  // DMA instructions per wave and stage (the vmcnt unit)
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+  const int lane = lane_id(), wave = wave_id();
+  const int lr = lane & 31, lh = lane >> 5;
+  const int wrow0 = SQ ? (wave >> 1) * 64 : wave * 32;       // this wave's first row / column inside the tile
+  const int wcol0 = SQ ? (wave & 1) * 64 : 0;
+  // Workgroups are dealt to the 8 XCDs round robin by linear id.  The column blocks of one 128-row tile all read the
+  // same A rows: give them to ONE XCD, back to back, so that the tile comes from HBM once and from that XCD's L2 for
+  // the other column blocks.
+  const int ncb = (a.N + BN - 1) / BN;
+  const long nrt = (a.M + 127) / 128;
+  const long id = blockIdx.x;
+  long rt;
+  int cbk;
+  if (nrt % 8 == 0) {
+    const long j = id >> 3;
+    cbk = (int)(j % ncb);
+    rt = (j / ncb) * 8 + (id & 7);
+  } else {
+    cbk = (int)(id % ncb);
+    rt = id / ncb;
+  }
+  const long m0 = rt * 128;
+  const int n0 = cbk * BN;
+  const int K = a.K;
+  const int ktiles = (K + 31) / 32;
+
+  // DMA pieces: 1 KiB = 16 rows x 64 B (4 chunks of 16 B); chunk swizzle (row/4)&3 on the source side
+  const int prow = lane >> 2, cs = lane & 3;
+  const unsigned short *arow[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (wave + i * 4) * 16 + prow;
+    long m = m0 + row;
+    if (m >= a.M) m = a.M - 1;
+    arow[i] = a.A + m * K + ((cs ^ ((row >> 2) & 3)) * 8);
+  }
+  const unsigned short *wrow[WPW];
+#pragma unroll
+  for (int i = 0; i < WPW; ++i) {
+    const int p = BN >= 64 ? wave + i * 4 : (wave & 1);
+    const int row = p * 16 + prow;
+    wrow[i] = a.W + (long)min(n0 + row, a.Np - 1) * K + ((cs ^ ((row >> 2) & 3)) * 8);
+  }
+  const int cl = cs ^ ((prow >> 2) & 3);                     // this lane's logical chunk (row/4 & 3 == prow/4 & 3)
+  auto issue = [&](int kt, int stg) {
+    const int kbase = kt * 32;
+    const bool ok = kbase + cl * 8 < K;                       // K % 16 == 0: the last step may hold two chunks only
+    unsigned char *dst = lds + stg * ST_BYTES;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      if (ok)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(arow[i] + kbase),
+                                         (__attribute__((address_space(3))) void *)(dst + (wave + i * 4) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < WPW; ++i)
+      if (ok)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wrow[i] + kbase),
+                                         (__attribute__((address_space(3))) void *)(dst + A_BYTES + (BN >= 64 ? wave + i * 4 : (wave & 1)) * 1024), 16, 0, 0);
+  };
+  // fragment byte offsets inside an image: row lr (of a 32-row block), k-step s (0,1), half lh; 64-B rows
+  unsigned int frag[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) frag[s] = (unsigned int)(lr * 64 + (((2 * s + lh) ^ ((lr >> 2) & 3)) << 4));
+
+  f32x16 acc[RB][CB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[rb][cb][i] = 0.f;
+
+#pragma unroll
+  for (int p = 0; p < NST - 1; ++p)
+    if (p < ktiles) issue(p, p);
+
+  auto ktile = [&](int kt, auto stgc) {
+    constexpr int STG = decltype(stgc)::value;
+    // stage kt must have landed: the younger stages in flight are min(NST-2, ktiles-1-kt)
+    const int later = min(NST - 2, ktiles - 1 - kt);
+    if (later >= 2) { if (DPS == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+    else if (later == 1) { if (DPS == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                            // every wave's share of stage kt is in; stage kt-1 is free
+    if (kt + NST - 1 < ktiles) issue(kt + NST - 1, (STG + NST - 1) % NST);
+    const unsigned char *ta = lds + STG * ST_BYTES + wrow0 * 64;
+    const unsigned char *tw = lds + STG * ST_BYTES + A_BYTES + wcol0 * 64;
+    const int ksteps = min(2, (K - kt * 32) >> 4);             // wave-uniform
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      if (s < ksteps) {
+        bf16x8 xf[RB], wf[CB];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) xf[rb] = *reinterpret_cast<const bf16x8 *>(ta + frag[s] + rb * 32 * 64);
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) wf[cb] = *reinterpret_cast<const bf16x8 *>(tw + frag[s] + cb * 32 * 64);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+          for (int cb = 0; cb < CB; ++cb)
+            acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cb], xf[rb], acc[rb][cb], 0, 0, 0);   // D[n][m]
+      }
+    }
+  };
+  for (int kt = 0; kt < ktiles; kt += 4) {
+    ktile(kt, std::integral_constant<int, 0>{});
+    if (kt + 1 < ktiles) ktile(kt + 1, std::integral_constant<int, 1>{});
+    if (kt + 2 < ktiles) ktile(kt + 2, std::integral_constant<int, 2>{});
+    if (kt + 3 < ktiles) ktile(kt + 3, std::integral_constant<int, 3>{});
+  }
+
+  // ---- epilogue.  Block (rb, cb): lane = output row m0 + wrow0 + rb*32 + lr; register i = column
+  // n0 + wcol0 + cb*32 + 8 (i>>2) + 4 lh + (i&3).  A lane's values are spread over its row in 8-byte pieces: stored
+  // straight from the registers, every store instruction would touch 32 rows (the 256->512 layer spent more time
+  // storing than multiplying).  The wave's tile goes through LDS instead (the stage ring is free now) and leaves as
+  // whole 16-byte chunks of consecutive rows: 1 KiB per store instruction.
+  __builtin_amdgcn_s_barrier();                               // every wave is done with the ring
+  const int esz = a.out_f32 ? 4 : 2;
+  const int rstride = WCOLS * esz + 16;                       // + 16 B: the column-wise writes below spread over the banks
+  unsigned char *tile = lds + wave * (RB * 32 * (WCOLS * 4 + 16));
+  const bool vec_ok = (a.N % (16 / esz)) == 0;                // rows are 16-byte aligned and chunks never straddle N
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const long mrow = m0 + wrow0 + rb * 32 + lr;
+    const bool mv = mrow < a.M;
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+      float bs1 = 0.f, bs2 = 0.f;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int nl = cb * 32 + 8 * g + 4 * lh;              // column inside the wave's tile
+        const int n = n0 + wcol0 + nl;
+        float4 v = {acc[rb][cb][4 * g], acc[rb][cb][4 * g + 1], acc[rb][cb][4 * g + 2], acc[rb][cb][4 * g + 3]};
+        if (a.bias) {
+          if (n + 3 < a.N && (a.N & 3) == 0) {
+            const float4 bq = *reinterpret_cast<const float4 *>(a.bias + n);
+            v.x += bq.x; v.y += bq.y; v.z += bq.z; v.w += bq.w;
+          } else {
+            v.x += n + 0 < a.N ? a.bias[n + 0] : 0.f;
+            v.y += n + 1 < a.N ? a.bias[n + 1] : 0.f;
+            v.z += n + 2 < a.N ? a.bias[n + 2] : 0.f;
+            v.w += n + 3 < a.N ? a.bias[n + 3] : 0.f;
+          }
+        }
+        if (a.gsum && mv) {
+          bs1 += (v.x + v.y) + (v.z + v.w);
+          bs2 = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, bs2))));
+        }
+        if (vec_ok) {
+          if (a.out_f32) {
+            *reinterpret_cast<float4 *>(tile + (rb * 32 + lr) * rstride + nl * 4) = v;
+          } else {
+            bf16x4 h = {(short)gemm_f2bf(v.x), (short)gemm_f2bf(v.y), (short)gemm_f2bf(v.z), (short)gemm_f2bf(v.w)};
+            *reinterpret_cast<bf16x4 *>(tile + (rb * 32 + lr) * rstride + nl * 2) = h;
+          }
+        } else if (mv) {                                      // narrow odd-width heads (10, 22, 3 columns): element stores
+          const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (n + e < a.N) {
+              if (a.out_f32) reinterpret_cast<float *>(a.out)[mrow * a.N + n + e] = vv[e];
+              else reinterpret_cast<unsigned short *>(a.out)[mrow * a.N + n + e] = gemm_f2bf(vv[e]);
+            }
+        }
+      }
+      if (a.gsum) {
+        // one partial per (32-row slab, 32-column block): f64 atomics on the (cloud, group) sums serialise at
+        // ~0.45 us per same-address add (2048 workgroups x 16: 100 us); gemm_stats_reduce_kernel folds the partials
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+          bs1 += __shfl_xor(bs1, o);
+          bs2 += __shfl_xor(bs2, o);
+        }
+        if (lane == 0 && n0 + wcol0 + cb * 32 < a.N) {
+          const long slab = (m0 + wrow0) / 32 + rb;
+          double *p = a.part + (slab * (a.N / 32) + ((n0 + wcol0) / 32 + cb)) * 2;
+          p[0] = (double)bs1;
+          p[1] = (double)bs2;
+        }
+      }
+    }
+  }
+  if (vec_ok) {
+    __builtin_amdgcn_wave_barrier();                          // same wave wrote the tile: in-order LDS queue
+    const int cpr = WCOLS * esz / 16;                         // 16-byte chunks per tile row (4 ... 32)
+    const int rpi = 64 / cpr;                                 // rows per store instruction
+    for (int r0 = 0; r0 < RB * 32; r0 += rpi) {
+      const int r = r0 + lane / cpr, ch = lane % cpr;
+      const int ncol = n0 + wcol0 + ch * (16 / esz);
+      const long mrow = m0 + wrow0 + r;
+      if (mrow < a.M && ncol < a.N) {
+        const uint4 d = *reinterpret_cast<const uint4 *>(tile + r * rstride + ch * 16);
+        *reinterpret_cast<uint4 *>(reinterpret_cast<unsigned char *>(a.out) + (mrow * a.N + ncol) * esz) = d;
+      }
+    }
+  }
+}
+
+// gsum[cloud][group][2] = sum of the partials of the cloud's row slabs and the group's column blocks
+__global__ __launch_bounds__(256) void gemm_stats_reduce_kernel(const double *__restrict__ part, double *__restrict__ gsum,
+                                                                int slabs_per_cloud, int nb32, int G) {
+  __shared__ double red[2][4];
+  const int cloud = blockIdx.x / G, grp = blockIdx.x % G;
+  const int bpg = nb32 / G;                                   // column blocks per group
+  const int total = slabs_per_cloud * bpg;
+  double s1 = 0.0, s2 = 0.0;
+  for (int e = threadIdx.x; e < total; e += 256) {
+    const int slab = e / bpg, cb = e % bpg;
+    const double *p = part + (((long)cloud * slabs_per_cloud + slab) * nb32 + grp * bpg + cb) * 2;
+    s1 += p[0];
+    s2 += p[1];
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    s1 += __shfl_xor(s1, o);
+    s2 += __shfl_xor(s2, o);
+  }
+  if (lane_id() == 0) { red[0][wave_id()] = s1; red[1][wave_id()] = s2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    gsum[(long)blockIdx.x * 2] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    gsum[(long)blockIdx.x * 2 + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  }
+}
+
+// ------------------------------------------------------------------ weight gradient: contraction over the rows
+// dW[n][k] = sum_m dY[m][n] X[m][k]   (dY (M,N) bf16, X (M,K) bf16, both row-major; dW (N,K) f32, accumulated with
+// atomics over the split of M).  Workgroup tile = 128 (n) x 128 (k); it walks its slice of M in steps of 64 rows:
+// the two [64 m][128] images are fetched by LDS-DMA as they lie in memory and read COLUMN-wise with
+// ds_read_b64_tr_b16 (per 16 lanes: a 4-row x 16-column block delivered column-major, i.e. 4 consecutive m per lane).
+struct WgradArgs {
+  const unsigned short *dY;  // (M,N)
+  const unsigned short *X;   // (M,K)
+  float *dW;                 // (N,K) f32, zeroed by the caller
+  long M;
+  int N, K, msplit;
+};
+
+typedef __attribute__((ext_vector_type(4))) short tr_v4i16;
+__device__ __forceinline__ bf16x4 lds_tr_read(unsigned int addr) {
+  const tr_v4i16 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr_v4i16 *)(uintptr_t)addr);
+  return bf16x4{r[0], r[1], r[2], r[3]};
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_wgrad_bf16_kernel(WgradArgs a) {
+  // images: [64 rows m][128 cols] bf16 = 256-B rows, 16 KB each, two buffers of (dY, X)
+  constexpr int IMG = 64 * 256;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+  const int lane = lane_id(), wave = wave_id();
+  const int n0 = blockIdx.x * 128, k0 = blockIdx.y * 128;
+  const long mper = ((a.M + a.msplit - 1) / a.msplit + 63) / 64 * 64;
+  const long mb = (long)blockIdx.z * mper;
+  const long me = mb + mper < a.M ? mb + mper : a.M;
+  if (mb >= me) return;
+  const int steps = (int)((me - mb + 63) / 64);
+
+  // DMA: 1 KiB = 4 rows x 256 B: 16 pieces per image; lane -> row p*4 + lane/16, chunk lane%16 (no swizzle: the
+  // transposed reads below take 4-row x 16-column blocks)
+  auto issue = [&](int st, int buf) {
+    const long mrow0 = mb + (long)st * 64;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int p = wave + i * 4;
+      const int row = p * 4 + (lane >> 4);
+      const int ch = lane & 15;
+      long m = mrow0 + row;
+      const bool ok = m < me;
+      if (!ok) m = me - 1;
+      // columns beyond N / K and rows beyond the slice: clamped reads whose products are masked out at the end
+      const int ncol = min(n0 + ch * 8, a.N - 8), kcol = min(k0 + ch * 8, a.K - 8);
+      const unsigned short *sy = a.dY + m * a.N + ncol;
+      const unsigned short *sx = a.X + m * a.K + kcol;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)sy,
+                                       (__attribute__((address_space(3))) void *)(lds + buf * 2 * IMG + p * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)sx,
+                                       (__attribute__((address_space(3))) void *)(lds + buf * 2 * IMG + IMG + p * 1024), 16, 0, 0);
+    }
+  };
+  // wave tile: 64 (n) x 64 (k): waves 2 x 2; MFMA D[n][k]: A = dY^T fragment (row n, 8 consecutive m), B = X^T fragment
+  const int wn = (wave >> 1) * 64, wk = (wave & 1) * 64;
+  // transposed read: group g = lane/16 of 16 lanes reads the block rows [8*(g/2).. +4 (+4 for the second read)] x
+  // columns [16*(g%2) .. +16) of a 32-column operand block; lane i = 4q+p of the group supplies row q, columns 4p..4p+3
+  const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+  const unsigned int tr_base = (unsigned int)((8 * (g >> 1) + q) * 256 + (16 * (g & 1) + 4 * pp) * 2);
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int st = 0; st < steps; ++st) {
+    const int buf = st & 1;
+    if (st + 1 < steps) issue(st + 1, buf ^ 1);
+    const unsigned int by = (unsigned int)(buf * 2 * IMG), bx = by + IMG;
+    const long mrow0 = mb + (long)st * 64;
+    const int mvalid = (int)(me - mrow0 < 64 ? me - mrow0 : 64);
+#pragma unroll
+    for (int ms = 0; ms < 4; ++ms) {                          // 16 rows m per MFMA k-step
+      if (ms * 16 < mvalid) {
+        bf16x8 fy[2], fx[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const unsigned int ry = by + tr_base + (unsigned int)(ms * 16 * 256 + (wn + t * 32) * 2);
+          const unsigned int rx = bx + tr_base + (unsigned int)(ms * 16 * 256 + (wk + t * 32) * 2);
+          const bf16x4 y0 = lds_tr_read(ry), y1 = lds_tr_read(ry + 4 * 256);
+          const bf16x4 x0 = lds_tr_read(rx), x1 = lds_tr_read(rx + 4 * 256);
+          fy[t] = bf16x8{y0[0], y0[1], y0[2], y0[3], y1[0], y1[1], y1[2], y1[3]};
+          fx[t] = bf16x8{x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+        }
+        // rows beyond the slice were clamped copies: zero their contribution (m index = ms*16 + 8*(lane/32) + e)
+        if (mvalid < 64) {
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if (ms * 16 + 8 * (lane >> 5) + e >= mvalid) fy[t][e] = 0;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fy[i], fx[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  // D[n][k]: lane column = k (lane%32), register e -> row n = 8 (e>>2) + 4 (lane/32) + (e&3)
+  const int lr = lane & 31, lh = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int kk = k0 + wk + j * 32 + lr;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int n = n0 + wn + i * 32 + 8 * (e >> 2) + 4 * lh + (e & 3);
+        if (n < a.N && kk < a.K) atomicAdd(a.dW + (long)n * a.K + kk, acc[i][j][e]);
+      }
+    }
+}
+
+}  // namespace gcn
+
+using namespace gcn;
+
+GCN_EXPORT long gcn_gemm_stats_ws_bytes(long M, int N) { return M < 0 || N < 1 ? -1 : (long)sizeof(double) * 2 * ((M + 31) / 32) * ((N + 31) / 32); }
+
+GCN_EXPORT int gcn_gemm_bf16(const void *A, const void *W, const float *bias, void *out, int out_f32, long M, int N,
+                             int Np, int K, double *gsum, void *stats_ws, int rows_per_cloud, int G, void *stream) {
+  GCN_REQUIRE(A && W && out, "gcn_gemm_bf16: null pointer");
+  GCN_REQUIRE(Np >= N, "gcn_gemm_bf16: W must hold Np >= N rows");
+  GCN_REQUIRE(M >= 0 && N >= 1 && K >= 16 && K % 16 == 0, "gcn_gemm_bf16: need K %% 16 == 0 (pad with zeros), got M=%ld N=%d K=%d", M, N, K);
+  GCN_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)out & 15) == 0, "gcn_gemm_bf16: 16-byte aligned operands");
+  GCN_REQUIRE(out_f32 == 0 || out_f32 == 1, "gcn_gemm_bf16: out_f32 must be 0 or 1");
+  if (gsum) {
+    GCN_REQUIRE(stats_ws, "gcn_gemm_bf16: gsum needs stats_ws (gcn_gemm_stats_ws_bytes(M, N) bytes)");
+    GCN_REQUIRE(G >= 1 && N % G == 0 && (N / G) % 32 == 0 && rows_per_cloud >= 128 && rows_per_cloud % 128 == 0 && M % rows_per_cloud == 0,
+                "gcn_gemm_bf16: fused GroupNorm statistics need (N/G) %% 32 == 0 and rows_per_cloud %% 128 == 0");
+  }
+  if (M == 0) return GCN_OK;
+  hipStream_t st = (hipStream_t)stream;
+  GemmArgs a{};
+  a.A = (const unsigned short *)A; a.W = (const unsigned short *)W; a.bias = bias; a.out = out; a.gsum = gsum;
+  a.M = M; a.N = N; a.Np = Np; a.K = K; a.out_f32 = out_f32; a.rows_per_cloud = rows_per_cloud; a.G = G;
+  a.part = (double *)stats_ws;
+  const int mblocks = (int)((M + 127) / 128);
+#define GEMM_LAUNCH(BNV)                                                                                           \
+  {                                                                                                                 \
+    constexpr int RING = 4 * (128 * 64 + BNV * 64);                                                                 \
+    constexpr int EPI = BNV == 128 ? 4 * 64 * (64 * 4 + 16) : 4 * 32 * (BNV * 4 + 16);                              \
+    constexpr int LDSB = RING > EPI ? RING : EPI;                                                                   \
+    GCN_HIP(hipFuncSetAttribute((const void *)gemm_bf16_kernel<BNV>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB)); \
+    gemm_bf16_kernel<BNV><<<mblocks * ((N + BNV - 1) / BNV), 256, LDSB, st>>>(a);                                \
+  }
+  if (N > 64) GEMM_LAUNCH(128) else if (N > 32) GEMM_LAUNCH(64) else GEMM_LAUNCH(32)
+#undef GEMM_LAUNCH
+  int rc = check_launch("gemm_bf16_kernel");
+  if (rc || !gsum) return rc;
+  gemm_stats_reduce_kernel<<<(int)(M / rows_per_cloud) * G, 256, 0, st>>>(a.part, gsum, rows_per_cloud / 32, N / 32, G);
+  return check_launch("gemm_stats_reduce_kernel");
+}
+
+GCN_EXPORT int gcn_gemm_wgrad_bf16(const void *dY, const void *X, long M, int N, int K, float *dW, void *stream) {
+  GCN_REQUIRE(dY && X && dW, "gcn_gemm_wgrad_bf16: null pointer");
+  GCN_REQUIRE(M >= 1 && N >= 8 && K >= 8 && N % 8 == 0 && K % 8 == 0, "gcn_gemm_wgrad_bf16: need N %% 8 == 0 and K %% 8 == 0, got N=%d K=%d", N, K);
+  GCN_REQUIRE(((uintptr_t)dY & 15) == 0 && ((uintptr_t)X & 15) == 0, "gcn_gemm_wgrad_bf16: 16-byte aligned operands");
+  hipStream_t st = (hipStream_t)stream;
+  GCN_HIP(hipMemsetAsync(dW, 0, sizeof(float) * (size_t)N * K, st));
+  WgradArgs a{};
+  a.dY = (const unsigned short *)dY; a.X = (const unsigned short *)X; a.dW = dW; a.M = M; a.N = N; a.K = K;
+  const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
+  int split = (256 + tiles - 1) / tiles;                     // ~256 workgroups (every split adds N*K float atomics)
+  const long maxsplit = (M + 511) / 512;                     // at least 512 rows each
+  if (split > maxsplit) split = (int)maxsplit;
+  if (split < 1) split = 1;
+  a.msplit = split;
+  const int LDSB = 2 * 2 * 64 * 256;
+  GCN_HIP(hipFuncSetAttribute((const void *)gemm_wgrad_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
+  gemm_wgrad_bf16_kernel<<<dim3((N + 127) / 128, (K + 127) / 128, split), 256, LDSB, st>>>(a);
+  return check_launch("gemm_wgrad_bf16_kernel");
+}

@@ -355,6 +355,19 @@ GCN_EXPORT int gcn_gn_fwd(const void *x, int dtype, const float *gamma, const fl
   return check_launch("gn_fwd");
 }
 
+GCN_EXPORT int gcn_gn_apply(const void *x, int dtype, const double *gsum, const float *gamma, const float *beta, int B,
+                            int N, int C, int G, float eps, int relu, void *y, float *mean_rstd, void *stream) {
+  int rc = gn_check("gcn_gn_apply", B, N, C, G, dtype);
+  if (rc) return rc;
+  GCN_REQUIRE(x && gsum && gamma && beta && y, "gcn_gn_apply: null pointer");
+  if (B == 0) return GCN_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int g2 = (int)(((long)N * C / 4 + 255) / 256 > 2048 ? 2048 : ((long)N * C / 4 + 255) / 256);
+  if (dtype == 1) gn_apply_kernel<true><<<dim3(g2, B), 256, 0, st>>>(x, gsum, gamma, beta, N, C, G, eps, relu, y, mean_rstd);
+  else gn_apply_kernel<false><<<dim3(g2, B), 256, 0, st>>>(x, gsum, gamma, beta, N, C, G, eps, relu, y, mean_rstd);
+  return check_launch("gn_apply_kernel");
+}
+
 GCN_EXPORT int gcn_gn_bwd(const void *dy, const void *x, int dtype, const float *gamma, const float *beta,
                           const float *mean_rstd, int B, int N, int C, int G, int relu, void *dx, float *dgamma,
                           float *dbeta, double *s_ws, void *stream) {

@@ -756,7 +756,7 @@ class PrimitivesEmbeddingDGCNGn(nn.Module):
         Activations are point-major (B,N,C) end to end; the reference's (B,C,N) Conv1d tensors are the same
         values transposed.  conv1 on cat[x4 repeated, x_features] (M4:510-511,644) is evaluated as
         W[:, :1024].x4 (once per cloud) + W[:, 1024:].x_features -- identical, 5x fewer FLOPs."""
-        from .layers import conv1x1, group_norm_relu, linear_pm, param_normalise
+        from .layers import conv1x1, conv1x1_gn_relu, group_norm_relu, linear_pm, param_normalise
         B, N, _ = points.shape
         pts = torch.cat([points, normals], dim=-1).contiguous() if self.mode == 5 else points.contiguous()   # (B,N,6)
         pts_cm = pts.transpose(1, 2).contiguous()
@@ -764,11 +764,11 @@ class PrimitivesEmbeddingDGCNGn(nn.Module):
         w1 = self.conv1.weight.flatten(1)
         h = linear_pm(xf, w1[:, 1024:]) + F.linear(x4, w1[:, :1024], self.conv1.bias).unsqueeze(1)
         x = group_norm_relu(h, self.bn1)
-        x_all = group_norm_relu(conv1x1(x, self.conv2), self.bn2)                             # (B,N,256)
-        x_type = group_norm_relu(conv1x1(x_all, self.mlp_prim_prob1), self.bn_prim_prob1)
+        x_all = conv1x1_gn_relu(x, self.conv2, self.bn2)                                      # (B,N,256)
+        x_type = conv1x1_gn_relu(x_all, self.mlp_prim_prob1, self.bn_prim_prob1)
         type_forgroup = conv1x1(x_type, self.mlp_prim_prob2)                                  # (B,N,P)
         type_per_point = F.log_softmax(type_forgroup.float(), dim=-1) if "r" in self.loss_class else type_forgroup
-        x_para = group_norm_relu(conv1x1(x_all, self.mlp_param_prob1), self.bn_param_prob1)
+        x_para = conv1x1_gn_relu(x_all, self.mlp_param_prob1, self.bn_param_prob1)
         p = conv1x1(x_para, self.mlp_param_prob2)
         if p.shape[-1] == 22 and p.is_cuda:               # one kernel each way instead of the slice/norm/div/cat chain
             param_per_point = param_normalise(p)
@@ -790,10 +790,14 @@ class PrimitivesEmbeddingDGCNGn(nn.Module):
             normal_feature = grouped_block(ef, self.conv_normal[0].weight, self.bn_normal.weight, self.bn_normal.bias, 2,
                                            self.bn_normal.eps, 0.2, self.dtype, pm_out=True)   # (B,N,64)
         x = torch.cat([x_all, x_type, x_para, normal_feature.to(x_all.dtype)], dim=2)          # (B,N,832)
-        x = group_norm_relu(conv1x1(x, self.mlp_seg_prob1), self.bn_seg_prob1)
+        x = conv1x1_gn_relu(x, self.mlp_seg_prob1, self.bn_seg_prob1)
         output_feats = conv1x1(x, self.mlp_seg_prob2).float()                                  # (B,N,emb)
-        feat_plus = torch.cat([x_all, pts.to(x_all.dtype)], dim=2)                             # (B,N,262)
-        feat_plus = group_norm_relu(conv1x1(feat_plus, self.conv3), self.bn3)                  # (B,N,128)
+        # (B,N,262) -> zero columns up to a multiple of 16: the GEMM kernel's k-step (the cat copies anyway)
+        kin = x_all.shape[2] + pts.shape[2]
+        parts = [x_all, pts.to(x_all.dtype)]
+        if pts.is_cuda and kin % 16:
+            parts.append(torch.zeros(B, N, (kin + 15) // 16 * 16 - kin, dtype=x_all.dtype, device=pts.device))
+        feat_plus = conv1x1_gn_relu(torch.cat(parts, dim=2), self.conv3, self.bn3)             # (B,N,128)
         semantic_scores = type_forgroup.reshape(-1, type_forgroup.shape[-1])
         pt_offsets = self.offset_pred_block(pts[:, :, 0:3], feat_plus.float(), output_feats, pm_out=True,
                                             topk_idx=topk_idx)

@@ -1,6 +1,12 @@
 """Point-major building blocks for the per-point heads: activations live as (B, N, C) so that one point
 is one contiguous row (what both the row gathers and the per-point GEMMs want).  GroupNorm(+ReLU) runs
-through csrc/gn.hip; the 1x1 convolutions are plain library GEMMs (torch.nn.functional.linear)."""
+through csrc/gn.hip.  The 1x1 convolutions (M4:556-603,644-699,713) are bf16 GEMMs: csrc/gemm.hip (hand-written MFMA
+kernels: forward with fused bias + GroupNorm statistics, weight gradient through the hardware transpose read) where
+that kernel is at least as fast as the library -- output widths <= 128 and the 256->256 layers whose statistics pass
+it absorbs -- and torch.nn.functional.linear (hipBLASLt) for the wide layers, where csrc/gemm.hip reaches 0.6-0.8x of
+the library's speed (tools/gemm_bench.py).  GCANET_GEMM=own|lib forces one or the other everywhere."""
+import os
+
 import torch
 
 from . import _lib
@@ -25,7 +31,7 @@ class GroupNormReLUFunction(torch.autograd.Function):
     """y = [ReLU](GroupNorm(x)) for x (B,N,C) f32 or bf16 (output dtype = input dtype)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, groups, eps, relu):
+    def forward(ctx, x, gamma, beta, groups, eps, relu, gsum=None):
         _lib.require_cuda(x)
         assert x.dim() == 3 and x.dtype in (torch.float32, torch.bfloat16)
         x = x.contiguous()
@@ -34,9 +40,13 @@ class GroupNormReLUFunction(torch.autograd.Function):
         ga, be = gamma.float().contiguous(), beta.float().contiguous()
         y = torch.empty_like(x)
         mean_rstd = torch.empty(B, groups, 2, dtype=torch.float32, device=x.device)
-        ws = torch.empty(B, groups, 2, dtype=torch.float64, device=x.device)
-        _run("gcn_gn_fwd", x, _lib.ptr(x), dt, _lib.ptr(ga), _lib.ptr(be), B, N, C, groups, float(eps), int(relu),
-             _lib.ptr(y), _lib.ptr(mean_rstd), _lib.ptr(ws))
+        if gsum is not None:          # statistics came out of the producing GEMM's epilogue (csrc/gemm.hip)
+            _run("gcn_gn_apply", x, _lib.ptr(x), dt, _lib.ptr(gsum), _lib.ptr(ga), _lib.ptr(be), B, N, C, groups, float(eps),
+                 int(relu), _lib.ptr(y), _lib.ptr(mean_rstd))
+        else:
+            ws = torch.empty(B, groups, 2, dtype=torch.float64, device=x.device)
+            _run("gcn_gn_fwd", x, _lib.ptr(x), dt, _lib.ptr(ga), _lib.ptr(be), B, N, C, groups, float(eps), int(relu),
+                 _lib.ptr(y), _lib.ptr(mean_rstd), _lib.ptr(ws))
         ctx.save_for_backward(x, ga, be, mean_rstd)
         ctx.cfg = (groups, relu, dt)
         return y
@@ -51,7 +61,7 @@ class GroupNormReLUFunction(torch.autograd.Function):
         ws, dgamma, dbeta = _acc_buffers(B * groups * 2, C, x.device)
         _run("gcn_gn_bwd", x, _lib.ptr(dy), _lib.ptr(x), dt, _lib.ptr(ga), _lib.ptr(be), _lib.ptr(mean_rstd), B, N, C,
              groups, int(relu), _lib.ptr(dx), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ws))
-        return dx, dgamma, dbeta, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None
 
 
 def group_norm_relu(x, gn, relu=True):
@@ -78,12 +88,26 @@ class CastCache:
     looks a weight up by identity and version; anything not registered (weight slices, ...) is cast as before."""
     _live = None
 
-    def __init__(self, module, dtype=torch.bfloat16):
+    def __init__(self, module, dtype=torch.bfloat16, pad_k=None):
+        """pad_k: {parameter: Kpad} -- 1x1-conv weights whose GEMM input is zero-padded to Kpad columns."""
         self.params = [p for p in module.parameters() if p.dtype == torch.float32 and p.dim() >= 1]
-        self.copies = [torch.empty_like(p, dtype=dtype) for p in self.params]
         self.dtype = dtype
         self.version = {}
         self.by_id = {id(p): i for i, p in enumerate(self.params)}
+        pad_k = {id(p): k for p, k in (pad_k or {}).items()}
+        # 1x1-conv weights (Cout, Cin, 1[, 1]) live inside a zeroed (Cout rounded up to 32, Cin rounded up to 16 or
+        # pad_k) bf16 image, the operand layout of csrc/gemm.hip; `copies` are views of it, so the one multi-tensor copy
+        # per step fills the padded images as well
+        self.padded, self.copies = {}, []
+        for p in self.params:
+            if p.dim() >= 2 and p[0].numel() == p.shape[1]:
+                n, k = p.shape[0], p.shape[1]
+                kp = max(pad_k.get(id(p), 0), (k + 15) // 16 * 16)
+                img = torch.zeros((n + 31) // 32 * 32, kp, dtype=dtype, device=p.device)
+                self.padded[id(p)] = img
+                self.copies.append(img[:n, :k].view(p.shape) if (kp == k) else img[:n, :k].unflatten(1, p.shape[1:]))
+            else:
+                self.copies.append(torch.empty_like(p, dtype=dtype))
 
     def refresh(self):
         """Call once per step after the optimizer update (or before the first forward)."""
@@ -103,16 +127,76 @@ class CastCache:
         if (i is None or c.version.get(id(base)) != base._version or base.numel() != t.numel() or not t.is_contiguous()
                 or t.storage_offset() != base.storage_offset()):      # only whole-tensor reshapes of the parameter
             return None
-        return c.copies[i].view(t.shape)
+        cp = c.copies[i]
+        return cp.view(t.shape) if cp.is_contiguous() else cp.reshape(t.shape)
+
+    @staticmethod
+    def lookup_padded(t, kx):
+        """The zero-padded (Np, kx) image of 1x1-conv weight `t` (a flatten(1) view of a registered parameter), or None."""
+        c = CastCache._live
+        if c is None:
+            return None
+        base = t._base if t._base is not None else t
+        img = c.padded.get(id(base))
+        if img is None or c.version.get(id(base)) != base._version or img.shape[1] != kx or base.numel() != t.numel():
+            return None
+        return img
+
+
+def _own_gemm(M, N, K, fused_gn):
+    """Policy: does csrc/gemm.hip serve this (M rows, N outputs, K inputs) layer?  (tools/gemm_bench.py, M = 65536)"""
+    mode = os.environ.get("GCANET_GEMM", "auto")
+    if mode == "lib" or K % 16 != 0 or M < 128:
+        return False
+    if mode == "own":
+        return True
+    return N <= 128 or (fused_gn and N * K <= 256 * 256)
+
+
+def gemm_own(x2, wq, bias, N, out_f32=False, gn=None, rows_per_cloud=0):
+    """out (M,N) = x2 (M,K) bf16 @ wq (Np,K)^T bf16 + bias through csrc/gemm.hip.  gn = number of groups: also returns
+    the (M/rows_per_cloud, gn, 2) f64 sums / sums of squares of the f32 results (for gcn_gn_apply)."""
+    M, K = x2.shape
+    out = torch.empty(M, N, dtype=torch.float32 if out_f32 else torch.bfloat16, device=x2.device)
+    gsum = ws = None
+    if gn:
+        gsum = torch.empty(M // rows_per_cloud, gn, 2, dtype=torch.float64, device=x2.device)
+        ws = torch.empty(_lib.lib().gcn_gemm_stats_ws_bytes(M, N), dtype=torch.uint8, device=x2.device)
+    with torch.cuda.device_of(x2):
+        _lib.call("gcn_gemm_bf16", _lib.ptr(x2), _lib.ptr(wq), _lib.ptr(bias), _lib.ptr(out), int(out_f32), M, N, wq.shape[0], K,
+                  _lib.ptr(gsum), _lib.ptr(ws), rows_per_cloud if gn else 0, gn or 0, _lib.stream_of(x2))
+    return out, gsum
 
 
 class LinearPMFunction(torch.autograd.Function):
     """y = x @ W^T + b on point-major rows with a split-K weight gradient (see tall_skinny_tn).
-    Runs in the autocast dtype (bf16 under torch.autocast, as the plain F.linear would)."""
+    Runs in the autocast dtype (bf16 under torch.autocast, as the plain F.linear would).  With gn_groups > 0 the
+    second output is the GroupNorm statistics of y (csrc/gemm.hip epilogue) for group_norm_relu(..., gsum=)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, gn_groups=0):
         dt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else x.dtype
+        N, K = weight.shape
+        Kx = x.shape[-1]                  # may exceed K: trailing zero columns the caller added to reach K % 16 == 0
+        M = x.numel() // Kx
+        rows = x.shape[-2] if x.dim() >= 2 else M
+        fused = gn_groups > 0 and (N // max(gn_groups, 1)) % 32 == 0 and rows % 128 == 0
+        ctx.own = bool(x.is_cuda and dt == torch.bfloat16 and _own_gemm(M, N, Kx, fused))
+        if ctx.own:
+            xc = x.to(dt).contiguous()
+            wq = CastCache.lookup_padded(weight, Kx)
+            if wq is None:                # not registered (or stale): pack here
+                wq = torch.zeros((N + 31) // 32 * 32, Kx, dtype=dt, device=x.device)
+                wq[:N, :K] = weight
+            y, gsum = gemm_own(xc.view(M, Kx), wq, None if bias is None else bias.float(), N, gn=gn_groups if fused else None,
+                               rows_per_cloud=rows)
+            ctx.save_for_backward(xc, wq)
+            ctx.has_bias, ctx.in_dtypes, ctx.nk = bias is not None, (x.dtype, weight.dtype), (N, K)
+            ctx.mark_non_differentiable(*([gsum] if gsum is not None else []))
+            y = y.view(*x.shape[:-1], N)
+            return (y, gsum) if gn_groups > 0 else y
+        if Kx != K:
+            x = x[..., :K]
         xc = x.to(dt)
         wc = (CastCache.lookup(weight, dt) if weight.dtype != dt else None)
         wc = weight.to(dt) if wc is None else wc
@@ -123,19 +207,36 @@ class LinearPMFunction(torch.autograd.Function):
         ctx.save_for_backward(xc, wc)
         ctx.has_bias = bias is not None
         ctx.in_dtypes = (x.dtype, weight.dtype)
+        ctx.kx = Kx
         with torch.autocast("cuda", enabled=False):
-            return torch.nn.functional.linear(xc, wc, bc)
+            y = torch.nn.functional.linear(xc, wc, bc)
+        return (y, None) if gn_groups > 0 else y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _gsum=None):
         xc, wc = ctx.saved_tensors
         dy = dy.to(xc.dtype).contiguous()
+        rows = dy.reshape(-1, dy.shape[-1])
         with torch.autocast("cuda", enabled=False):
-            dx = (dy @ wc).to(ctx.in_dtypes[0])
-            rows = dy.reshape(-1, dy.shape[-1])
-            dw = tall_skinny_tn(rows, xc.reshape(-1, xc.shape[-1]), out_dtype=ctx.in_dtypes[1])
+            if ctx.own:
+                N, K = ctx.nk
+                Kx = xc.shape[-1]
+                dx = (dy @ wc[:N]).to(ctx.in_dtypes[0])                   # (.., Kx); the zero-weight padding columns get 0
+                if N % 8 == 0:                                            # csrc/gemm.hip: transpose-read weight gradient
+                    dwf = torch.empty(N, Kx, dtype=torch.float32, device=dy.device)
+                    with torch.cuda.device_of(dy):
+                        _lib.call("gcn_gemm_wgrad_bf16", _lib.ptr(rows), _lib.ptr(xc), rows.shape[0], N, Kx, _lib.ptr(dwf),
+                                  _lib.stream_of(dy))
+                    dw = dwf[:, :K].to(ctx.in_dtypes[1])
+                else:
+                    dw = tall_skinny_tn(rows, xc.reshape(-1, Kx), out_dtype=ctx.in_dtypes[1])[:, :K]
+            else:
+                dx = (dy @ wc).to(ctx.in_dtypes[0])
+                if ctx.kx != wc.shape[1]:
+                    dx = torch.nn.functional.pad(dx, (0, ctx.kx - wc.shape[1]))
+                dw = tall_skinny_tn(rows, xc.reshape(-1, xc.shape[-1]), out_dtype=ctx.in_dtypes[1])
             db = rows.sum(0, dtype=torch.float32) if ctx.has_bias else None   # f32 accumulation, no f32 copy of dy
-        return dx, dw, db
+        return dx, dw, db, None
 
 
 def linear_pm(x, weight, bias=None):
@@ -145,6 +246,13 @@ def linear_pm(x, weight, bias=None):
 def conv1x1(x, conv):
     """Conv1d(kernel 1) applied to point-major x (B,N,Cin) as a GEMM with the SAME parameter tensor."""
     return linear_pm(x, conv.weight.flatten(1), conv.bias)      # (Cout,Cin,1) -> (Cout,Cin) view
+
+
+def conv1x1_gn_relu(x, conv, gn, relu=True):
+    """group_norm_relu(conv1x1(x, conv), gn) with the GroupNorm statistics taken from the GEMM's epilogue where
+    csrc/gemm.hip serves the layer (no separate statistics pass over the conv output)."""
+    y, gsum = LinearPMFunction.apply(x, conv.weight.flatten(1), conv.bias, gn.num_groups)
+    return GroupNormReLUFunction.apply(y, gn.weight, gn.bias, gn.num_groups, gn.eps, relu, gsum)
 
 
 class GlobalMaxPoolFunction(torch.autograd.Function):

@@ -464,6 +464,28 @@ int gcn_gn_max_fwd(const void *x, int dtype, const float *gamma, const float *be
 int gcn_param_normalise_fwd(const float *p, long R, float *out, void *stream);
 int gcn_param_normalise_bwd(const float *p, const float *grad_out, long R, float *grad_in, void *stream);
 
+/* gcn_gn_fwd's second half alone: the (B,G,2) f64 sums and sums of squares are already in `gsum` -- written by the
+ * epilogue of the GEMM that produced x (gcn_gemm_bf16), so the statistics pass over x is skipped. */
+int gcn_gn_apply(const void *x, int dtype, const double *gsum, const float *gamma, const float *beta, int B,
+                 int N, int C, int G, float eps, int relu, void *y, float *mean_rstd, void *stream);
+
+/* ---------------------------------- per-point 1x1 convolutions of the heads (bf16 MFMA GEMMs) ------ */
+
+/* The Conv1d(kernel 1) layers of the heads (M4:556-603,644-699,713) on POINT-major activations (csrc/gemm.hip):
+ *   out (M,N) = A (M,K) . W (N,K)^T + bias      A, W bf16 (both contiguous along K), out bf16 (out_f32 = 0) or f32,
+ * K % 16 == 0 (pad with zero columns), W holds Np >= N rows (rows N..Np-1 zero: pad N up to a multiple of 32 so the
+ * tile loads stay in bounds without reading other weights).  The input gradient is the same call with A = dY and
+ * W = the transposed weight.  gsum (M/rows_per_cloud, G, 2) f64 or NULL: per (cloud, group) sum / sum of squares of
+ * the f32 results for the GroupNorm that follows (needs (N/G) % 32 == 0, rows_per_cloud % 128 == 0, and stats_ws =
+ * gcn_gemm_stats_ws_bytes(M, N) bytes of scratch for the per-wave partial sums); feed it to gcn_gn_apply.
+ * gcn_gemm_wgrad_bf16: dW (N,K) f32 = dY (M,N)^T . X (M,K), the contraction running down the rows of both row-major
+ * operands (fragments by ds_read_b64_tr_b16, M split over workgroups, f32 atomics into the zeroed dW); N % 8 == 0,
+ * K % 8 == 0. */
+long gcn_gemm_stats_ws_bytes(long M, int N);
+int gcn_gemm_bf16(const void *A, const void *W, const float *bias, void *out, int out_f32, long M, int N, int Np,
+                  int K, double *gsum, void *stats_ws, int rows_per_cloud, int G, void *stream);
+int gcn_gemm_wgrad_bf16(const void *dY, const void *X, long M, int N, int K, float *dW, void *stream);
+
 /* ------------------------------------------------------------- attention stacks ------ */
 
 /* Fused scaled-dot-product attention forward (online softmax; the (Lq x Lk) score matrix never

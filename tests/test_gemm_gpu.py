@@ -1,0 +1,66 @@
+"""GPU parity of the head GEMM kernels (csrc/gemm.hip): forward / input-gradient form with fused bias and GroupNorm
+statistics, and the weight-gradient form (hardware transpose reads), vs fp32 torch on the same bf16-rounded operands
+(products of bf16 values are exact in f32: the difference left is f32 summation order, 1e-4 relative to the scale)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf(t):
+    return t.to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("M,N,K,bias,out_f32", [
+    (1024, 512, 256, True, 0), (1024, 256, 512, True, 0), (1000, 256, 832, True, 0), (640, 64, 256, True, 1),
+    (384, 10, 256, True, 1), (384, 22, 256, False, 1), (300, 3, 256, True, 1), (512, 128, 272, True, 0),
+    (256, 1024, 256, True, 0), (512, 256, 16, False, 0), (512, 256, 32, True, 0), (129, 96, 80, True, 1)])
+def test_gemm_forward(dev, M, N, K, bias, out_f32):
+    from gcanet_amd import _lib
+    g = torch.Generator().manual_seed(M + N + K)
+    A = _bf(torch.randn(M, K, generator=g)).to(dev)
+    Np = (N + 31) // 32 * 32
+    W = torch.zeros(Np, K, dtype=torch.bfloat16)
+    W[:N] = _bf(torch.randn(N, K, generator=g) / K ** 0.5)
+    W = W.to(dev)
+    b = torch.randn(N, generator=g).to(dev) if bias else None
+    out = torch.empty(M, N, dtype=torch.float32 if out_f32 else torch.bfloat16, device=dev)
+    _lib.call("gcn_gemm_bf16", _lib.ptr(A), _lib.ptr(W), _lib.ptr(b), _lib.ptr(out), out_f32, M, N, Np, K, None, None, 0, 0,
+              _lib.stream_of(A))
+    ref = A.float() @ W[:N].float().t()
+    if bias:
+        ref = ref + b
+    tol = 1e-4 if out_f32 else 1e-2           # bf16 output: one rounding of the result (2^-9 relative)
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref.cpu().numpy(), rtol=tol, atol=tol * float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("B,Npts,N,K,G", [(2, 256, 512, 256, 8), (3, 128, 256, 512, 4), (2, 384, 128, 272, 4), (1, 256, 1024, 256, 8)])
+def test_gemm_fused_groupnorm_statistics(dev, B, Npts, N, K, G):
+    from gcanet_amd import _lib
+    g = torch.Generator().manual_seed(N + K + G)
+    M = B * Npts
+    A = _bf(torch.randn(M, K, generator=g)).to(dev)
+    W = _bf(torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    gsum = torch.empty(B, G, 2, dtype=torch.float64, device=dev)
+    ws = torch.empty(_lib.lib().gcn_gemm_stats_ws_bytes(M, N), dtype=torch.uint8, device=dev)
+    _lib.call("gcn_gemm_bf16", _lib.ptr(A), _lib.ptr(W), _lib.ptr(b), _lib.ptr(out), 0, M, N, N, K, _lib.ptr(gsum), _lib.ptr(ws),
+              Npts, G, _lib.stream_of(A))
+    y = (A.float() @ W.float().t() + b).double().view(B, Npts, G, N // G)
+    np.testing.assert_allclose(gsum[..., 0].cpu().numpy(), y.sum((1, 3)).cpu().numpy(), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(gsum[..., 1].cpu().numpy(), (y * y).sum((1, 3)).cpu().numpy(), rtol=1e-5)
+
+
+@pytest.mark.parametrize("M,N,K", [(2048, 256, 256), (4096, 512, 256), (1000, 64, 256), (3000, 16, 256), (2048, 256, 272),
+                                   (2048, 128, 832), (700, 32, 256), (5000, 256, 1024), (1024, 8, 64)])
+def test_gemm_weight_gradient(dev, M, N, K):
+    from gcanet_amd import _lib
+    g = torch.Generator().manual_seed(M + N + K)
+    dY = _bf(torch.randn(M, N, generator=g)).to(dev)
+    X = _bf(torch.randn(M, K, generator=g)).to(dev)
+    dW = torch.empty(N, K, device=dev)
+    _lib.call("gcn_gemm_wgrad_bf16", _lib.ptr(dY), _lib.ptr(X), M, N, K, _lib.ptr(dW), _lib.stream_of(X))
+    ref = dY.float().t() @ X.float()
+    np.testing.assert_allclose(dW.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
