@@ -31,6 +31,7 @@ def parse_args(argv=None):
     ap.add_argument("--points", type=int, default=8192)
     ap.add_argument("--k", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-full", action="store_true", help="skip the second workload (literal full forward_train + losses)")
     ap.add_argument("--rehearse-cpu", action="store_true",
                     help="launcher/collective rehearsal on a box WITHOUT a GPU: gloo ranks, a tiny torch stand-in "
                          "module instead of the HIP hot path; the JSON line is marked invalid as a measurement")
@@ -157,6 +158,72 @@ def cpu_baseline(N, k, seconds_budget=30.0):
     return {"value": round(1.0 / best, 5), "unit": "clouds/s", "cores": threads, "kind": "port",
             "sample": "1 cloud N=%d k=%d, full hot path fwd+bwd fp32 via oracle/ref_model.hot_path "
                       "(torch CPU restatement of M4:634-747), 1 warm-up + best of %d" % (N, k, runs)}
+
+
+def blob_clouds(cloud_ids, N, device, blobs=64, sigma=0.004):
+    """Clouds made of `blobs` tight clusters (class-consistent geometry), so that forward_grouping finds proposals even
+    with random-init weights: xyz = centre + sigma*N(0,1), normals = the blob's direction + noise; the blob id is the
+    instance label."""
+    pts, nrm, lab = [], [], []
+    for cid in cloud_ids:
+        g = torch.Generator().manual_seed(4321 + int(cid))
+        centres = torch.rand(blobs, 3, generator=g) * 0.9 + 0.05
+        dirs = torch.nn.functional.normalize(torch.randn(blobs, 3, generator=g), dim=-1)
+        which = torch.arange(N) % blobs
+        pts.append(centres[which] + sigma * torch.randn(N, 3, generator=g))
+        nrm.append(torch.nn.functional.normalize(dirs[which] + 0.05 * torch.randn(N, 3, generator=g), dim=-1))
+        lab.append(which)
+    return torch.stack(pts).to(device), torch.stack(nrm).to(device), torch.stack(lab).to(device)
+
+
+def full_workload(args, dev, steps=5, warmup=2):
+    """Second workload: the LITERAL forward_train of the reference (M4:634-777) -- hot path ->
+    forward_grouping on the device -> proposal cap -> clusters_voxelization -> sparse-conv instance head -- plus the
+    losses that call the hot-path ops (utils/loss_utils.py:203-257,308-435) and a per-point NLL, backward and Adam, on
+    blob clouds so that proposals exist.  Reported beside the headline number, never part of it."""
+    from gcanet_amd.gcanet import GCANet
+    from gcanet_amd.layers import CastCache
+    from gcanet_amd.losses import compute_embedding_loss, instance_loss
+    B, N, k = args.batch, args.points, args.k
+    torch.manual_seed(0)
+    net = GCANet(nn_nb=k, dtype="bf16", grouping_cfg=dict(similarity_threshold_inst=0.0, min_npoint=30)).to(dev)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, fused=True)
+    casts = CastCache(net.point_net, pad_k={net.point_net.conv3.weight: (net.point_net.conv3.weight.shape[1] + 15) // 16 * 16})
+    pts, nrm, lab = blob_clouds(range(B), N, dev)
+    blobs = int(lab.max()) + 1
+    inst = (lab + torch.arange(B, device=dev).view(B, 1) * blobs).reshape(-1)          # global instance ids
+    pointnum = torch.bincount(inst, minlength=B * blobs).int()
+    inst_cls = (torch.arange(B * blobs, device=dev) % blobs % 9 + 1).long()            # foreground classes 1..9
+    sem = inst_cls[inst]                                                               # (B*N,)
+    rand = (torch.full((3,), 0.5), torch.full((3,), 0.5))
+    info = {}
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        casts.refresh()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            (type_pp, param_pp, sem_scores, off, ibi, cls_s, iou_s, mask_s, pidx, poff, feats) = net(pts, nrm, rand=rand)
+        loss = compute_embedding_loss(feats.float(), lab)[0].sum() \
+            + torch.nn.functional.nll_loss(type_pp.float().reshape(-1, type_pp.shape[-1]), sem) \
+            + off.float().abs().mean() \
+            + instance_loss(cls_s.float(), mask_s.float(), iou_s.float(), pidx, poff, inst, pointnum, inst_cls, ibi)
+        loss.backward()
+        opt.step()
+        info.update(proposals=int(poff.shape[0]) - 1, members=int(pidx.shape[0]), loss=float(loss.detach()))
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"workload": "literal forward_train (M4:634-777: hot path + device forward_grouping + clusters_voxelization + "
+                        "sparse instance head) + embedding/instance/NLL/offset losses + backward + Adam; %d blob clouds "
+                        "N=%d k=%d (%d blobs each)" % (B, N, k, blobs),
+            "ms_per_step": round(dt * 1e3, 3), "clouds_per_s": round(B / dt, 2), "steps": steps, "warmup": warmup,
+            "proposals": info.get("proposals"), "members": info.get("members"), "loss": info.get("loss")}
 
 
 def _event_ms(fn, iters=20, warm=3):
@@ -417,6 +484,8 @@ def main():
     }
     if world == 1:
         res["north_star"] = north_star_rooflines(dev)
+    if world == 1 and not args.no_full:
+        res["full_workload"] = full_workload(args, dev)
     if world == 1 and not args.no_cpu_baseline:
         res["forward_grouping"] = grouping_times(model, pts, nrm)
         res["cpu_baseline"] = cpu_baseline(N, args.k)

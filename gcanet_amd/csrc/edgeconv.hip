@@ -676,6 +676,36 @@ __global__ __launch_bounds__(1024) void reverse_sum_lds_kernel(const float *__re
 }
 
 
+// in-degrees only (the first EdgeConv layer needs no transposed sum: the cloud itself carries no gradient): every
+// workgroup owns R destination counters in LDS and scans the cloud's u16 edge list, 8 ids per 16-byte load
+__global__ __launch_bounds__(1024) void indeg_lds_kernel(const unsigned short *__restrict__ idx, int B, int N, int k, int R,
+                                                         float *__restrict__ indeg) {
+  extern __shared__ unsigned int cnt_s[];
+  const int b = blockIdx.x % B, m0 = (blockIdx.x / B) * R;     // cloud fastest: one cloud per XCD (see reverse_sum_lds_kernel)
+  for (int i = threadIdx.x; i < R; i += 1024) cnt_s[i] = 0u;
+  __syncthreads();
+  const long E = (long)N * k;
+  const unsigned short *ib = idx + (long)b * E;
+  const long E8 = E & ~7L;                                     // b*E*2 bytes is 16-byte aligned when E % 8 == 0 (checked by the host)
+  for (long e = (long)threadIdx.x * 8; e < E8; e += 1024 * 8) {
+    const uint4 v = *reinterpret_cast<const uint4 *>(ib + e);
+    const unsigned int w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned int lo = (w[i] & 0xffffu) - (unsigned int)m0, hi = (w[i] >> 16) - (unsigned int)m0;
+      if (lo < (unsigned int)R) atomicAdd(&cnt_s[lo], 1u);
+      if (hi < (unsigned int)R) atomicAdd(&cnt_s[hi], 1u);
+    }
+  }
+  for (long e = E8 + threadIdx.x; e < E; e += 1024) {
+    const unsigned int d = (unsigned int)ib[e] - (unsigned int)m0;
+    if (d < (unsigned int)R) atomicAdd(&cnt_s[d], 1u);
+  }
+  __syncthreads();
+  const int rows = min(R, N - m0);
+  for (int i = threadIdx.x; i < rows; i += 1024) indeg[(long)b * N + m0 + i] = (float)cnt_s[i];
+}
+
 // ------------------------------------------------------------------ key-point edge block (offset module)
 // OFFSET_PRED_MODULE (M4:398-452) builds, for every point, k edges to a fixed set of NK key points,
 // scales the 131-channel edge feature by the KPAM weight att[n,j] and runs Conv2d(131->128)+GN+
@@ -1041,6 +1071,12 @@ GCN_EXPORT int gcn_reverse_sum(const float *x_pm, const int64_t *idx, int B, int
     unsigned short *i16 = reinterpret_cast<unsigned short *>((char *)ws + 16);
     const long E = (long)B * N * k;
     idx_to_u16_kernel<<<cdiv((E + 1) / 2, 256), 256, 0, st>>>(idx, E, i16);
+    if (C == 0 && ((long)N * k) % 8 == 0) {                  // in-degrees only
+      int Rc = (int)(((long)N * B + 255) / 256);
+      if (Rc < 1) Rc = 1;
+      indeg_lds_kernel<<<cdiv(N, Rc) * B, 1024, (size_t)Rc * 4, st>>>(i16, B, N, k, Rc, indeg);
+      return check_launch("indeg_lds_kernel");
+    }
     if (C == 64) {
       GCN_HIP(hipFuncSetAttribute((const void *)reverse_sum_lds_kernel<unsigned short, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       reverse_sum_lds_kernel<unsigned short, true><<<grid, 1024, lds, st>>>(x_pm, i16, (const unsigned int *)ws, B, N, C, k, R, r, indeg);
