@@ -30,11 +30,11 @@ class SDPAFunction(torch.autograd.Function):
             m8 = mask.to(torch.uint8).contiguous()
             per_bh = 1 if m8.dim() == 3 else 0
         with torch.cuda.device_of(q):
-            if precision == "bf16":
+            if precision in ("bf16", "fp16"):
                 ws = _workspace(BH, Lq, Lk, D, q.device)
-                _lib.call("gcn_attention_fwd_bf16", _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(m8), per_bh, BH, Lq,
+                _lib.call("gcn_attention_fwd_" + ("bf16" if precision == "bf16" else "f16"), _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(m8), per_bh, BH, Lq,
                           Lk, D, float(scale), _lib.ptr(out), _lib.ptr(lse), _lib.ptr(ws), _lib.stream_of(q),
-                          tag="attention_fwd_bf16[BH=%d,Lq=%d,Lk=%d,D=%d]" % (BH, Lq, Lk, D))
+                          tag="attention_fwd_%s[BH=%d,Lq=%d,Lk=%d,D=%d]" % (precision, BH, Lq, Lk, D))
             else:
                 _lib.call("gcn_attention_fwd", _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(m8), per_bh, BH, Lq, Lk,
                           D, float(scale), _lib.ptr(out), _lib.ptr(lse), _lib.stream_of(q),
@@ -47,7 +47,7 @@ class SDPAFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         q, k, v, out, lse, m8 = ctx.saved_tensors
-        if ctx.precision == "bf16":
+        if ctx.precision in ("bf16", "fp16"):
             BH, Lq, D = q.shape
             Lk = k.shape[1]
             dout = dout.float().contiguous()
@@ -55,10 +55,10 @@ class SDPAFunction(torch.autograd.Function):
             mm = m8 if m8.numel() else None
             with torch.cuda.device_of(q):
                 ws = _workspace(BH, Lq, Lk, D, q.device)
-                _lib.call("gcn_attention_bwd_bf16", _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(out), _lib.ptr(dout),
+                _lib.call("gcn_attention_bwd_" + ("bf16" if ctx.precision == "bf16" else "f16"), _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(out), _lib.ptr(dout),
                           _lib.ptr(lse), _lib.ptr(mm), 1 if (mm is not None and mm.dim() == 3) else 0, BH, Lq, Lk, D,
                           float(ctx.scale), _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), _lib.ptr(ws), _lib.stream_of(q),
-                          tag="attention_bwd_bf16[BH=%d,Lq=%d,Lk=%d,D=%d]" % (BH, Lq, Lk, D))
+                          tag="attention_bwd_%s[BH=%d,Lq=%d,Lk=%d,D=%d]" % (ctx.precision, BH, Lq, Lk, D))
             return dq, dk, dv, None, None, None
         s = torch.bmm(q, k.transpose(1, 2)) * ctx.scale
         if m8.numel():
@@ -72,7 +72,8 @@ class SDPAFunction(torch.autograd.Function):
 
 
 def sdpa(q, k, v, mask=None, scale=None, precision="f32"):
-    """precision "f32": exact kernel (parity path, head dim 8..64); "bf16": matrix-core flash kernels (head dim 32/64)."""
+    """precision "f32": exact kernel (parity path, head dim 8..64); "bf16" / "fp16": matrix-core flash kernels
+    (head dim 32/64) on bf16 or IEEE-half operands (BASELINE config 5 names fp16)."""
     if scale is None:
         scale = q.shape[-1] ** -0.5
     return SDPAFunction.apply(q, k, v, mask, scale, precision)

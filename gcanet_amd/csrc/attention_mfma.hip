@@ -37,6 +37,36 @@ __device__ __forceinline__ unsigned short to_bf16(float f) {
   return __builtin_bit_cast(unsigned short, h);
 }
 
+// 16-bit operand type of the kernels: bf16 (F16 = false) or IEEE half (F16 = true, BASELINE config 5 "fp16+MFMA":
+// 11 significand bits instead of 8, at the price of range -- values below 6e-8 flush, which the probabilities and
+// their gradients tolerate).  The images, fragments and LDS layouts are identical; only the conversions and the MFMA
+// opcode (v_mfma_f32_32x32x16_f16) differ.
+typedef __attribute__((ext_vector_type(8))) _Float16 a_f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 a_f16x2;
+template <bool F16>
+__device__ __forceinline__ unsigned int pack_x2(float a, float b) {
+  if (F16) {
+    a_f32x2 v = {a, b};
+    a_f16x2 h = __builtin_convertvector(v, a_f16x2);   // round to nearest even
+    return __builtin_bit_cast(unsigned int, h);
+  }
+  return pack_bf16x2(a, b);
+}
+template <bool F16>
+__device__ __forceinline__ unsigned short to_16(float f) {
+  if (F16) {
+    _Float16 h = (_Float16)f;
+    return __builtin_bit_cast(unsigned short, h);
+  }
+  return to_bf16(f);
+}
+template <bool F16>
+__device__ __forceinline__ a_f32x16 mfma_16(a_bf16x8 a, a_bf16x8 b, a_f32x16 c) {
+  if (F16)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(a_f16x8, a), __builtin_bit_cast(a_f16x8, b), c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
 // position (within a group of 16) -> row of the group, in accumulator order: lane half h = p>>3 holds
 // rows 4h + (i&3) + 8(i>>2), i = p&7
 __device__ __host__ __forceinline__ int attn_row_of_pos(int p) {
@@ -46,7 +76,7 @@ __device__ __host__ __forceinline__ int attn_row_of_pos(int p) {
 
 // src (BH, L, D) f32 -> row-major image dst_rm (BH, Lp, D) bf16 (zero rows past L, values * mul)
 // and/or permuted transposed image dst_t (BH, D, Lp) bf16.  One block = 64 rows of one bh.
-template <int D>
+template <int D, bool F16>
 __global__ __launch_bounds__(256) void attn_pack_kernel(const float *__restrict__ src, int L, int Lp, float mul,
                                                         unsigned short *__restrict__ dst_rm,
                                                         unsigned short *__restrict__ dst_t) {
@@ -57,14 +87,14 @@ __global__ __launch_bounds__(256) void attn_pack_kernel(const float *__restrict_
     const int r = e / D, d = e % D;
     const float v = (l0 + r < L) ? s[(long)(l0 + r) * D + d] * mul : 0.f;
     tile[r][d] = v;
-    if (dst_rm) dst_rm[((long)bh * Lp + l0 + r) * D + d] = to_bf16(v);
+    if (dst_rm) dst_rm[((long)bh * Lp + l0 + r) * D + d] = to_16<F16>(v);
   }
   if (!dst_t) return;
   __syncthreads();
   for (int e = threadIdx.x; e < 64 * D; e += 256) {
     const int d = e / 64, p = e % 64;
     const int r = (p & ~15) + attn_row_of_pos(p & 15);
-    dst_t[((long)bh * D + d) * Lp + l0 + p] = to_bf16(tile[r][d]);
+    dst_t[((long)bh * D + d) * Lp + l0 + p] = to_16<F16>(tile[r][d]);
   }
 }
 
@@ -114,7 +144,7 @@ __device__ __forceinline__ a_bf16x8 lds_t_frag(const unsigned char *lds, int row
 // ---- forward --------------------------------------------------------------------------------------
 // qb (BH,Lqp,D) bf16 pre-scaled by scale*log2(e); kb (BH,Lkp,D); vt (BH,D,Lkp) permuted; mask bytes
 // (1 = masked out) (Lq,Lk) [+ bh stride]; out (BH,Lq,D) f32; lse (BH,Lq) f32 natural-log units.
-template <int D, bool MASK>
+template <int D, bool MASK, bool F16>
 __global__ __launch_bounds__(512, 2) void attn_fwd_mfma_kernel(const unsigned short *__restrict__ qb,
                                                                const unsigned short *__restrict__ kb,
                                                                const unsigned short *__restrict__ vt,
@@ -171,7 +201,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_mfma_kernel(const unsigned sh
       for (int r = 0; r < 16; ++r) sc[kb2][r] = 0.f;
 #pragma unroll
       for (int s = 0; s < KS; ++s)
-        sc[kb2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_rm_frag<D>(kt, 32 * kb2 + lr, 2 * s + lh), qf[s], sc[kb2], 0, 0, 0);
+        sc[kb2] = mfma_16<F16>(lds_rm_frag<D>(kt, 32 * kb2 + lr, 2 * s + lh), qf[s], sc[kb2]);
     }
     // keys past Lk (zero padding of the last tile) and user mask -> -inf
     if (MASK || key0 + 64 > Lk) {
@@ -204,7 +234,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_mfma_kernel(const unsigned sh
         const float p0 = __builtin_amdgcn_exp2f(sc[kb2][r] - m_use);
         const float p1 = __builtin_amdgcn_exp2f(sc[kb2][r + 1] - m_use);
         ps += p0 + p1;
-        pf[kb2][r >> 3][(r & 7) >> 1] = pack_bf16x2(p0, p1);
+        pf[kb2][r >> 3][(r & 7) >> 1] = pack_x2<F16>(p0, p1);
       }
     l_run = l_run * alpha + ps;
     if (__builtin_amdgcn_ballot_w64(alpha != 1.f)) {                 // wave-uniform skip once the maxima settle
@@ -222,7 +252,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_mfma_kernel(const unsigned sh
           a_bf16x8 pb;
           unsigned int *pw = reinterpret_cast<unsigned int *>(&pb);
           pw[0] = pf[kb2][tt][0]; pw[1] = pf[kb2][tt][1]; pw[2] = pf[kb2][tt][2]; pw[3] = pf[kb2][tt][3];
-          o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_t_frag(vtile, 32 * d + lr, 4 * kb2 + 2 * tt + lh), pb, o[d], 0, 0, 0);
+          o[d] = mfma_16<F16>(lds_t_frag(vtile, 32 * d + lr, 4 * kb2 + 2 * tt + lh), pb, o[d]);
         }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -284,7 +314,7 @@ __device__ __forceinline__ a_bf16x8 make_frag(const unsigned int *w) {
 
 // dQ: the workgroup owns 128 queries (lane = query) and streams key tiles: K, V (row-major) and K^T.
 //   S^T = K.Qs^T, dP^T = V.dO^T, dS^T = P^T o (dP^T - delta), dQ^T += K^T.dS^T;  dQ = scale * dQ^T.
-template <int D, bool MASK>
+template <int D, bool MASK, bool F16>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const unsigned short *__restrict__ qs,
                                                              const unsigned short *__restrict__ kr,
                                                              const unsigned short *__restrict__ vr,
@@ -339,8 +369,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const unsigned shor
       for (int r = 0; r < 16; ++r) { sc[r] = -my_lse2; dp[r] = -my_delta; }
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
-        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_rm_frag<D>(kt, 32 * kb2 + lr, 2 * s + lh), qf[s], sc, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_rm_frag<D>(vtile, 32 * kb2 + lr, 2 * s + lh), dof[s], dp, 0, 0, 0);
+        sc = mfma_16<F16>(lds_rm_frag<D>(kt, 32 * kb2 + lr, 2 * s + lh), qf[s], sc);
+        dp = mfma_16<F16>(lds_rm_frag<D>(vtile, 32 * kb2 + lr, 2 * s + lh), dof[s], dp);
       }
       unsigned int dsw[2][4];
 #pragma unroll
@@ -354,14 +384,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const unsigned shor
           const float p = dead ? 0.f : __builtin_amdgcn_exp2f(sc[r + u]);
           ds2[u] = p * dp[r + u];
         }
-        dsw[r >> 3][(r & 7) >> 1] = pack_bf16x2(ds2[0], ds2[1]);
+        dsw[r >> 3][(r & 7) >> 1] = pack_x2<F16>(ds2[0], ds2[1]);
       }
 #pragma unroll
       for (int d = 0; d < DB; ++d)
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt)
-          acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_t_frag(ktt, 32 * d + lr, 4 * kb2 + 2 * tt + lh),
-                                                           make_frag(dsw[tt]), acc[d], 0, 0, 0);
+          acc[d] = mfma_16<F16>(lds_t_frag(ktt, 32 * d + lr, 4 * kb2 + 2 * tt + lh),
+                                                           make_frag(dsw[tt]), acc[d]);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -380,7 +410,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const unsigned shor
 // dK, dV: the workgroup owns 128 keys (lane = key) and streams query tiles: Qs, dO (row-major), Qs^T, dO^T
 // and the tile's lse2 / delta.   S = Qs.K^T - lse2, dP = dO.V^T - delta (row constants enter as the initial
 // accumulator), P = exp2(S), dS = P o dP;  dV^T += dO^T.P,  dK^T += Qs^T.dS;  dK = ln2 * dK^T (Qs carries log2 e).
-template <int D, bool MASK>
+template <int D, bool MASK, bool F16>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const unsigned short *__restrict__ qs,
                                                               const unsigned short *__restrict__ qst,
                                                               const unsigned short *__restrict__ kr,
@@ -449,8 +479,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const unsigned sho
       }
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
-        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_rm_frag<D>(qt, 32 * qb2 + lr, 2 * s + lh), kf[s], sc, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_rm_frag<D>(dot_rm, 32 * qb2 + lr, 2 * s + lh), vf[s], dp, 0, 0, 0);
+        sc = mfma_16<F16>(lds_rm_frag<D>(qt, 32 * qb2 + lr, 2 * s + lh), kf[s], sc);
+        dp = mfma_16<F16>(lds_rm_frag<D>(dot_rm, 32 * qb2 + lr, 2 * s + lh), vf[s], dp);
       }
       unsigned int pw[2][4], dsw[2][4];
 #pragma unroll
@@ -466,17 +496,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const unsigned sho
           p2[u] = p;
           ds2[u] = p * dp[r + u];
         }
-        pw[r >> 3][(r & 7) >> 1] = pack_bf16x2(p2[0], p2[1]);
-        dsw[r >> 3][(r & 7) >> 1] = pack_bf16x2(ds2[0], ds2[1]);
+        pw[r >> 3][(r & 7) >> 1] = pack_x2<F16>(p2[0], p2[1]);
+        dsw[r >> 3][(r & 7) >> 1] = pack_x2<F16>(ds2[0], ds2[1]);
       }
 #pragma unroll
       for (int d = 0; d < DB; ++d)
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
-          dvt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_t_frag(dott, 32 * d + lr, 4 * qb2 + 2 * tt + lh),
-                                                           make_frag(pw[tt]), dvt[d], 0, 0, 0);
-          dkt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_t_frag(qtt, 32 * d + lr, 4 * qb2 + 2 * tt + lh),
-                                                           make_frag(dsw[tt]), dkt[d], 0, 0, 0);
+          dvt[d] = mfma_16<F16>(lds_t_frag(dott, 32 * d + lr, 4 * qb2 + 2 * tt + lh),
+                                                           make_frag(pw[tt]), dvt[d]);
+          dkt[d] = mfma_16<F16>(lds_t_frag(qtt, 32 * d + lr, 4 * qb2 + 2 * tt + lh),
+                                                           make_frag(dsw[tt]), dkt[d]);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -499,7 +529,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const unsigned sho
 
 static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
-template <int D>
+template <int D, bool F16>
 static int run_bwd(const float *q, const float *k, const float *v, const float *out, const float *dout, const float *lse,
                    const uint8_t *mask, int mask_per_bh, int BH, int Lq, int Lk, float scale, float *dq, float *dk,
                    float *dv, unsigned char *wsb, hipStream_t st) {
@@ -508,43 +538,43 @@ static int run_bwd(const float *q, const float *k, const float *v, const float *
   unsigned short *qs = (unsigned short *)wsb, *qst = qs + nq, *dor = qst + nq, *dot = dor + nq;
   unsigned short *kr = dot + nq, *ktr = kr + nk, *vr = ktr + nk;
   float *delta = (float *)(vr + nk), *lse2 = delta + (size_t)BH * Lqp;
-  attn_pack_kernel<D><<<dim3(Lqp / 64, BH), 256, 0, st>>>(q, Lq, Lqp, scale * 1.4426950408889634f, qs, qst);
-  attn_pack_kernel<D><<<dim3(Lqp / 64, BH), 256, 0, st>>>(dout, Lq, Lqp, 1.f, dor, dot);
-  attn_pack_kernel<D><<<dim3(Lkp / 64, BH), 256, 0, st>>>(k, Lk, Lkp, 1.f, kr, ktr);
-  attn_pack_kernel<D><<<dim3(Lkp / 64, BH), 256, 0, st>>>(v, Lk, Lkp, 1.f, vr, nullptr);
+  attn_pack_kernel<D, F16><<<dim3(Lqp / 64, BH), 256, 0, st>>>(q, Lq, Lqp, scale * 1.4426950408889634f, qs, qst);
+  attn_pack_kernel<D, F16><<<dim3(Lqp / 64, BH), 256, 0, st>>>(dout, Lq, Lqp, 1.f, dor, dot);
+  attn_pack_kernel<D, F16><<<dim3(Lkp / 64, BH), 256, 0, st>>>(k, Lk, Lkp, 1.f, kr, ktr);
+  attn_pack_kernel<D, F16><<<dim3(Lkp / 64, BH), 256, 0, st>>>(v, Lk, Lkp, 1.f, vr, nullptr);
   attn_delta_kernel<D><<<dim3(Lqp / 32, BH), 256, 0, st>>>(dout, out, lse, Lq, Lqp, delta, lse2);
   const long ms = mask_per_bh ? (long)Lq * Lk : 0;
   const int lds_q = 2 * 3 * 64 * D * 2, lds_kv = 2 * (4 * 64 * D * 2 + 1024);
   if (mask) {
-    GCN_HIP(hipFuncSetAttribute((const void *)attn_bwd_dkv_kernel<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv));
-    attn_bwd_dq_kernel<D, true><<<dim3(Lqp / 128, BH), 256, lds_q, st>>>(qs, kr, vr, ktr, dor, lse2, delta, mask, ms, Lq, Lk, Lqp, Lkp, scale, dq);
-    attn_bwd_dkv_kernel<D, true><<<dim3(Lkp / 128, BH), 256, lds_kv, st>>>(qs, qst, kr, vr, dor, dot, lse2, delta, mask, ms, Lq, Lk, Lqp, Lkp, dk, dv);
+    GCN_HIP(hipFuncSetAttribute((const void *)attn_bwd_dkv_kernel<D, true, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv));
+    attn_bwd_dq_kernel<D, true, F16><<<dim3(Lqp / 128, BH), 256, lds_q, st>>>(qs, kr, vr, ktr, dor, lse2, delta, mask, ms, Lq, Lk, Lqp, Lkp, scale, dq);
+    attn_bwd_dkv_kernel<D, true, F16><<<dim3(Lkp / 128, BH), 256, lds_kv, st>>>(qs, qst, kr, vr, dor, dot, lse2, delta, mask, ms, Lq, Lk, Lqp, Lkp, dk, dv);
   } else {
-    GCN_HIP(hipFuncSetAttribute((const void *)attn_bwd_dkv_kernel<D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv));
-    attn_bwd_dq_kernel<D, false><<<dim3(Lqp / 128, BH), 256, lds_q, st>>>(qs, kr, vr, ktr, dor, lse2, delta, nullptr, 0, Lq, Lk, Lqp, Lkp, scale, dq);
-    attn_bwd_dkv_kernel<D, false><<<dim3(Lkp / 128, BH), 256, lds_kv, st>>>(qs, qst, kr, vr, dor, dot, lse2, delta, nullptr, 0, Lq, Lk, Lqp, Lkp, dk, dv);
+    GCN_HIP(hipFuncSetAttribute((const void *)attn_bwd_dkv_kernel<D, false, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv));
+    attn_bwd_dq_kernel<D, false, F16><<<dim3(Lqp / 128, BH), 256, lds_q, st>>>(qs, kr, vr, ktr, dor, lse2, delta, nullptr, 0, Lq, Lk, Lqp, Lkp, scale, dq);
+    attn_bwd_dkv_kernel<D, false, F16><<<dim3(Lkp / 128, BH), 256, lds_kv, st>>>(qs, qst, kr, vr, dor, dot, lse2, delta, nullptr, 0, Lq, Lk, Lqp, Lkp, dk, dv);
   }
   return check_launch("attn_bwd kernels");
 }
 
 
-template <int D>
+template <int D, bool F16>
 static int run_fwd(const float *q, const float *k, const float *v, const uint8_t *mask, int mask_per_bh, int BH, int Lq,
                    int Lk, float scale, float *out, float *lse, unsigned short *ws, hipStream_t st) {
   const int Lqp = round_up(Lq, 128), Lkp = round_up(Lk, 64);
   unsigned short *qb = ws, *kb = qb + (size_t)BH * Lqp * D, *vt = kb + (size_t)BH * Lkp * D;
-  attn_pack_kernel<D><<<dim3(Lqp / 64, BH), 256, 0, st>>>(q, Lq, Lqp, scale * 1.4426950408889634f, qb, nullptr);
-  attn_pack_kernel<D><<<dim3(Lkp / 64, BH), 256, 0, st>>>(k, Lk, Lkp, 1.f, kb, nullptr);
-  attn_pack_kernel<D><<<dim3(Lkp / 64, BH), 256, 0, st>>>(v, Lk, Lkp, 1.f, nullptr, vt);
+  attn_pack_kernel<D, F16><<<dim3(Lqp / 64, BH), 256, 0, st>>>(q, Lq, Lqp, scale * 1.4426950408889634f, qb, nullptr);
+  attn_pack_kernel<D, F16><<<dim3(Lkp / 64, BH), 256, 0, st>>>(k, Lk, Lkp, 1.f, kb, nullptr);
+  attn_pack_kernel<D, F16><<<dim3(Lkp / 64, BH), 256, 0, st>>>(v, Lk, Lkp, 1.f, nullptr, vt);
   const int lds = 2 * 2 * 64 * D * 2;
   const long ms = mask_per_bh ? (long)Lq * Lk : 0;
   // eight waves (256 query rows) per streamed tile when the padded length allows it: half the LDS-DMA work per row
   const int threads = (Lqp % 256 == 0) ? 512 : 256;
   const dim3 grid(Lqp / (threads / 2), BH);
   if (mask)
-    attn_fwd_mfma_kernel<D, true><<<grid, threads, lds, st>>>(qb, kb, vt, mask, ms, Lq, Lk, Lqp, Lkp, out, lse);
+    attn_fwd_mfma_kernel<D, true, F16><<<grid, threads, lds, st>>>(qb, kb, vt, mask, ms, Lq, Lk, Lqp, Lkp, out, lse);
   else
-    attn_fwd_mfma_kernel<D, false><<<grid, threads, lds, st>>>(qb, kb, vt, nullptr, 0, Lq, Lk, Lqp, Lkp, out, lse);
+    attn_fwd_mfma_kernel<D, false, F16><<<grid, threads, lds, st>>>(qb, kb, vt, nullptr, 0, Lq, Lk, Lqp, Lkp, out, lse);
   return check_launch("attn_fwd_mfma_kernel");
 }
 
@@ -559,22 +589,37 @@ GCN_EXPORT long gcn_attention_ws_bytes(int BH, int Lq, int Lk, int D) {
   return 2L * BH * D * (4 * Lqp + 4 * Lkp) + 8L * BH * Lqp + 1024;
 }
 
-GCN_EXPORT int gcn_attention_fwd_bf16(const float *q, const float *k, const float *v, const uint8_t *mask, int mask_per_bh,
-                                      int BH, int Lq, int Lk, int D, float scale, float *out, float *lse, void *ws,
-                                      void *stream) {
+static int attention_fwd_16(bool f16, const float *q, const float *k, const float *v, const uint8_t *mask, int mask_per_bh,
+                            int BH, int Lq, int Lk, int D, float scale, float *out, float *lse, void *ws, void *stream) {
   GCN_REQUIRE(q && k && v && out && ws, "gcn_attention_fwd_bf16: null pointer");
   GCN_REQUIRE(BH >= 0 && Lq >= 1 && Lk >= 1, "gcn_attention_fwd_bf16: bad shape");
   GCN_REQUIRE(D == 32 || D == 64, "gcn_attention_fwd_bf16: head dim %d unsupported (32, 64)", D);
   GCN_REQUIRE(((uintptr_t)ws & 15) == 0 && ((uintptr_t)out & 15) == 0, "gcn_attention_fwd_bf16: ws/out must be 16-B aligned");
   if (BH == 0) return GCN_OK;
   hipStream_t st = (hipStream_t)stream;
-  if (D == 32) return run_fwd<32>(q, k, v, mask, mask_per_bh, BH, Lq, Lk, scale, out, lse, (unsigned short *)ws, st);
-  return run_fwd<64>(q, k, v, mask, mask_per_bh, BH, Lq, Lk, scale, out, lse, (unsigned short *)ws, st);
+  if (f16) {
+    if (D == 32) return run_fwd<32, true>(q, k, v, mask, mask_per_bh, BH, Lq, Lk, scale, out, lse, (unsigned short *)ws, st);
+    return run_fwd<64, true>(q, k, v, mask, mask_per_bh, BH, Lq, Lk, scale, out, lse, (unsigned short *)ws, st);
+  }
+  if (D == 32) return run_fwd<32, false>(q, k, v, mask, mask_per_bh, BH, Lq, Lk, scale, out, lse, (unsigned short *)ws, st);
+  return run_fwd<64, false>(q, k, v, mask, mask_per_bh, BH, Lq, Lk, scale, out, lse, (unsigned short *)ws, st);
 }
 
-GCN_EXPORT int gcn_attention_bwd_bf16(const float *q, const float *k, const float *v, const float *out, const float *dout,
-                                      const float *lse, const uint8_t *mask, int mask_per_bh, int BH, int Lq, int Lk, int D,
-                                      float scale, float *dq, float *dk, float *dv, void *ws, void *stream) {
+GCN_EXPORT int gcn_attention_fwd_bf16(const float *q, const float *k, const float *v, const uint8_t *mask, int mask_per_bh,
+                                      int BH, int Lq, int Lk, int D, float scale, float *out, float *lse, void *ws,
+                                      void *stream) {
+  return attention_fwd_16(false, q, k, v, mask, mask_per_bh, BH, Lq, Lk, D, scale, out, lse, ws, stream);
+}
+
+GCN_EXPORT int gcn_attention_fwd_f16(const float *q, const float *k, const float *v, const uint8_t *mask, int mask_per_bh,
+                                     int BH, int Lq, int Lk, int D, float scale, float *out, float *lse, void *ws,
+                                     void *stream) {
+  return attention_fwd_16(true, q, k, v, mask, mask_per_bh, BH, Lq, Lk, D, scale, out, lse, ws, stream);
+}
+
+static int attention_bwd_16(bool f16, const float *q, const float *k, const float *v, const float *out, const float *dout,
+                            const float *lse, const uint8_t *mask, int mask_per_bh, int BH, int Lq, int Lk, int D,
+                            float scale, float *dq, float *dk, float *dv, void *ws, void *stream) {
   GCN_REQUIRE(q && k && v && out && dout && lse && dq && dk && dv && ws, "gcn_attention_bwd_bf16: null pointer");
   GCN_REQUIRE(BH >= 0 && Lq >= 1 && Lk >= 1, "gcn_attention_bwd_bf16: bad shape");
   GCN_REQUIRE(D == 32 || D == 64, "gcn_attention_bwd_bf16: head dim %d unsupported (32, 64)", D);
@@ -582,6 +627,22 @@ GCN_EXPORT int gcn_attention_bwd_bf16(const float *q, const float *k, const floa
               "gcn_attention_bwd_bf16: buffers must be 16-B aligned");
   if (BH == 0) return GCN_OK;
   hipStream_t st = (hipStream_t)stream;
-  if (D == 32) return run_bwd<32>(q, k, v, out, dout, lse, mask, mask_per_bh, BH, Lq, Lk, scale, dq, dk, dv, (unsigned char *)ws, st);
-  return run_bwd<64>(q, k, v, out, dout, lse, mask, mask_per_bh, BH, Lq, Lk, scale, dq, dk, dv, (unsigned char *)ws, st);
+  if (f16) {
+    if (D == 32) return run_bwd<32, true>(q, k, v, out, dout, lse, mask, mask_per_bh, BH, Lq, Lk, scale, dq, dk, dv, (unsigned char *)ws, st);
+    return run_bwd<64, true>(q, k, v, out, dout, lse, mask, mask_per_bh, BH, Lq, Lk, scale, dq, dk, dv, (unsigned char *)ws, st);
+  }
+  if (D == 32) return run_bwd<32, false>(q, k, v, out, dout, lse, mask, mask_per_bh, BH, Lq, Lk, scale, dq, dk, dv, (unsigned char *)ws, st);
+  return run_bwd<64, false>(q, k, v, out, dout, lse, mask, mask_per_bh, BH, Lq, Lk, scale, dq, dk, dv, (unsigned char *)ws, st);
+}
+
+GCN_EXPORT int gcn_attention_bwd_bf16(const float *q, const float *k, const float *v, const float *out, const float *dout,
+                                      const float *lse, const uint8_t *mask, int mask_per_bh, int BH, int Lq, int Lk, int D,
+                                      float scale, float *dq, float *dk, float *dv, void *ws, void *stream) {
+  return attention_bwd_16(false, q, k, v, out, dout, lse, mask, mask_per_bh, BH, Lq, Lk, D, scale, dq, dk, dv, ws, stream);
+}
+
+GCN_EXPORT int gcn_attention_bwd_f16(const float *q, const float *k, const float *v, const float *out, const float *dout,
+                                     const float *lse, const uint8_t *mask, int mask_per_bh, int BH, int Lq, int Lk, int D,
+                                     float scale, float *dq, float *dk, float *dv, void *ws, void *stream) {
+  return attention_bwd_16(true, q, k, v, out, dout, lse, mask, mask_per_bh, BH, Lq, Lk, D, scale, dq, dk, dv, ws, stream);
 }

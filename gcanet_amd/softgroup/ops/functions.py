@@ -163,16 +163,42 @@ class BallQueryBatchP_Easy(Function):
 ballquery_batch_p_easy = BallQueryBatchP_Easy.apply
 
 
+def _octree_leaf(coords):
+    """Breadth-first leaf number (0..511) of every point in the reference's fixed 3-level octree over the cloud's
+    bounding box (octree_ball_query.cpp:19-108: octant bit = coordinate >= box centre, child centre = centre +- w/4),
+    in the same f32 operations."""
+    mx, mn = coords.max(0)[0], coords.min(0)[0]
+    c = ((mx + mn) / 2).unsqueeze(0).expand_as(coords).clone()
+    w = (mx - mn).unsqueeze(0).expand_as(coords).clone()
+    node = torch.zeros(coords.shape[0], dtype=torch.int64, device=coords.device)
+    for _ in range(3):
+        bit = ~(coords < c)                                   # (n,3) x,y,z
+        node = node * 8 + (bit[:, 2].long() << 2) + (bit[:, 1].long() << 1) + bit[:, 0].long() + 1
+        w = w / 2
+        c = torch.where(bit, c + w / 2, c - w / 2)
+    return node - 73
+
+
 def octree_ball_query(coords, mean_active, radius):
-    """functions.py:111-157.  The reference builds a fixed 3-level octree on the host only to prune
-    the pair tests; the neighbour SETS are those of a single-segment radius query capped at 1000 per
-    point (octree_ball_query.cu:56-126).  On MI355X the tiled brute-force scan is used instead; lists
-    come out in ascending index order rather than octree-leaf order."""
-    coords = coords.cuda().contiguous()
+    """functions.py:127-157.  The reference builds a fixed 3-level octree on the host to prune the pair tests
+    (octree_ball_query.cpp:19-165) and lists, per point, the in-radius points of every active leaf in breadth-first
+    leaf order, ascending index inside a leaf, capped at 1000 (octree_ball_query.cu:56-126).  Here the candidate
+    search is the uniform-grid radius query of ball_query_easy (same neighbour sets) and the lists are put into the
+    reference's order by one segmented sort on (point, leaf, index).  A point with more than 1000 neighbours keeps
+    its 1000 lowest-index ones instead of the first 1000 in leaf order."""
+    coords = coords.cuda().contiguous().float()
     n = coords.size(0)
     batch_idxs = torch.zeros(n, dtype=torch.int32, device=coords.device)
     batch_offsets = torch.tensor([0, n], dtype=torch.int32, device=coords.device)
-    return ballquery_batch_p_easy(coords, batch_idxs, batch_offsets, radius, mean_active)
+    idx, start_len = ballquery_batch_p_easy(coords, batch_idxs, batch_offsets, radius, mean_active)
+    if idx.numel() == 0:
+        return idx, start_len
+    leaf = _octree_leaf(coords)
+    lens = start_len[:, 1].long()
+    seg = torch.repeat_interleave(torch.arange(n, device=coords.device), lens)      # CSR segments are in point order
+    j = idx.long()
+    order = torch.argsort((seg * 512 + leaf[j]) * n + j)
+    return idx[order].contiguous(), start_len
 
 
 def ball_query(coords, batch_idxs, batch_offsets, adj_mat_inst, similarity_threshold_inst, adj_mat_para,

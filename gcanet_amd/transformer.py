@@ -42,7 +42,7 @@ class Attention(nn.Module):
 
     def __init__(self, dim, heads=8, dim_head=64, dropout=0., precision="f32"):
         super().__init__()
-        self.precision = precision      # "f32" exact kernel | "bf16" matrix-core flash kernels (dim_head 32/64)
+        self.precision = precision      # "f32" exact kernel | "bf16" / "fp16" matrix-core flash kernels (dim_head 32/64)
         inner_dim = dim_head * heads
         self.heads = heads
         self.scale = dim ** -0.5

@@ -516,6 +516,16 @@ int gcn_attention_bwd_bf16(const float *q, const float *k, const float *v, const
                            const float *lse, const uint8_t *mask, int mask_per_bh, int BH, int Lq, int Lk, int D,
                            float scale, float *dq, float *dk, float *dv, void *ws, void *stream);
 
+/* The same two entry points with IEEE half operands (v_mfma_f32_32x32x16_f16) -- the "fp16+MFMA" type BASELINE config 5
+ * names: three more significand bits than bf16 (results ~8x closer to the f32 kernel), values below 6e-8 flush.
+ * Same arguments, workspace and layout. */
+int gcn_attention_fwd_f16(const float *q, const float *k, const float *v, const uint8_t *mask, int mask_per_bh,
+                          int BH, int Lq, int Lk, int D, float scale, float *out, float *lse, void *ws,
+                          void *stream);
+int gcn_attention_bwd_f16(const float *q, const float *k, const float *v, const float *out, const float *dout,
+                          const float *lse, const uint8_t *mask, int mask_per_bh, int BH, int Lq, int Lk, int D,
+                          float scale, float *dq, float *dk, float *dv, void *ws, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -233,6 +233,32 @@ def ballquery_batch_p(coords, batch_idxs, batch_offsets, radius, mean_active,
     return idx[:nActive], start_len
 
 
+def octree_ball_query(coords, mean_active, radius):
+    """softgroup/ops/functions.py:127-157 + octree_ball_query.cpp/.cu: (idx (nActive,) i32, start_len (n,2) i32) with the
+    reference's per-point list order (active leaves in breadth-first order, ascending index inside a leaf); CSR
+    segments in point order (the reference's segment order is an atomicAdd race)."""
+    coords = _f32(coords)
+    n = coords.shape[0]
+    mx, mn = coords.max(0), coords.min(0)
+    xyzwhl = np.concatenate([(mx + mn) / 2, mx - mn]).astype(np.float32)
+    boxes = np.zeros((585, 6), np.float32)
+    leaf = np.zeros(n, np.int32)
+    lib().orc_octree_build(_p(coords), n, _p(xyzwhl), _p(boxes), _p(leaf))
+    order = np.lexsort((np.arange(n), leaf)).astype(np.int32)                 # by (leaf, index): export_data's pt_inds
+    counts = np.bincount(leaf, minlength=512).astype(np.int32)
+    psl = np.stack([np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.int32), counts], 1).copy()
+    sl = np.zeros((n, 2), np.int32)
+    total = lib().orc_octree_ball_query(_p(coords), n, _p(boxes), _p(order), _p(psl), int(mean_active), C.c_float(radius),
+                                        None, _p(sl))
+    while total > n * mean_active:                                            # functions.py:147-154
+        mean_active = int(total // n + 1)
+        total = n * mean_active
+    idx = np.zeros(max(total, 1), np.int32)
+    total = lib().orc_octree_ball_query(_p(coords), n, _p(boxes), _p(order), _p(psl), int(mean_active), C.c_float(radius),
+                                        _p(idx), _p(sl))
+    return idx[:total], sl, leaf
+
+
 def bfs_cluster(class_numpoint_mean, ball_query_idxs, start_len, threshold, class_id):
     cm, bq, sl = _f32(class_numpoint_mean), _i32(ball_query_idxs), _i32(start_len)
     N = sl.shape[0]

@@ -520,6 +520,101 @@ ORC_API int orc_ballquery_batch_p(int n, int meanActive, float radius, const flo
   return (int)cumsum;
 }
 
+/* ------------------------------------------------------------------------- */
+/* octree_ball_query: softgroup/ops/src/octree_ball_query/octree_ball_query.cpp:19-165 (host tree: fixed 3 levels,   */
+/* 585 nodes / 512 leaves, breadth-first export) + octree_ball_query.cu:14-126 (per point: walk the active octants,  */
+/* test the points of every active leaf, cap 1000).  Output CSR is deterministic here (start = running sum); the     */
+/* reference hands out segments with atomicAdd.                                                                      */
+/* ------------------------------------------------------------------------- */
+#define OCT_NODES 585
+#define OCT_LEAVES 512
+#define OCT_MIDS 73
+
+/* octant index of a point in a parent box (octree_ball_query.cpp:52-57) */
+static int oct_ind(const float *p, const float *box) {
+  int ix = p[0] < box[0] ? 0 : 1, iy = p[1] < box[1] ? 0 : 1, iz = p[2] < box[2] ? 0 : 1;
+  return (iz << 2) + (iy << 1) + ix;
+}
+
+/* boxes (585,6) in breadth-first order, leaf (n) = breadth-first leaf number of every point (octree_ball_query.cpp:60-108) */
+ORC_API void orc_octree_build(const float *points, int n, const float *xyzwhl, float *boxes, int32_t *leaf_of) {
+  for (int i = 0; i < 6; ++i) boxes[i] = xyzwhl[i];
+  /* node i's octants are nodes 8 i + 1 + o: exactly the breadth-first numbering export_data produces */
+  for (int node = 0; node < OCT_MIDS; ++node)
+    for (int o = 0; o < 8; ++o) {
+      const float *pb = boxes + node * 6;
+      float *b = boxes + (node * 8 + o + 1) * 6;
+      float w = pb[3] / 2, h = pb[4] / 2, l = pb[5] / 2;
+      b[0] = (o & 1) ? pb[0] + w / 2 : pb[0] - w / 2;
+      b[1] = ((o >> 1) & 1) ? pb[1] + h / 2 : pb[1] - h / 2;
+      b[2] = ((o >> 2) & 1) ? pb[2] + l / 2 : pb[2] - l / 2;
+      b[3] = w; b[4] = h; b[5] = l;
+    }
+  for (int i = 0; i < n; ++i) {
+    int node = 0;
+    for (int lev = 0; lev < 3; ++lev) node = node * 8 + oct_ind(points + 3 * i, boxes + node * 6) + 1;
+    leaf_of[i] = node - OCT_MIDS;
+  }
+}
+
+static int oct_intersect(const float *box, const float *p, float r) {
+  float dx = fabsf(box[0] - p[0]), dy = fabsf(box[1] - p[1]), dz = fabsf(box[2] - p[2]);
+  float w = box[3], h = box[4], l = box[5];
+  if (dx > (w / 2 + r)) return 0;
+  if (dy > (h / 2 + r)) return 0;
+  if (dz > (l / 2 + r)) return 0;
+  if (dx <= (w / 2)) return 1;
+  if (dy <= (h / 2)) return 1;
+  if (dz <= (l / 2)) return 1;
+  float ex = dx - w / 2, ey = dy - h / 2, ez = dz - l / 2;
+  float t = ex * ex;
+  t = fmaf(ey, ey, t);
+  t = fmaf(ez, ez, t);
+  return t <= r * r;
+}
+
+/* pt_inds (n) = points by (leaf, index), pt_start_len (512,2); query as octree_ball_query.cu:56-126.  idx may be NULL
+ * (sizes only); returns the total count. */
+ORC_API int orc_octree_ball_query(const float *points, int n, const float *boxes, const int32_t *pt_inds,
+                                  const int32_t *pt_start_len, int mean_active, float radius, int32_t *idx,
+                                  int32_t *start_len) {
+  long cumsum = 0, thr = (long)n * mean_active;
+  int *tmp = (int *)malloc(sizeof(int) * 1000);
+  char actives[OCT_NODES];
+  for (int p = 0; p < n; ++p) {
+    int count = 0, stop = 0;
+    for (int i = 0; i < OCT_NODES; ++i) actives[i] = 1;
+    const float *cp = points + 3 * p;
+    for (int node = 0; node < OCT_MIDS && !stop; ++node)
+      for (int o = 0; o < 8 && !stop; ++o) {
+        int oct = node * 8 + o + 1;
+        if (!actives[node]) { actives[oct] = 0; continue; }
+        int hit = oct_intersect(boxes + oct * 6, cp, radius);
+        actives[oct] = (char)hit;
+        if (hit && oct >= OCT_MIDS) {
+          int leaf = oct - OCT_MIDS, s = pt_start_len[leaf * 2], e = s + pt_start_len[leaf * 2 + 1];
+          for (int i = s; i < e; ++i) {
+            int q = pt_inds[i];
+            if (sqdist3(cp[0], cp[1], cp[2], points[3 * q], points[3 * q + 1], points[3 * q + 2]) < radius * radius) {
+              if (count < 1000) tmp[count++] = q;
+              else break;          /* octree_ball_query.cu:103: leaves THIS leaf's loop; the walk goes on, adding nothing */
+            }
+          }
+        }
+      }
+    start_len[p * 2] = (int32_t)cumsum;
+    start_len[p * 2 + 1] = count;
+    long s = cumsum;
+    cumsum += count;
+    if (!idx || s >= thr) continue;
+    int w = count;
+    if (s + count >= thr) w = (int)(thr - s);
+    for (int i = 0; i < w; ++i) idx[s + i] = tmp[i];
+  }
+  free(tmp);
+  return (int)cumsum;
+}
+
 /* bfs_cluster/bfs_cluster.cpp:48-143.  Two-call: cluster_idxs == NULL -> sizes only. */
 ORC_API void orc_bfs_cluster(const float *class_numpoint_mean, const int32_t *ball_query_idxs,
                              const int32_t *start_len, int nPoint, float threshold, int class_id,

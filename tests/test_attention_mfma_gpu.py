@@ -116,3 +116,69 @@ def test_modules_accept_precision(dev):
     a, b = qd16(feats, offs), qd32(feats, offs)
     _close(a["labels"], b["labels"], "QueryDecoder labels")
     _close(a["parameters"], b["parameters"], "QueryDecoder parameters")
+
+
+def _close_to(a, b, what, rel_tol, max_tol):
+    rel = ((a - b).norm() / b.norm().clamp_min(1e-12)).item()
+    mx = (a - b).abs().max().item() / max(b.abs().max().item(), 1e-12)
+    assert rel < rel_tol and mx < max_tol, "%s: rel fro %.3e, max/|ref|max %.3e" % (what, rel, mx)
+
+
+@pytest.mark.parametrize("BH,Lq,Lk,D", [(4, 256, 256, 64), (3, 100, 1000, 32), (2, 130, 77, 64), (8, 1, 64, 32),
+                                        (1, 333, 2049, 64)])
+@pytest.mark.parametrize("masked", [None, "shared", "per_bh"])
+def test_fp16_fwd_bwd_vs_f32(dev, BH, Lq, Lk, D, masked):
+    """IEEE-half operand variant (v_mfma_f32_32x32x16_f16), the type BASELINE config 5 names.  TOLERANCE: 11 significand
+    bits instead of 8, so the bound asserted is 8x tighter than the bf16 one: 2.5e-3 relative Frobenius, 5e-3 of max|ref|."""
+    from gcanet_amd import attention
+    g = torch.Generator().manual_seed(BH * 1000 + Lq + Lk + D + 1)
+    q, k, v = (torch.randn(BH, L, D, generator=g).to(dev) for L in (Lq, Lk, Lk))
+    do = torch.randn(BH, Lq, D, generator=g).to(dev)
+    mask = None
+    if masked == "shared":
+        mask = (torch.rand(Lq, Lk, generator=g) < 0.3).to(dev)
+        mask[0, :] = True
+    elif masked == "per_bh":
+        mask = (torch.rand(BH, Lq, Lk, generator=g) < 0.5).to(dev)
+    scale = 0.7 * D ** -0.5
+    qa, ka, va = (t.clone().requires_grad_(True) for t in (q, k, v))
+    out = attention.sdpa(qa, ka, va, mask, scale, "fp16")
+    out.backward(do)
+    qb, kb, vb = (t.clone().requires_grad_(True) for t in (q, k, v))
+    ref = _ref(qb, kb, vb, mask, scale)
+    ref.backward(do)
+    assert torch.isfinite(out).all() and torch.isfinite(qa.grad).all()
+    for a, b, what in ((out, ref.detach(), "out"), (qa.grad, qb.grad, "dq"), (ka.grad, kb.grad, "dk"),
+                       (va.grad, vb.grad, "dv")):
+        _close_to(a, b, "fp16 " + what, 2.5e-3, 5e-3)
+    if masked == "shared":
+        assert out[:, 0].abs().max().item() == 0.0
+
+
+def test_fp16_config5_sampled_rows_and_modules(dev):
+    """Config 5 length (n = 16384, 8 heads of 32) in its stated type: 64 sampled query rows against f32 torch, constant
+    V reproduced, and the Transformer / QueryDecoder modules accept precision="fp16"."""
+    from gcanet_amd import attention, query_decoder, transformer
+    g = torch.Generator().manual_seed(12)
+    BH, L, D = 8, 16384, 32
+    q, k, v = (torch.randn(BH, L, D, generator=g).to(dev) for _ in range(3))
+    scale = 256 ** -0.5
+    oc = attention.sdpa(q, k, torch.full_like(v, 0.75), None, scale, "fp16")
+    assert (oc - 0.75).abs().max().item() < 2e-3
+    o = attention.sdpa(q, k, v, None, scale, "fp16")
+    rows = torch.randint(0, L, (64,), generator=g).to(dev)
+    ref = torch.softmax(torch.bmm(q[:, rows], k.transpose(1, 2)) * scale, -1) @ v
+    _close_to(o[:, rows], ref, "fp16 sampled rows", 2.5e-3, 5e-3)
+    torch.manual_seed(0)
+    t32 = transformer.Transformer(64, 1, 2, 32, 128, 0.0).to(dev)
+    t16 = transformer.Transformer(64, 1, 2, 32, 128, 0.0, precision="fp16").to(dev)
+    t16.load_state_dict(t32.state_dict())
+    x = torch.randn(2, 300, 64, device=dev)
+    _close_to(t16(x), t32(x), "Transformer fp16 vs f32", 2.5e-3, 5e-3)
+    qd32 = query_decoder.QueryDecoder(num_layer=1, num_query=20, in_channel=16, d_model=64, nhead=2, hidden_dim=64).to(dev)
+    qd16 = query_decoder.QueryDecoder(num_layer=1, num_query=20, in_channel=16, d_model=64, nhead=2, hidden_dim=64,
+                                      precision="fp16").to(dev)
+    qd16.load_state_dict(qd32.state_dict())
+    feats = torch.randn(500, 16, device=dev)
+    a, b = qd16(feats, [0, 200, 500]), qd32(feats, [0, 200, 500])
+    _close_to(a["labels"], b["labels"], "QueryDecoder labels fp16", 2.5e-3, 5e-3)

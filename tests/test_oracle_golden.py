@@ -178,3 +178,19 @@ def test_transformer_masked_rows_follow_the_reference():
     sd = {k[3:]: g[k] for k in g.files if k.startswith("sd_")}
     y = R.transformer(torch.from_numpy(g["x"]), sd, depth=2, heads=4, mask=torch.from_numpy(g["mask"]))
     np.testing.assert_allclose(y.numpy(), g["y"], rtol=1e-5, atol=1e-5)
+
+
+def test_octree_ball_query_restatement_is_a_radius_query():
+    """CPU: the octree restatement (octree_ball_query.cpp/.cu) returns, per point, exactly the in-radius set of the
+    brute-force restatement (the octree only prunes), ordered by (leaf, index)."""
+    import oracle
+    rng = np.random.default_rng(0)
+    c = rng.random((1500, 3)).astype(np.float32)
+    idx, sl, leaf = oracle.octree_ball_query(c, 50, 0.08)
+    bi, bo = np.zeros(1500, np.int32), np.array([0, 1500], np.int32)
+    i2, s2 = oracle.ballquery_batch_p(c, bi, bo, 0.08, 50)[:2]
+    for p in range(1500):
+        a = idx[sl[p, 0]:sl[p, 0] + sl[p, 1]]
+        assert set(a) == set(i2[s2[p, 0]:s2[p, 0] + s2[p, 1]])
+        key = leaf[a].astype(np.int64) * 1500 + a
+        assert (np.diff(key) > 0).all()

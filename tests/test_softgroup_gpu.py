@@ -246,3 +246,21 @@ def test_bfs_cluster_device_matches_oracle(dev, class_id, threshold):
     assert rco.size > 3 and not ci.is_cuda
     np.testing.assert_array_equal(co.numpy(), rco)
     np.testing.assert_array_equal(ci.numpy(), rci)
+
+
+def test_octree_ball_query_matches_oracle_order(dev):
+    """octree_ball_query (functions.py:127-157): neighbour lists in the reference's order -- active leaves of the fixed
+    3-level octree breadth first, ascending index inside a leaf -- vs the CPU restatement of octree_ball_query.cpp:19-165
+    + .cu:56-126 (oracle/gcanet_oracle.c).  Parity unpinned by reference data (the reference holds no vectors)."""
+    import oracle
+    from gcanet_amd.softgroup.ops import functions as SGF
+    rng = np.random.default_rng(7)
+    for n, radius in ((3000, 0.06), (500, 0.2), (4096, 0.03)):
+        c = rng.random((n, 3)).astype(np.float32)
+        c[: n // 4] *= 0.25                                           # a dense corner: long lists, several leaves each
+        idx_o, sl_o, leaf_o = oracle.octree_ball_query(c, 40, radius)
+        idx_d, sl_d = SGF.octree_ball_query(torch.from_numpy(c), 40, radius)
+        np.testing.assert_array_equal(SGF._octree_leaf(torch.from_numpy(c).to(dev)).cpu().numpy(), leaf_o)
+        np.testing.assert_array_equal(sl_d.cpu().numpy(), sl_o)
+        np.testing.assert_array_equal(idx_d.cpu().numpy(), idx_o)
+        assert int(sl_o[:, 1].max()) < 1000                           # below the cap, where the two truncation rules agree

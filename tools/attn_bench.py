@@ -62,3 +62,18 @@ def fb():
 
 t = timeit(fb, 3)
 print("bf16 fwd+bwd: %.3f ms  %.1f TFLOP/s (4+14 = 18 B H L^2 D incl. packing)" % (t, 18.0 * BH * L * L * D / t / 1e9))
+
+# IEEE-half variant (the type BASELINE config 5 names)
+o_h = attention.sdpa(q, k, v, None, scale, "fp16")
+print("fp16 vs bf16 kernel: max abs %.3e" % (o_h - o_bf).abs().max().item())
+t = timeit(lambda: attention.sdpa(q, k, v, None, scale, "fp16"))
+print("fp16 fwd: %.3f ms  %.1f TFLOP/s (incl. operand packing)" % (t, 4.0 * BH * L * L * D / t / 1e9))
+
+
+def fbh():
+    o = attention.sdpa(qq, kk, vv, None, scale, "fp16")
+    o.backward(do)
+
+
+t = timeit(fbh, 3)
+print("fp16 fwd+bwd: %.3f ms  %.1f TFLOP/s" % (t, 18.0 * BH * L * L * D / t / 1e9))
