@@ -21,6 +21,7 @@
 //     (knn.cu:125-131) -- bit-exact indices vs oracle/gcanet_oracle.c.
 // Arithmetic follows the oracle's contraction convention (explicit fmaf chains; the file
 // is compiled with -ffp-contract=off).
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -882,8 +883,12 @@ int launch_knn_flagged(const float *x_pm, const float *xx, const unsigned char *
 
 GCN_EXPORT long gcn_knn_tiles_ws_bytes(int B, int C, int N) {
   if (B < 0 || C < 1 || N < 1) return -1;
-  return (long)tile_ws_layout(nullptr, B, C, N).total;
+  size_t need = tile_ws_layout(nullptr, B, C, N).total;
+  if (C == 6 && knn_normal_supported(B, N, 1)) need = std::max(need, knn_normal_ws_bytes(B, N));
+  return (long)need;
 }
+
+GCN_EXPORT int gcn_knn_normal_supported(int B, int N, int k2) { return knn_normal_supported(B, N, k2) ? 1 : 0; }
 
 GCN_EXPORT int gcn_knn_model(const float *x, int B, int C, int N, int k1, int k2, int metric,
                              int64_t *idx, float *val, float *xx_ws, void *tile_ws, void *stream) {
@@ -907,6 +912,15 @@ GCN_EXPORT int gcn_knn_model(const float *x, int B, int C, int N, int k1, int k2
   a.ref_sd = a.q_sd = N; a.ref_sn = a.q_sn = 1;
   a.o_sb = (long)N * kout; a.o_sk = 1; a.o_sq = kout;
   a.dist = val; a.ind = idx;
+  // xyz + normal clouds at filter-friendly sizes: threshold + filter + re-rank (knn_normal.hip), then the exhaustive
+  // kernel for the few queries it flags
+  if (metric == 1 && C == 6 && tile_ws && knn_normal_supported(B, N, k2)) {
+    const unsigned char *flag = nullptr;
+    rc = run_knn_normal(x, xx_ws, B, N, k2, step, kout, idx, val, tile_ws, &flag, st);
+    if (rc) return rc;
+    a.only = flag;
+    return launch_knn<2, 6>(a, B, st);
+  }
   // 3-D clouds: Morton-tiled kernel with bounding-box pruning (identical results, ~5x fewer candidates)
   const bool tiled = tile_ws && k2 <= 64 && N >= 512 && ((metric == 1 && C == 6) || (metric == 0 && C == 3));
   if (tiled)

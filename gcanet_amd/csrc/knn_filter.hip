@@ -441,68 +441,9 @@ __global__ __launch_bounds__(256) void knnf_rerank_kernel(KnnfArgs a) {
       cj[bt] = j;
     }
   }
-  // the k-th smallest key value by an MSB-first search with wave-wide counts (scalar unit), then ONE bitonic sort of
-  // the candidates at or below it instead of a sort + merge per batch of 64
-  const int nb = (total + 63) >> 6;
-  auto kth_key = [&](auto nbc) -> unsigned int {
-    constexpr int NB = decltype(nbc)::value;
-    unsigned int pk = 0;
-    for (int bit = 31; bit >= 0; --bit) {
-      const unsigned int trial = pk | (1u << bit);
-      int c = 0;
-#pragma unroll
-      for (int bt = 0; bt < NB; ++bt) c += __popcll(__ballot(kf[bt] < trial));
-      pk = c >= a.k ? pk : trial;
-    }
-    return pk;
-  };
-  unsigned int pk;
-  switch (nb) {
-    case 1: pk = kth_key(std::integral_constant<int, 1>{}); break;
-    case 2: pk = kth_key(std::integral_constant<int, 2>{}); break;
-    case 3: pk = kth_key(std::integral_constant<int, 3>{}); break;
-    case 4: pk = kth_key(std::integral_constant<int, 4>{}); break;
-    case 5: pk = kth_key(std::integral_constant<int, 5>{}); break;
-    case 6: pk = kth_key(std::integral_constant<int, 6>{}); break;
-    case 7: pk = kth_key(std::integral_constant<int, 7>{}); break;
-    default: pk = kth_key(std::integral_constant<int, 8>{}); break;
-  }
   TopB tb;
-  tb.init();
-  int npend = 0;
-  int nle = 0, nlt = 0;
-#pragma unroll
-  for (int bt = 0; bt < 8; ++bt)
-    if (bt * 64 < total) {
-      nle += __popcll(__ballot(kf[bt] <= pk));
-      nlt += __popcll(__ballot(kf[bt] < pk));
-    }
-  // candidates strictly below the k-th key all belong to the result; of those EQUAL to it the lowest indices fill
-  // the remaining k - nlt places (ties -> lowest index, as the reference's stable insertion).  Usually nle == k and
-  // the index bound is the maximum.
-  int jmax = 0x7fffffff;
-  if (nle > 64) {                                            // wave-uniform, rare: an exact tie straddles the k-th place
-    const int need = a.k - nlt;
-    int pj = 0;
-    for (int bit = 15; bit >= 0; --bit) {                    // largest pj with fewer than `need` tied indices below it
-      const int trial = pj | (1 << bit);
-      int c = 0;
-#pragma unroll
-      for (int bt = 0; bt < 8; ++bt)
-        if (bt * 64 < total) c += __popcll(__ballot(kf[bt] == pk && cj[bt] < trial));
-      pj = c >= need ? pj : trial;
-    }
-    jmax = pj;                                               // the need-th smallest tied index
-  }
+  rank_candidates(kf, cj, total, a.k, lane, tb);
   const bool overflow = false;
-#pragma unroll
-  for (int bt = 0; bt < 8; ++bt)
-    if (bt * 64 < total) {
-      const bool pass = kf[bt] < pk || (kf[bt] == pk && cj[bt] <= jmax);
-      const unsigned long long m = __ballot(pass);
-      if (m) npend = tb.append(m, pass, key_u2f(kf[bt]), cj[bt], npend, lane);
-    }
-  tb.sort_pending(npend, lane);
   // a-posteriori check with the exact k-th key (header comment)
   const float dk = key_u2f((unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(tb.lst >> 32), a.k - 1));
   const float nq = 2.f * a.hn[(long)b * N + q];

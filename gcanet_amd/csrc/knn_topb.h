@@ -2,6 +2,8 @@
 #pragma once
 #include "common.h"
 
+#include <type_traits>
+
 namespace gcn {
 
 typedef unsigned long long u64;
@@ -73,9 +75,82 @@ struct TopB {
 };
 
 
+// The k smallest of up to 512 candidates held 8 per lane as (monotone integer key kf[bt], index cj[bt]), batch bt valid
+// when bt*64 < total (empty slots carry 0xFFFFFFFF), sorted by (key, index) into tb.lst.  The k-th smallest key VALUE
+// comes from an MSB-first search with wave-wide counts (scalar unit), then ONE bitonic sort of the candidates at or
+// below it instead of a sort + merge per batch of 64.  Used by the re-rank kernels of knn_filter.hip / knn_normal.hip.
+__device__ __forceinline__ void rank_candidates(const unsigned int (&kf)[8], const int (&cj)[8], int total, int k, int lane,
+                                                TopB &tb) {
+  const int nb = (total + 63) >> 6;
+  auto kth_key = [&](auto nbc) -> unsigned int {
+    constexpr int NB = decltype(nbc)::value;
+    unsigned int pk = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+      const unsigned int trial = pk | (1u << bit);
+      int c = 0;
+#pragma unroll
+      for (int bt = 0; bt < NB; ++bt) c += __popcll(__ballot(kf[bt] < trial));
+      pk = c >= k ? pk : trial;
+    }
+    return pk;
+  };
+  unsigned int pk;
+  switch (nb) {
+    case 1: pk = kth_key(std::integral_constant<int, 1>{}); break;
+    case 2: pk = kth_key(std::integral_constant<int, 2>{}); break;
+    case 3: pk = kth_key(std::integral_constant<int, 3>{}); break;
+    case 4: pk = kth_key(std::integral_constant<int, 4>{}); break;
+    case 5: pk = kth_key(std::integral_constant<int, 5>{}); break;
+    case 6: pk = kth_key(std::integral_constant<int, 6>{}); break;
+    case 7: pk = kth_key(std::integral_constant<int, 7>{}); break;
+    default: pk = kth_key(std::integral_constant<int, 8>{}); break;
+  }
+  tb.init();
+  int npend = 0;
+  int nle = 0, nlt = 0;
+#pragma unroll
+  for (int bt = 0; bt < 8; ++bt)
+    if (bt * 64 < total) {
+      nle += __popcll(__ballot(kf[bt] <= pk));
+      nlt += __popcll(__ballot(kf[bt] < pk));
+    }
+  // candidates strictly below the k-th key all belong to the result; of those EQUAL to it the lowest indices fill
+  // the remaining k - nlt places (ties -> lowest index, as the reference's stable insertion).  Usually nle == k and
+  // the index bound is the maximum.
+  int jmax = 0x7fffffff;
+  if (nle > 64) {                                            // wave-uniform, rare: an exact tie straddles the k-th place
+    const int need = k - nlt;
+    int pj = 0;
+    for (int bit = 15; bit >= 0; --bit) {                    // largest pj with fewer than `need` tied indices below it
+      const int trial = pj | (1 << bit);
+      int c = 0;
+#pragma unroll
+      for (int bt = 0; bt < 8; ++bt)
+        if (bt * 64 < total) c += __popcll(__ballot(kf[bt] == pk && cj[bt] < trial));
+      pj = c >= need ? pj : trial;
+    }
+    jmax = pj;                                               // the need-th smallest tied index
+  }
+#pragma unroll
+  for (int bt = 0; bt < 8; ++bt)
+    if (bt * 64 < total) {
+      const bool pass = kf[bt] < pk || (kf[bt] == pk && cj[bt] <= jmax);
+      const unsigned long long m = __ballot(pass);
+      if (m) npend = tb.append(m, pass, key_u2f(kf[bt]), cj[bt], npend, lane);
+    }
+  tb.sort_pending(npend, lane);
+}
+
 // exact kNN in the model's expanded form for the queries whose flag byte is set (the safety net of knn_filter.hip);
 // x_pm (B,N,C) point-major, xx (B,N), flag (B,N), idx (B,N,kout).  Implemented in knn.hip on knn_select_kernel.
 int launch_knn_flagged(const float *x_pm, const float *xx, const unsigned char *flag, int B, int N, int C, int k, int step,
                        int kout, int64_t *idx, hipStream_t st);
+
+// knn_points_normals by threshold + filter + re-rank (knn_normal.hip).  The caller runs the flagged queries (flag byte
+// set) through knn_select_kernel afterwards.
+bool knn_normal_supported(int B, int N, int k);
+size_t knn_normal_ws_bytes(int B, int N);
+int run_knn_normal(const float *x, const float *xx, int B, int N, int k, int step, int kout, int64_t *idx, float *val,
+                   void *ws, const unsigned char **flag_out, hipStream_t st);
 
 }  // namespace gcn

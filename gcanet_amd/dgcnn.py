@@ -8,6 +8,9 @@ import torch
 from . import _lib
 
 
+_KNN_WS = {}
+
+
 def _knn_model(x, k1, k2, metric):
     if x.dim() != 3:
         raise RuntimeError("knn: x must be (B, C, N)")
@@ -24,13 +27,16 @@ def _knn_model(x, k1, k2, metric):
     # normals (the synthetic benchmark clouds) more than half of the tiles survive -- slower than the full scan.
     if k2 <= 64 and N >= 512 and metric == 0 and C == 3:
         tile_ws = torch.empty(_lib.lib().gcn_knn_tiles_ws_bytes(B, C, N), dtype=torch.uint8, device=x.device)
+    # xyz + normal clouds at N % 1024 == 0: threshold + filter + re-rank in exact arithmetic (csrc/knn_normal.hip)
+    if metric == 1 and C == 6 and _lib.lib().gcn_knn_normal_supported(B, N, k2):
+        key = ("normal", B, N, x.device)
+        if key not in _KNN_WS:        # one scratch buffer per shape and device (calls are stream-ordered)
+            _KNN_WS[key] = torch.empty(_lib.lib().gcn_knn_tiles_ws_bytes(B, C, N), dtype=torch.uint8, device=x.device)
+        tile_ws = _KNN_WS[key]
     with torch.cuda.device_of(x):
         _lib.call("gcn_knn_model", _lib.ptr(x), B, C, N, k1, k2, metric, _lib.ptr(idx), None, _lib.ptr(xx),
                   _lib.ptr(tile_ws), _lib.stream_of(x), tag="knn_model[B=%d,C=%d,N=%d,k=%d]" % (B, C, N, k2))
     return idx
-
-
-_KNN_WS = {}
 
 
 def knn_feature_pm(x_pm, k1, k2):

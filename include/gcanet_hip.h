@@ -65,6 +65,12 @@ int gcn_knn_model(const float *x, int B, int C, int N, int k1, int k2, int metri
  * against itself (ref == query, k <= 64, nr >= 512). */
 long gcn_knn_tiles_ws_bytes(int B, int C, int N);
 
+/* knn_points_normals (metric 1, C == 6) is served by threshold + filter + re-rank in the reference's exact arithmetic
+ * (csrc/knn_normal.hip: sampled order statistic -> one bit per pair -> exact ranking of ~3k survivors; identical
+ * indices/values) when this returns 1 (N % 1024 == 0, 1024 <= N <= 16384, k2 <= 64) AND tile_ws is given:
+ * gcn_knn_tiles_ws_bytes(B, 6, N) then includes the B*N*N/8-byte bitmap. */
+int gcn_knn_normal_supported(int B, int N, int k2);
+
 /* Feature-space kNN of the in-model `knn` (models/dgcnn-hais-concat-direct-4.py:30-47) for C in {32,64,128} as a
  * bf16 matrix-core PREFILTER + exact f32 re-rank (csrc/knn_filter.hip): same indices as gcn_knn_model(metric 0), bit
  * for bit (ties -> lowest index), several times faster at N >= 1024.

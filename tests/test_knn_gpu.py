@@ -83,7 +83,7 @@ def _knn_model(x, k1, k2, metric):
 @pytest.mark.parametrize("C,N,k1,k2,metric", [
     (3, 2048, 16, 16, 0), (3, 1000, 4, 16, 0), (64, 700, 20, 20, 0), (128, 513, 64, 64, 0), (64, 2048, 64, 64, 0),
     (32, 256, 8, 16, 0), (128, 1028, 33, 33, 0), (64, 64, 64, 64, 0),
-    (6, 2048, 16, 16, 1), (6, 999, 80, 80, 1), (3, 300, 100, 200, 0), (9, 64, 64, 64, 0)])
+    (6, 2048, 16, 16, 1), (6, 1024, 16, 64, 1), (6, 3072, 64, 64, 1), (6, 999, 80, 80, 1), (3, 300, 100, 200, 0), (9, 64, 64, 64, 0)])
 def test_knn_model_matches_oracle_exactly(dev, C, N, k1, k2, metric):
     g = torch.Generator().manual_seed(1234 + C + N)
     x = torch.rand(2, C, N, generator=g)
@@ -195,9 +195,11 @@ def _knn_both(x, k, metric):
 
 
 @pytest.mark.parametrize("kind", ["uniform", "clustered", "grid_ties", "plane", "duplicates"])
-@pytest.mark.parametrize("B,N,k,metric", [(2, 2048, 64, 0), (3, 1000, 20, 0), (2, 4096, 64, 1), (1, 777, 33, 1)])
+@pytest.mark.parametrize("B,N,k,metric", [(2, 2048, 64, 0), (3, 1000, 20, 0), (2, 4096, 64, 1), (2, 2000, 64, 1), (1, 777, 33, 1)])
 def test_knn_tiles_bitexact_vs_bruteforce(dev, kind, B, N, k, metric):
-    """Morton-tiled pruned kNN == brute-force kernel, indices AND distances, on benign and adversarial clouds:
+    """Morton-tiled pruned kNN (and, for the normal metric at N % 1024 == 0, the threshold + filter + re-rank path of
+    knn_normal.hip, which the same workspace switches on) == brute-force kernel, indices AND distances, on benign and
+    adversarial clouds:
     clusters (uneven density), an integer grid (masses of exact ties), a plane (degenerate boxes), duplicated points."""
     g = torch.Generator().manual_seed(N * 7 + k + metric)
     if kind == "uniform":
