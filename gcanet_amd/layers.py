@@ -108,11 +108,34 @@ class CastCache:
                 self.copies.append(img[:n, :k].view(p.shape) if (kp == k) else img[:n, :k].unflatten(1, p.shape[1:]))
             else:
                 self.copies.append(torch.empty_like(p, dtype=dtype))
+        self._segs = None
+
+    def _segment_table(self, chunk=16384):
+        """Device table for gcn_multi_cast_bf16: one record per `chunk` elements of every parameter."""
+        recs = []
+        for p, c in zip(self.params, self.copies):
+            if not (p.is_cuda and p.is_contiguous() and self.dtype == torch.bfloat16):
+                return None
+            img = self.padded.get(id(p))
+            cols = p[0].numel() if p.dim() >= 2 else p.numel()
+            pitch = img.shape[1] if img is not None else cols
+            n = p.numel()
+            for first in range(0, n, chunk):
+                recs.append([p.data_ptr(), c.data_ptr(), cols, pitch, first, min(chunk, n - first)])
+        dev = self.params[0].device
+        return torch.tensor(recs, dtype=torch.int64).to(dev), [p.data_ptr() for p in self.params]
 
     def refresh(self):
         """Call once per step after the optimizer update (or before the first forward)."""
         with torch.no_grad():
-            torch._foreach_copy_(self.copies, self.params)
+            if self._segs is None and self.params and self.params[0].is_cuda:
+                self._segs = self._segment_table() or False
+            if self._segs and self._segs[1] == [p.data_ptr() for p in self.params]:
+                tab = self._segs[0]
+                with torch.cuda.device_of(tab):
+                    _lib.call("gcn_multi_cast_bf16", _lib.ptr(tab), tab.shape[0], _lib.stream_of(tab))
+            else:                                   # CPU tensors, another dtype, or storage that moved
+                torch._foreach_copy_(self.copies, self.params)
         self.version = {id(p): p._version for p in self.params}
         CastCache._live = self
 
@@ -168,6 +191,27 @@ def gemm_own(x2, wq, bias, N, out_f32=False, gn=None, rows_per_cloud=0):
     return out, gsum
 
 
+def _own_wgrad(dy2, x2):
+    """Does csrc/gemm.hip's weight-gradient kernel serve dy2 (M,N)^T @ x2 (M,K)?  (bf16 rows, 16-byte aligned)"""
+    if os.environ.get("GCANET_GEMM", "auto") == "lib":
+        return False
+    return (dy2.is_cuda and dy2.dtype == torch.bfloat16 and x2.dtype == torch.bfloat16 and dy2.shape[1] % 8 == 0
+            and x2.shape[1] % 8 == 0 and dy2.shape[0] >= 512 and dy2.is_contiguous() and x2.is_contiguous())
+
+
+def _wgrad_own(dy2, x2, with_bias):
+    """(dW (N,K) f32, db (N,) f32 | None) = (dy2^T @ x2, column sums of dy2) in ONE pass over the rows (csrc/gemm.hip):
+    no split-K partial products to add up, no separate reduction for the bias gradient."""
+    M, N = dy2.shape
+    K = x2.shape[1]
+    raw = torch.empty(N * K + (N if with_bias else 0), dtype=torch.float32, device=dy2.device)
+    dw = raw[:N * K].view(N, K)
+    db = raw[N * K:] if with_bias else None
+    with torch.cuda.device_of(dy2):
+        _lib.call("gcn_gemm_wgrad_bf16", _lib.ptr(dy2), _lib.ptr(x2), M, N, K, _lib.ptr(dw), _lib.ptr(db), _lib.stream_of(dy2))
+    return dw, db
+
+
 class LinearPMFunction(torch.autograd.Function):
     """y = x @ W^T + b on point-major rows with a split-K weight gradient (see tall_skinny_tn).
     Runs in the autocast dtype (bf16 under torch.autocast, as the plain F.linear would).  With gn_groups > 0 the
@@ -218,15 +262,13 @@ class LinearPMFunction(torch.autograd.Function):
         dy = dy.to(xc.dtype).contiguous()
         rows = dy.reshape(-1, dy.shape[-1])
         with torch.autocast("cuda", enabled=False):
+            db = None
             if ctx.own:
                 N, K = ctx.nk
                 Kx = xc.shape[-1]
                 dx = (dy @ wc[:N]).to(ctx.in_dtypes[0])                   # (.., Kx); the zero-weight padding columns get 0
                 if N % 8 == 0:                                            # csrc/gemm.hip: transpose-read weight gradient
-                    dwf = torch.empty(N, Kx, dtype=torch.float32, device=dy.device)
-                    with torch.cuda.device_of(dy):
-                        _lib.call("gcn_gemm_wgrad_bf16", _lib.ptr(rows), _lib.ptr(xc), rows.shape[0], N, Kx, _lib.ptr(dwf),
-                                  _lib.stream_of(dy))
+                    dwf, db = _wgrad_own(rows, xc.reshape(-1, Kx), ctx.has_bias)
                     dw = dwf[:, :K].to(ctx.in_dtypes[1])
                 else:
                     dw = tall_skinny_tn(rows, xc.reshape(-1, Kx), out_dtype=ctx.in_dtypes[1])[:, :K]
@@ -234,8 +276,14 @@ class LinearPMFunction(torch.autograd.Function):
                 dx = (dy @ wc).to(ctx.in_dtypes[0])
                 if ctx.kx != wc.shape[1]:
                     dx = torch.nn.functional.pad(dx, (0, ctx.kx - wc.shape[1]))
-                dw = tall_skinny_tn(rows, xc.reshape(-1, xc.shape[-1]), out_dtype=ctx.in_dtypes[1])
-            db = rows.sum(0, dtype=torch.float32) if ctx.has_bias else None   # f32 accumulation, no f32 copy of dy
+                x2 = xc.reshape(-1, xc.shape[-1])
+                if _own_wgrad(rows, x2):
+                    dwf, db = _wgrad_own(rows, x2, ctx.has_bias)
+                    dw = dwf.to(ctx.in_dtypes[1])
+                else:
+                    dw = tall_skinny_tn(rows, x2, out_dtype=ctx.in_dtypes[1])
+            if ctx.has_bias and db is None:
+                db = rows.sum(0, dtype=torch.float32)                     # f32 accumulation, no f32 copy of dy
         return dx, dw, db, None
 
 

@@ -486,11 +486,11 @@ int gcn_gn_apply(const void *x, int dtype, const double *gsum, const float *gamm
  * gcn_gemm_stats_ws_bytes(M, N) bytes of scratch for the per-wave partial sums); feed it to gcn_gn_apply.
  * gcn_gemm_wgrad_bf16: dW (N,K) f32 = dY (M,N)^T . X (M,K), the contraction running down the rows of both row-major
  * operands (fragments by ds_read_b64_tr_b16, M split over workgroups, f32 atomics into the zeroed dW); N % 8 == 0,
- * K % 8 == 0. */
+ * K % 8 == 0.  db (N) f32 or NULL: the bias gradient (column sums of dY) from the same pass. */
 long gcn_gemm_stats_ws_bytes(long M, int N);
 int gcn_gemm_bf16(const void *A, const void *W, const float *bias, void *out, int out_f32, long M, int N, int Np,
                   int K, double *gsum, void *stats_ws, int rows_per_cloud, int G, void *stream);
-int gcn_gemm_wgrad_bf16(const void *dY, const void *X, long M, int N, int K, float *dW, void *stream);
+int gcn_gemm_wgrad_bf16(const void *dY, const void *X, long M, int N, int K, float *dW, float *db, void *stream);
 
 /* ------------------------------------------------------------- attention stacks ------ */
 
@@ -531,6 +531,13 @@ int gcn_attention_fwd_f16(const float *q, const float *k, const float *v, const 
 int gcn_attention_bwd_f16(const float *q, const float *k, const float *v, const float *out, const float *dout,
                           const float *lse, const uint8_t *mask, int mask_per_bh, int BH, int Lq, int Lk, int D,
                           float scale, float *dq, float *dk, float *dv, void *ws, void *stream);
+
+/* One launch for many f32 -> bf16 (round to nearest even) copies: the per-step refresh of the low-precision parameter
+ * copies the autocast path of the reference (torch.autocast casts each weight at each use) needs.
+ *   segs_dev: device array of nseg records of six int64 {src f32*, dst bf16*, cols, pitch, first, count}: one
+ *   workgroup converts elements [first, first+count) of a row-major tensor with `cols` columns into an image whose
+ *   rows are `pitch` elements apart (pitch == cols for plain copies). */
+int gcn_multi_cast_bf16(const void *segs_dev, int nseg, void *stream);
 
 #ifdef __cplusplus
 }

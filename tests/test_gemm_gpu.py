@@ -61,6 +61,15 @@ def test_gemm_weight_gradient(dev, M, N, K):
     dY = _bf(torch.randn(M, N, generator=g)).to(dev)
     X = _bf(torch.randn(M, K, generator=g)).to(dev)
     dW = torch.empty(N, K, device=dev)
-    _lib.call("gcn_gemm_wgrad_bf16", _lib.ptr(dY), _lib.ptr(X), M, N, K, _lib.ptr(dW), _lib.stream_of(X))
+    _lib.call("gcn_gemm_wgrad_bf16", _lib.ptr(dY), _lib.ptr(X), M, N, K, _lib.ptr(dW), None, _lib.stream_of(X))
     ref = dY.float().t() @ X.float()
     np.testing.assert_allclose(dW.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
+    # with the bias gradient (column sums of dY) from the same pass, adjacent and separate accumulators
+    raw = torch.empty(N * K + N, device=dev)
+    _lib.call("gcn_gemm_wgrad_bf16", _lib.ptr(dY), _lib.ptr(X), M, N, K, _lib.ptr(raw), _lib.ptr(raw[N * K:]), _lib.stream_of(X))
+    db2 = torch.full((N,), 7.0, device=dev)
+    _lib.call("gcn_gemm_wgrad_bf16", _lib.ptr(dY), _lib.ptr(X), M, N, K, _lib.ptr(dW), _lib.ptr(db2), _lib.stream_of(X))
+    dbr = dY.float().sum(0)
+    for got in (raw[N * K:], db2):
+        np.testing.assert_allclose(got.cpu().numpy(), dbr.cpu().numpy(), rtol=1e-4, atol=1e-4 * float(dbr.abs().max()) + 1e-5)
+    np.testing.assert_allclose(raw[:N * K].view(N, K).cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-4 * float(ref.abs().max()))

@@ -24,7 +24,7 @@ def timed(fn, iters=20):
     return e0.elapsed_time(e1) / iters * 1e3
 
 
-for N, K in [(512, 256), (256, 512), (256, 256), (256, 832), (64, 256), (128, 272), (1024, 256), (32, 256)]:
+for N, K in [(512, 1280), (512, 256), (256, 512), (256, 256), (256, 832), (64, 256), (128, 272), (1024, 256), (32, 256)]:
     A = torch.randn(M, K, device=dev).bfloat16()
     W = (torch.randn(N, K, device=dev) / K ** 0.5).bfloat16()
     b = torch.randn(N, device=dev)
@@ -40,9 +40,10 @@ for N, K in [(512, 256), (256, 512), (256, 256), (256, 832), (64, 256), (128, 27
                                       None, None, 0, 0, st))
     t_lib = timed(lambda: torch.nn.functional.linear(A, W, bb))
     dY = torch.randn(M, N, device=dev).bfloat16()
-    dW = torch.empty(N, K, device=dev)
-    t_wg = timed(lambda: _lib.call("gcn_gemm_wgrad_bf16", _lib.ptr(dY), _lib.ptr(A), M, N, K, _lib.ptr(dW), st))
-    t_wl = timed(lambda: torch.bmm(dY.view(32, M // 32, N).transpose(1, 2), A.view(32, M // 32, K)).sum(0))
+    raw = torch.empty(N * K + N, device=dev)
+    t_wg = timed(lambda: _lib.call("gcn_gemm_wgrad_bf16", _lib.ptr(dY), _lib.ptr(A), M, N, K, _lib.ptr(raw), _lib.ptr(raw[N * K:]), st))
+    t_wl = timed(lambda: (torch.bmm(dY.view(32, M // 32, N).transpose(1, 2), A.view(32, M // 32, K)).sum(0),
+                          dY.sum(0, dtype=torch.float32)))
     fl = 2.0 * M * N * K
-    print("N=%4d K=%4d  fwd mine %6.1f us (%5.0f TF)%s  plain %6.1f us  lib %6.1f us | wgrad mine %6.1f us  lib(split-K bmm+sum) %6.1f us" % (
+    print("N=%4d K=%4d  fwd mine %6.1f us (%5.0f TF)%s  plain %6.1f us  lib %6.1f us | wgrad+dbias mine %6.1f us  lib(split-K bmm+sum, sum) %6.1f us" % (
         N, K, t_mine, fl / t_mine / 1e6, " +GN stats" if G else "", t_plain, t_lib, t_wg, t_wl))
