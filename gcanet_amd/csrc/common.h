@@ -154,21 +154,23 @@ inline void exscan_rows(hipStream_t st, int rows, int m, int32_t *v, int32_t *bs
   scan_apply_kernel<<<dim3(nb, rows), 1024, 0, st>>>(m, v, bsum, copy);
 }
 
-// Zero up to three device spans with as few hipMemsetAsync calls as possible: spans that are adjacent in memory
+// Zero up to four device spans with as few hipMemsetAsync calls as possible: spans that are adjacent in memory
 // (the Python side allocates the small per-call accumulators back to back) collapse into one fill -- a fill of a few
 // hundred bytes costs ~4.5 us of GPU time like any other launch, and a training step had ~80 of them.
 struct ZeroSpan { void *p; size_t n; };
-inline hipError_t zero_spans(hipStream_t st, ZeroSpan a, ZeroSpan b = {nullptr, 0}, ZeroSpan c = {nullptr, 0}) {
-  ZeroSpan v[3] = {a, b, c};
-  // sort by address (3 elements), skip empties
-  for (int i = 0; i < 3; ++i)
-    for (int j = i + 1; j < 3; ++j)
+inline hipError_t zero_spans(hipStream_t st, ZeroSpan a, ZeroSpan b = {nullptr, 0}, ZeroSpan c = {nullptr, 0},
+                             ZeroSpan d = {nullptr, 0}) {
+  constexpr int NS = 4;
+  ZeroSpan v[NS] = {a, b, c, d};
+  // sort by address, skip empties
+  for (int i = 0; i < NS; ++i)
+    for (int j = i + 1; j < NS; ++j)
       if (v[j].p && (!v[i].p || (char *)v[j].p < (char *)v[i].p)) { ZeroSpan t = v[i]; v[i] = v[j]; v[j] = t; }
   int i = 0;
-  while (i < 3 && v[i].p) {
+  while (i < NS && v[i].p) {
     char *lo = (char *)v[i].p, *hi = lo + v[i].n;
     int j = i + 1;
-    while (j < 3 && v[j].p && (char *)v[j].p <= hi) {             // exactly adjacent (or overlapping) spans only
+    while (j < NS && v[j].p && (char *)v[j].p <= hi) {            // exactly adjacent (or overlapping) spans only
       char *h2 = (char *)v[j].p + v[j].n;
       if (h2 > hi) hi = h2;
       ++j;

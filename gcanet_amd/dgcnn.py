@@ -405,7 +405,12 @@ def _route_backward_fused(dout_pm, gamma, beta, ymax, ymin, amax, amin, mean_rst
     jsel = torch.empty(B, N, Cout, dtype=torch.int64, device=dev) if want_jsel else None
     dsp = torch.empty(B, N, Cout, dtype=torch.float32, device=dev) if want_dsp else None
     from .layers import _acc_buffers
-    S, dgamma, dbeta = _acc_buffers(B * G * 2, Cout, dev)      # adjacent: one zero fill inside gcn_route_bwd
+    dsp_ws = None
+    if want_dsp and (B * G * 2 * 8 + 2 * Cout * 4) % 16 == 0:
+        # scratch of the partitioned LDS scatter, right behind the accumulators: one zero fill inside gcn_route_bwd
+        S, dgamma, dbeta, dsp_ws = _acc_buffers(B * G * 2, Cout, dev, tail_bytes=_lib.lib().gcn_route_bwd_ws_bytes(B, N, Cout))
+    else:
+        S, dgamma, dbeta = _acc_buffers(B * G * 2, Cout, dev)
     ymin = ymin if (ymin is not None and ymin.numel()) else None
     amin = amin if (amin is not None and amin.numel()) else None
     Ac = torch.empty(B, Cout, dtype=torch.float32, device=dev)
@@ -413,7 +418,7 @@ def _route_backward_fused(dout_pm, gamma, beta, ymax, ymin, amax, amin, mean_rst
     _run("gcn_route_bwd", ymax, _lib.ptr(dout_pm), _lib.ptr(ymax), _lib.ptr(ymin), _lib.ptr(amax), _lib.ptr(amin),
          _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(mean_rstd), _lib.ptr(idx), B, N, k, Cout, G, float(slope),
          _lib.ptr(coef), _lib.ptr(jsel), None, _lib.ptr(dsp), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(S),
-         float(count_per_group), _lib.ptr(Ac), _lib.ptr(Bc))
+         float(count_per_group), _lib.ptr(Ac), _lib.ptr(Bc), _lib.ptr(dsp_ws))
     return jsel, coef, Ac, Bc, dgamma, dbeta, dsp
 
 

@@ -17,14 +17,16 @@ def _run(name, like, *args):
         _lib.call(name, *args, _lib.stream_of(like))
 
 
-def _acc_buffers(n_f64, C, device):
+def _acc_buffers(n_f64, C, device, tail_bytes=0):
     """(S (n_f64,) f64, dgamma (C,) f32, dbeta (C,) f32) carved back to back from ONE allocation, so that the library
-    zeroes them with a single fill (csrc/common.h:zero_spans) instead of three 4.5-us launches."""
-    raw = torch.empty(n_f64 * 8 + 2 * C * 4, dtype=torch.uint8, device=device)
+    zeroes them with a single fill (csrc/common.h:zero_spans) instead of three 4.5-us launches.  tail_bytes > 0: a
+    fourth return value, a uint8 scratch view that starts right behind dbeta (its zeroed header joins the same fill)."""
+    head = n_f64 * 8 + 2 * C * 4
+    raw = torch.empty(head + tail_bytes, dtype=torch.uint8, device=device)
     S = raw[:n_f64 * 8].view(torch.float64)
     dg = raw[n_f64 * 8:n_f64 * 8 + C * 4].view(torch.float32)
-    db = raw[n_f64 * 8 + C * 4:].view(torch.float32)
-    return S, dg, db
+    db = raw[n_f64 * 8 + C * 4:head].view(torch.float32)
+    return (S, dg, db, raw[head:]) if tail_bytes else (S, dg, db)
 
 
 class GroupNormReLUFunction(torch.autograd.Function):

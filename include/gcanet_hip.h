@@ -417,12 +417,17 @@ int gcn_topk_rows(const void *x, int dtype, long R, int NK, int k, float *vals, 
  * call), dgamma/dbeta (Cout) and S (B,G,2) f64 = [sum gamma*gz, sum gamma*gz*yhat] (zeroed by the call).
  * idx (B,N,k) int64 may be NULL when neither msel nor dsp is wanted.  Ac/Bc (B,Cout) f32 (both or
  * neither): the affine GroupNorm terms of dy = coef*[j==jsel] + Ac + Bc*y for count_per_group =
- * (Cout/G)*N*k conv outputs per group, evaluated in double from S and mean_rstd. */
+ * (Cout/G)*N*k conv outputs per group, evaluated in double from S and mean_rstd.
+ * dsp_ws: NULL, or gcn_route_bwd_ws_bytes(B,N,Cout) bytes of scratch (16-byte aligned; its first 4 bytes are zeroed by
+ * the call -- place it right behind dbeta and the fill merges with the other accumulators').  With it, and Cout in
+ * {64,128}, N <= 65536, N*Cout % 65536 == 0, dsp is built by a destination-partitioned LDS scatter in 64-bit fixed
+ * point (bitwise reproducible, every element written, no zero fill) instead of B*N*Cout global f32 atomics. */
+long gcn_route_bwd_ws_bytes(int B, int N, int Cout);
 int gcn_route_bwd(const float *dout_pm, const float *ymax, const float *ymin, const uint8_t *amax,
                   const uint8_t *amin, const float *gamma, const float *beta, const float *mean_rstd,
                   const int64_t *idx, int B, int N, int k, int Cout, int G, float slope, float *coef,
                   int64_t *jsel, int64_t *msel, float *dsp, float *dgamma, float *dbeta, double *S,
-                  double count_per_group, float *Ac, float *Bc, void *stream);
+                  double count_per_group, float *Ac, float *Bc, void *dsp_ws, void *stream);
 
 /* Weight gradient of the fused EdgeConv block from the pieces above, all row reductions in one pass on the
  * f32 matrix cores:  dW (Cout,2C) = [dW1 - dWd | dWd] with dWd = D2^T x and

@@ -125,3 +125,59 @@ def test_new_entry_points_handle_empty_and_reject_bad_shapes(dev):
         _lib.call("gcn_normal_edge_fwd", _lib.ptr(t), _lib.ptr(i64), _lib.ptr(t), 1, 8, 300, 8, 2, _lib.ptr(t), _lib.ptr(t),
                   _lib.ptr(u8), _lib.ptr(u8), _lib.ptr(d), st)                                              # k > 256
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("B,N,k,Cout,kind", [(2, 1024, 16, 64, "random"), (3, 512, 20, 128, "random"), (1, 2048, 64, 128, "random"),
+                                            (2, 1024, 8, 64, "one_hub"), (1, 512, 8, 128, "few_hubs"),
+                                            (1, 4096, 8, 64, "one_hub"), (1, 8192, 4, 128, "few_hubs")])
+def test_route_bwd_lds_scatter_matches_definition(dev, B, N, k, Cout, kind):
+    """gcn_route_bwd's sparse scatter Dsp[b, idx[b,n,jsel[n,c]], c] += coef[b,n,c] through the partition-staged LDS sum
+    (dsp_ws given) == the f32-atomics path (dsp_ws NULL) == an f64 index_add of the returned coef, including the
+    degenerate graphs where every point selects the same neighbour (one accumulator takes N addends; at N >= 4096 a
+    tile files more than DSP_CAP entries under one partition and the overflow list is used).  Fixed-point sums: bitwise reproducible run to run."""
+    from gcanet_amd import _lib
+    from gcanet_amd.layers import _acc_buffers
+    g = torch.Generator().manual_seed(B * 1000 + N + Cout + k)
+    G = 2
+    dout = torch.randn(B, N, Cout, generator=g).to(dev)
+    dout[0, 0] *= 300.0
+    ymax = torch.randn(B, N, Cout, generator=g).to(dev)
+    amax = torch.randint(0, k, (B, N, Cout), generator=g, dtype=torch.uint8).to(dev)
+    gamma = (torch.rand(Cout, generator=g) + 0.5).to(dev)
+    beta = torch.randn(Cout, generator=g).to(dev)
+    mean_rstd = torch.stack([torch.randn(B, G, generator=g), torch.rand(B, G, generator=g) + 0.5], -1).to(dev).contiguous()
+    if kind == "random":
+        idx = torch.randint(0, N, (B, N, k), generator=g)
+    elif kind == "one_hub":
+        idx = torch.full((B, N, k), 7, dtype=torch.int64)
+    else:
+        idx = torch.randint(0, 3, (B, N, k), generator=g) * (N // 3)
+    idx = idx.to(dev)
+
+    def run(with_ws):
+        coef = torch.empty(B, N, Cout, device=dev)
+        dsp = torch.full((B, N, Cout), float("nan"), device=dev)
+        Ac, Bc = torch.empty(B, Cout, device=dev), torch.empty(B, Cout, device=dev)
+        if with_ws:
+            S, dg, db, ws = _acc_buffers(B * G * 2, Cout, dev, tail_bytes=_lib.lib().gcn_route_bwd_ws_bytes(B, N, Cout))
+        else:
+            (S, dg, db), ws = _acc_buffers(B * G * 2, Cout, dev), None
+        _lib.call("gcn_route_bwd", _lib.ptr(dout), _lib.ptr(ymax), None, _lib.ptr(amax), None, _lib.ptr(gamma), _lib.ptr(beta),
+                  _lib.ptr(mean_rstd), _lib.ptr(idx), B, N, k, Cout, G, 0.2, _lib.ptr(coef), None, None, _lib.ptr(dsp),
+                  _lib.ptr(dg), _lib.ptr(db), _lib.ptr(S), float((Cout // G) * N * k), _lib.ptr(Ac), _lib.ptr(Bc),
+                  _lib.ptr(ws), _lib.stream_of(dout))
+        return coef, dsp, dg.clone(), db.clone(), S.clone()
+
+    coef1, dsp1, dg1, db1, S1 = run(True)
+    coef0, dsp0, dg0, db0, S0 = run(False)
+    assert torch.equal(coef1, coef0)
+    msel = torch.gather(idx, 2, amax.long())                                   # (B,N,Cout)
+    ref = torch.zeros(B, N, Cout, dtype=torch.float64, device=dev)
+    ref.scatter_add_(1, msel, coef1.double())
+    scale = ref.abs().max().item()
+    assert torch.isfinite(dsp1).all()
+    assert (dsp1.double() - ref).abs().max().item() <= 1e-7 * scale + 1e-30     # one final rounding to f32
+    assert (dsp0.double() - ref).abs().max().item() <= 1e-4 * scale + 1e-30     # f32 atomics in arbitrary order
+    for a, b in ((dg1, dg0), (db1, db0), (S1.float(), S0.float())):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-4 * float(b.abs().max()))
+    assert torch.equal(run(True)[1], dsp1)                                     # bitwise reproducible
