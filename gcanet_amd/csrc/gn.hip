@@ -316,6 +316,105 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const void *__restric
   }
 }
 
+// ---------------------------------------------------------------- backward of  max_n [ReLU](GroupNorm(x))
+// The gradient of the pooled output reaches ONE row per (sample, channel): dy is zero except at (b, arg[b,c], c).
+// GroupNorm's input gradient is then  dx = rstd*gamma*g*[n == arg] + A[b,g] + Bx[b,g]*x  with per-(sample, group)
+// constants -- the two group sums run over B*C values, not B*N*C.  Three launches: the sums (tiny), the dense affine
+// map (reads x, writes dx: two tensor passes instead of a zero fill, a scatter and the five passes of the generic
+// reduce + apply), and the B*C sparse corrections.
+template <bool BF16>
+__device__ __forceinline__ float load1(const void *p, long i) {
+  return BF16 ? bf2f(reinterpret_cast<const unsigned short *>(p)[i]) : reinterpret_cast<const float *>(p)[i];
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(1024) void gn_max_bwd_sums_kernel(const void *__restrict__ x, const float *__restrict__ gamma,
+                                                               const float *__restrict__ beta, const float *__restrict__ mean_rstd,
+                                                               const float *__restrict__ dout, const int64_t *__restrict__ arg,
+                                                               int B, int N, int C, int G, int relu, float *__restrict__ AB,
+                                                               float *__restrict__ sp, float *__restrict__ dgamma,
+                                                               float *__restrict__ dbeta) {
+  __shared__ double p1[1024], p2[1024];
+  const int cpg = C / G;
+  const double M = (double)cpg * (double)N;
+  for (int c0 = 0; c0 < C; c0 += 1024) {
+    const int c = c0 + threadIdx.x;
+    const bool live = c < C;
+    const float ga = live ? gamma[c] : 0.f, be = live ? beta[c] : 0.f;
+    const int g = live ? c / cpg : 0;
+    float dg = 0.f, db = 0.f;
+    for (int b = 0; b < B; ++b) {
+      double s1 = 0.0, s2 = 0.0;
+      if (live) {
+        const float mean = mean_rstd[((long)b * G + g) * 2], rstd = mean_rstd[((long)b * G + g) * 2 + 1];
+        const long n = arg[(long)b * C + c];
+        const float xv = load1<BF16>(x, ((long)b * N + n) * C + c);
+        const float xh = (xv - mean) * rstd;
+        const float z = xh * ga + be;
+        const float gz = (relu && !(z > 0.f)) ? 0.f : dout[(long)b * C + c];
+        dg = fmaf(gz, xh, dg);
+        db += gz;
+        s1 = (double)(ga * gz);
+        s2 = (double)(ga * gz) * (double)xh;
+        sp[(long)b * C + c] = rstd * ga * gz;
+      }
+      p1[threadIdx.x] = s1;
+      p2[threadIdx.x] = s2;
+      __syncthreads();
+      // groups whose channels lie in this chunk: one thread per group adds its channels in order (deterministic)
+      const int g0 = c0 / cpg, g1 = min(G, (min(C, c0 + 1024) + cpg - 1) / cpg);
+      if ((int)threadIdx.x < g1 - g0) {
+        const int gg = g0 + threadIdx.x;
+        const int lo = max(gg * cpg, c0) - c0, hi = min((gg + 1) * cpg, c0 + 1024) - c0;
+        double a1 = 0.0, a2 = 0.0;
+        for (int i = lo; i < hi; ++i) { a1 += p1[i]; a2 += p2[i]; }
+        // a group may straddle chunks (cpg > 1024): accumulate in AB as raw sums first (f32 pairs hold them below)
+        double *acc = reinterpret_cast<double *>(AB) + ((long)b * G + gg) * 2;   // AB doubles as (B,G,2) f64 scratch
+        if (max(gg * cpg, c0) == gg * cpg) { acc[0] = a1; acc[1] = a2; } else { acc[0] += a1; acc[1] += a2; }
+        if (min((gg + 1) * cpg, c0 + 1024) == (gg + 1) * cpg) {               // group complete: the affine constants
+          const double mu = (double)mean_rstd[((long)b * G + gg) * 2], rs = (double)mean_rstd[((long)b * G + gg) * 2 + 1];
+          const double Bg = (-(rs * rs)) * acc[1] / M;
+          const double Ag = (-(rs * acc[0])) / M - Bg * mu;
+          float *o = AB + ((long)B * G * 2) * 2 + ((long)b * G + gg) * 2;       // floats behind the f64 scratch
+          o[0] = (float)Ag;
+          o[1] = (float)Bg;
+        }
+      }
+      __syncthreads();
+    }
+    if (live) { dgamma[c] = dg; dbeta[c] = db; }
+  }
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void gn_max_bwd_dense_kernel(const void *__restrict__ x, const float *__restrict__ ab, int N,
+                                                               int C, int G, void *__restrict__ dx) {
+  const int b = blockIdx.y;
+  const long per = (long)N * C / 4;
+  const int cpg = C / G;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < per; e += (long)gridDim.x * 256) {
+    const int g = (int)((e * 4) % C) / cpg;
+    const float A = ab[((long)b * G + g) * 2], Bx = ab[((long)b * G + g) * 2 + 1];
+    float xv[4], o[4];
+    load4<BF16>(x, (long)b * N * C + e * 4, xv);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = fmaf(Bx, xv[i], A);
+    store4<BF16>(dx, (long)b * N * C + e * 4, o);
+  }
+}
+
+template <bool BF16>
+__global__ void gn_max_bwd_sparse_kernel(const void *__restrict__ x, const float *__restrict__ ab, const float *__restrict__ sp,
+                                         const int64_t *__restrict__ arg, int B, int N, int C, int G, void *__restrict__ dx) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * C) return;
+  const int b = (int)(i / C), c = (int)(i % C), g = c / (C / G);
+  const long o = ((long)b * N + arg[i]) * C + c;
+  const float v = fmaf(ab[((long)b * G + g) * 2 + 1], load1<BF16>(x, o), ab[((long)b * G + g) * 2]) + sp[i];
+  if (BF16) reinterpret_cast<unsigned short *>(dx)[o] = f2bf(v);
+  else reinterpret_cast<float *>(dx)[o] = v;
+}
+
 static int gn_check(const char *who, int B, int N, int C, int G, int dtype) {
   GCN_REQUIRE(dtype == 0 || dtype == 1, "%s: dtype must be 0 (f32) or 1 (bf16)", who);
   GCN_REQUIRE(B >= 0 && N >= 1 && C >= 4 && G >= 1 && C % G == 0, "%s: bad shape", who);
@@ -412,4 +511,34 @@ GCN_EXPORT int gcn_gn_max_fwd(const void *x, int dtype, const float *gamma, cons
   }
   gn_max_unpack_kernel<<<cdiv((long)B * C, 256), 256, 0, st>>>(best, (long)B * C, out_max, out_arg);
   return check_launch("gn_max_fwd");
+}
+
+GCN_EXPORT long gcn_gn_max_bwd_ws_floats(int B, int C, int G) {
+  if (B < 0 || C < 1 || G < 1) return -1;
+  return 6L * B * G + (long)B * C;             // (B,G,2) f64 sums, (B,G,2) f32 constants, (B,C) f32 sparse terms
+}
+
+GCN_EXPORT int gcn_gn_max_bwd(const void *x, int dtype, const float *gamma, const float *beta, const float *mean_rstd,
+                              const float *dout, const int64_t *arg, int B, int N, int C, int G, int relu, void *dx,
+                              float *dgamma, float *dbeta, float *ws, void *stream) {
+  int rc = gn_check("gcn_gn_max_bwd", B, N, C, G, dtype);
+  if (rc) return rc;
+  GCN_REQUIRE(x && gamma && beta && mean_rstd && dout && arg && dx && dgamma && dbeta && ws, "gcn_gn_max_bwd: null pointer");
+  GCN_REQUIRE(((uintptr_t)ws & 7) == 0, "gcn_gn_max_bwd: ws must be 8-byte aligned");
+  if (B == 0) return GCN_OK;
+  hipStream_t st = (hipStream_t)stream;
+  float *ab = ws + 4L * B * G;
+  float *sp = ws + 6L * B * G;
+  const int g2 = (int)(((long)N * C / 4 + 255) / 256 > 2048 ? 2048 : ((long)N * C / 4 + 255) / 256);
+  const int g3 = (int)cdiv((long)B * C, 256);
+  if (dtype == 1) {
+    gn_max_bwd_sums_kernel<true><<<1, 1024, 0, st>>>(x, gamma, beta, mean_rstd, dout, arg, B, N, C, G, relu, ws, sp, dgamma, dbeta);
+    gn_max_bwd_dense_kernel<true><<<dim3(g2, B), 256, 0, st>>>(x, ab, N, C, G, dx);
+    gn_max_bwd_sparse_kernel<true><<<g3, 256, 0, st>>>(x, ab, sp, arg, B, N, C, G, dx);
+  } else {
+    gn_max_bwd_sums_kernel<false><<<1, 1024, 0, st>>>(x, gamma, beta, mean_rstd, dout, arg, B, N, C, G, relu, ws, sp, dgamma, dbeta);
+    gn_max_bwd_dense_kernel<false><<<dim3(g2, B), 256, 0, st>>>(x, ab, N, C, G, dx);
+    gn_max_bwd_sparse_kernel<false><<<g3, 256, 0, st>>>(x, ab, sp, arg, B, N, C, G, dx);
+  }
+  return check_launch("gn_max_bwd");
 }

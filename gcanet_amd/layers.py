@@ -331,8 +331,8 @@ def global_max_pool(x):
 
 class GroupNormReLUMaxFunction(torch.autograd.Function):
     """max over points of [ReLU](GroupNorm(x)) for x (B,N,C) -> (B,C), the (B,N,C) activation never written
-    (csrc/gn.hip: gn_apply_max_kernel).  Backward routes the gradient to the arg-max rows and runs the ordinary
-    GroupNorm backward on that (B,N,C) gradient."""
+    (csrc/gn.hip: gn_apply_max_kernel).  Backward: the gradient reaches one row per (sample, channel), so the GroupNorm
+    input gradient is a per-(sample, group) affine map of x plus B*C corrections (gcn_gn_max_bwd) -- no dense dy."""
 
     @staticmethod
     def forward(ctx, x, gamma, beta, groups, eps, relu):
@@ -358,12 +358,13 @@ class GroupNormReLUMaxFunction(torch.autograd.Function):
         x, ga, be, mean_rstd, arg = ctx.saved_tensors
         groups, relu, dt = ctx.cfg
         B, N, C = x.shape
-        dy = torch.zeros(B, N, C, dtype=x.dtype, device=x.device)
-        dy.scatter_(1, arg.unsqueeze(1), dout.to(x.dtype).unsqueeze(1))
         dx = torch.empty_like(x)
-        ws, dgamma, dbeta = _acc_buffers(B * groups * 2, C, x.device)
-        _run("gcn_gn_bwd", x, _lib.ptr(dy), _lib.ptr(x), dt, _lib.ptr(ga), _lib.ptr(be), _lib.ptr(mean_rstd), B, N, C,
-             groups, int(relu), _lib.ptr(dx), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ws))
+        dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+        ws = torch.empty(_lib.lib().gcn_gn_max_bwd_ws_floats(B, C, groups), dtype=torch.float32, device=x.device)
+        _run("gcn_gn_max_bwd", x, _lib.ptr(x), dt, _lib.ptr(ga), _lib.ptr(be), _lib.ptr(mean_rstd),
+             _lib.ptr(dout.float().contiguous()), _lib.ptr(arg), B, N, C, groups, int(relu), _lib.ptr(dx), _lib.ptr(dgamma),
+             _lib.ptr(dbeta), _lib.ptr(ws))
         return dx, dgamma, dbeta, None, None, None
 
 

@@ -469,6 +469,16 @@ int gcn_gn_max_fwd(const void *x, int dtype, const float *gamma, const float *be
                    float eps, int relu, float *out_max, int64_t *out_arg, float *mean_rstd, double *gsum_ws,
                    void *best_ws, void *stream);
 
+/* Backward of gcn_gn_max_fwd for dout (B,C) f32 routed to the rows out_arg (B,C): the upstream gradient is zero
+ * except at one row per (sample, channel), so dx = rstd*gamma*g*[n == arg] + A[b,g] + Bx[b,g]*x with per-(sample,
+ * group) constants from sums over B*C values: one dense affine pass (read x, write dx) + B*C corrections instead of
+ * a zero fill, a scatter and the generic two-pass gcn_gn_bwd.  dx same dtype as x; dgamma/dbeta (C) f32 (written);
+ * ws: gcn_gn_max_bwd_ws_floats(B,C,G) floats, 8-byte aligned. */
+long gcn_gn_max_bwd_ws_floats(int B, int C, int G);
+int gcn_gn_max_bwd(const void *x, int dtype, const float *gamma, const float *beta, const float *mean_rstd,
+                   const float *dout, const int64_t *arg, int B, int N, int C, int G, int relu, void *dx,
+                   float *dgamma, float *dbeta, float *ws, void *stream);
+
 /* Parameter head epilogue (M4:664-676): p (R,22) f32 rows; the triples 4:7, 8:11, 15:18 are divided by
  * (their L2 norm + 1e-12), the other columns pass through -- one kernel instead of the slice / norm / div / cat
  * chain; _bwd is its vector-Jacobian product (grad_in (R,22) fully written). */
