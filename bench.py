@@ -137,21 +137,32 @@ def kernel_model(tag):
 
 
 def pmc_traffic(tag):
-    """HBM bytes per launch of the kernel behind `tag`, from the committed rocprofv3 PMC passes of this same
-    command (profiles/r01_pmc_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 read
-    correction applied).  Counters cannot be read from inside the process, hence the file; null if absent or if
-    the profile was taken at another shape."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    """HBM bytes per call of the entry point behind `tag` (all the kernels it launches, summed), from the committed
+    rocprofv3 PMC passes of this same command (profiles/r02_pmc_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE
+    runs, gfx950 read correction applied; tools/pmc_traffic.py).  Counters cannot be read from inside the process,
+    hence the file; null if absent or if the profile was taken at another shape."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
     if not os.path.exists(path) or "B=8" not in tag or "N=8192" not in tag:
         return None
     ks = json.load(open(path))["kernels"]
-    name = {"knn_model[B=8,C=64": "gcn::knn_mfma16_kernel<64, 64", "knn_model[B=8,C=6,": "gcn::knn_select_kernel<1, 8, 2, 6>",
-            "edgeconv_fwd[B=8,N=8192,k=64,C=64,Cout=128": "gcn::edgeconv_fwd_bf16_kernel<8, 4, 1, true, true, 64>"}
-    for pre, kn in name.items():
+    parts = {
+        "knn_model[B=8,C=64": ["gcn::knnf_colsum_kernel", "gcn::knnf_prep_kernel", "gcn::knnf_stream_kernel<4, 0>",
+                               "gcn::knnf_stream_kernel<4, 1>", "gcn::knnf_rerank_kernel<64>", "gcn::knnf_fallback_kernel<64>"],
+        "knn_model[B=8,C=6,": ["gcn::knnn_prep_kernel", "gcn::knnn_sample_kernel", "gcn::knnn_filter_kernel",
+                               "gcn::knnn_rerank_kernel"],
+        "edgeconv_fwd[B=8,N=8192,k=64,C=64,Cout=128": ["gcn::edgeconv_center_kernel<4, 4>",
+                                                       "gcn::edgeconv_fwd_q_kernel<4, 4, 2, true, true, true>"],
+    }
+    for pre, names in parts.items():
         if tag.startswith(pre):
-            for full, rec in ks.items():          # template arguments appended later (e.g. the list-registers count) still match
-                if full.startswith(kn):
-                    return rec["hbm_bytes_corrected"]
+            tot, found = 0, False
+            for kn in names:
+                for full, rec in ks.items():
+                    if full.startswith(kn):
+                        tot += rec["hbm_bytes_corrected"]
+                        found = True
+                        break
+            return tot if found else None
     return None
 
 
@@ -493,6 +504,12 @@ def main():
         roofline = {"kernel": tag, "bound": km["bound"], "achieved": round(ach, 2), "peak": km["peak"],
                     "unit": "TFLOP/s", "frac": round(ach / km["peak"], 4), "traffic": pmc_traffic(tag),
                     "avg_launch_ms": round(avg_ms, 4), "launches_per_step": n / args.steps}
+        if tag.startswith("knn_model"):
+            # since round 2 the N^2 part of this entry point is a FILTER (bf16 MFMA for feature space, packed f32 VALU
+            # for xyz+normal) and only ~3k survivors per query get the exact f32 arithmetic: `achieved` stays the
+            # algorithmic 2*B*N^2*C f32 FLOPs of SURVEY 8d over the entry point's whole duration (all its kernels)
+            roofline["note"] = ("algorithmic exact-f32 distance FLOPs / time of the whole entry point (prep + threshold + "
+                                "filter + exact re-rank kernels); the N^2 pass itself runs as a bf16-MFMA / packed-f32 filter")
     knn_ms = sum(tot for tag, (n, tot) in timing.items() if tag.startswith("knn_model")) / args.steps
     res = {
         "metric": "point-clouds/sec fwd+bwd (N=%d,k=%d)" % (N, args.k), "value": round(clouds_per_s, 3),

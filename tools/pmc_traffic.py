@@ -1,4 +1,4 @@
-"""Build profiles/r01_pmc_traffic.json from two rocprofv3 PMC passes of the bench command:
+"""Build profiles/r02_pmc_traffic.json from two rocprofv3 PMC passes of the bench command:
 
   cd /tmp && export TMPDIR=/tmp
   rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d /tmp/pf -- python3 $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline
@@ -27,7 +27,7 @@ def per_kernel(path, counter):
 
 def main():
     f, w = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
-    out = sys.argv[3] if len(sys.argv) > 3 else "profiles/r01_pmc_traffic.json"
+    out = sys.argv[3] if len(sys.argv) > 3 else "profiles/r02_pmc_traffic.json"
     ks = {}
     for name in f:
         fe = sum(f[name]) / len(f[name])
