@@ -25,6 +25,8 @@
 //               ds_read_b128 fragment reads are bank-conflict-free; double buffered: tile
 //               t+1 is gathered by global_load_lds_dwordx4 while tile t is on the MFMAs
 //   centre rows x_i are staged once per point and read as LDS broadcasts.
+#include <algorithm>
+
 #include "common.h"
 #include "edgeconv_fwd.h"
 
@@ -1044,9 +1046,18 @@ GCN_EXPORT int gcn_neighbor_sum(const float *x_pm, const int64_t *idx, int B, in
   return check_launch("neighbor_sum_kernel");
 }
 
-GCN_EXPORT long gcn_reverse_sum_ws_bytes(int B, int N, int k) {
-  if (B < 0 || N < 1 || k < 1) return -1;
-  return 16 + (N <= 65536 ? 2L * B * N * k : 0);
+namespace gcn {   // rsum.hip: stage + sort + gather form of the transposed aggregation
+bool rsum_staged_supported(int B, int N, int C, int k);
+size_t rsum_staged_ws_bytes(int B, int N, int C, int k);
+int run_reverse_sum_staged(const float *x, const int64_t *idx, int B, int N, int C, int k, float *r, float *indeg, void *ws,
+                           hipStream_t st);
+}
+
+GCN_EXPORT long gcn_reverse_sum_ws_bytes(int B, int N, int C, int k) {
+  if (B < 0 || N < 1 || k < 1 || C < 0) return -1;
+  long need = 256 + (N <= 65536 ? 2L * B * N * k : 0);
+  if (rsum_staged_supported(B, N, C, k)) need = std::max(need, (long)rsum_staged_ws_bytes(B, N, C, k));
+  return need;
 }
 
 GCN_EXPORT int gcn_reverse_sum(const float *x_pm, const int64_t *idx, int B, int N, int C, int k, float *r, float *indeg,
@@ -1058,8 +1069,9 @@ GCN_EXPORT int gcn_reverse_sum(const float *x_pm, const int64_t *idx, int B, int
   GCN_REQUIRE(((uintptr_t)ws & 15) == 0 && ((uintptr_t)idx & 15) == 0, "gcn_reverse_sum: ws/idx must be 16-B aligned");
   if (B == 0) return GCN_OK;
   hipStream_t st = (hipStream_t)stream;
-  GCN_HIP(hipMemsetAsync(ws, 0, 4, st));
+  GCN_HIP(hipMemsetAsync(ws, 0, 256, st));          // max |x| bits + the staged path's overflow counters
   if (C > 0) absmax_kernel<<<512, 256, 0, st>>>(x_pm, (long)B * N * C, (unsigned int *)ws);
+  if (C > 0 && rsum_staged_supported(B, N, C, k)) return run_reverse_sum_staged(x_pm, idx, B, N, C, k, r, indeg, ws, st);
   // destination rows per workgroup: ~256 workgroups in total, bounded by 128 KB of LDS
   int R = (int)(((long)N * B + 255) / 256);
   const int rmax = (128 * 1024) / (8 * C + 4);
@@ -1068,7 +1080,7 @@ GCN_EXPORT int gcn_reverse_sum(const float *x_pm, const int64_t *idx, int B, int
   const size_t lds = (size_t)R * C * 8 + (size_t)R * 4;
   const int grid = cdiv(N, R) * B;
   if (N <= 65536) {
-    unsigned short *i16 = reinterpret_cast<unsigned short *>((char *)ws + 16);
+    unsigned short *i16 = reinterpret_cast<unsigned short *>((char *)ws + 256);
     const long E = (long)B * N * k;
     idx_to_u16_kernel<<<cdiv((E + 1) / 2, 256), 256, 0, st>>>(idx, E, i16);
     if (C == 0 && ((long)N * k) % 8 == 0) {                  // in-degrees only

@@ -197,7 +197,7 @@ def _edgeconv_backward(saved, cfg, dout, pm, need_dx=True):
         r = torch.empty_like(x) if need_dx else None
         indeg = torch.empty(B, N, dtype=torch.float32, device=x.device)
         _run("gcn_neighbor_sum", x, _lib.ptr(x), _lib.ptr(idx), B, N, C, k, _lib.ptr(s))
-        ws4 = torch.empty(_lib.lib().gcn_reverse_sum_ws_bytes(B, N, k), dtype=torch.uint8, device=x.device)
+        ws4 = torch.empty(_lib.lib().gcn_reverse_sum_ws_bytes(B, N, C, k), dtype=torch.uint8, device=x.device)
         _run("gcn_reverse_sum", x, _lib.ptr(x), _lib.ptr(idx), B, N, C, k, _lib.ptr(r), _lib.ptr(indeg), _lib.ptr(ws4))
         SW, XW = s @ W1.t(), x @ Wd.t()                                  # (B,N,Cout) each
         if need_dx:

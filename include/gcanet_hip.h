@@ -361,10 +361,13 @@ int gcn_edgeconv_finish(const float *ymax, const float *ymin, const double *gsum
  *                     partitioned 64-bit fixed-point LDS accumulation: no global atomics, bitwise
  *                     reproducible; both outputs fully written; indeg (B,N) f32 may be NULL, or r may
  *                     be NULL (in-degrees only: no rows are read);
- *                     ws: gcn_reverse_sum_ws_bytes(B,N,k) bytes of device scratch, 16-B aligned). */
+ *                     ws: gcn_reverse_sum_ws_bytes(B,N,C,k) bytes of device scratch, 16-B aligned).
+ *                     C in {64,128}, N <= 16384, N % (16384/C) == 0: edges are filed per destination
+ *                     partition, sorted by destination row in LDS and the source rows GATHERED with 64-bit
+ *                     integer adds in registers (csrc/rsum.hip) -- same guarantees, no shared accumulators. */
 int gcn_neighbor_sum(const float *x_pm, const int64_t *idx, int B, int N, int C, int k, float *s,
                      void *stream);
-long gcn_reverse_sum_ws_bytes(int B, int N, int k);
+long gcn_reverse_sum_ws_bytes(int B, int N, int C, int k);
 int gcn_reverse_sum(const float *x_pm, const int64_t *idx, int B, int N, int C, int k, float *r,
                     float *indeg, void *ws, void *stream);
 

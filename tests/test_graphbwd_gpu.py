@@ -22,7 +22,7 @@ def test_reverse_and_neighbor_sum(dev, B, N, k, C):
     r = torch.empty_like(x)
     s = torch.empty_like(x)
     indeg = torch.empty(B, N, device=dev)
-    ws = torch.empty(_lib.lib().gcn_reverse_sum_ws_bytes(B, N, k), dtype=torch.uint8, device=dev)
+    ws = torch.empty(_lib.lib().gcn_reverse_sum_ws_bytes(B, N, C, k), dtype=torch.uint8, device=dev)
     _lib.call("gcn_reverse_sum", _lib.ptr(x), _lib.ptr(idx), B, N, C, k, _lib.ptr(r), _lib.ptr(indeg), _lib.ptr(ws),
               _lib.stream_of(x))
     _lib.call("gcn_neighbor_sum", _lib.ptr(x), _lib.ptr(idx), B, N, C, k, _lib.ptr(s), _lib.stream_of(x))
@@ -40,6 +40,42 @@ def test_reverse_and_neighbor_sum(dev, B, N, k, C):
     r2 = torch.empty_like(x)
     _lib.call("gcn_reverse_sum", _lib.ptr(x), _lib.ptr(idx), B, N, C, k, _lib.ptr(r2), None, _lib.ptr(ws), _lib.stream_of(x))
     assert torch.equal(r, r2)                         # bitwise reproducible (integer sums)
+
+
+@pytest.mark.parametrize("B,N,k,C,kind", [(2, 1024, 16, 64, "one_hub"), (1, 2048, 64, 64, "hub_partition"), (2, 512, 20, 128, "one_hub"),
+                                          (1, 4096, 32, 128, "random"), (3, 8192, 8, 64, "random")])
+def test_reverse_sum_staged_path_degenerate_graphs(dev, B, N, k, C, kind):
+    """The stage + sort + gather form (csrc/rsum.hip; C in {64,128}) on graphs that overflow a staging segment (every edge
+    to one node) or the LDS sort list (every edge into one partition): the overflow list and the accumulate-in-LDS path
+    must give the same sums, in-degrees included, bitwise reproducibly."""
+    from gcanet_amd import _lib
+    g = torch.Generator().manual_seed(N + k + C)
+    x = torch.randn(B, N, C, generator=g).to(dev)
+    if kind == "one_hub":
+        idx = torch.full((B, N, k), 5, dtype=torch.int64)
+    elif kind == "hub_partition":
+        idx = torch.randint(0, 100, (B, N, k), generator=g)
+    else:
+        idx = torch.randint(0, N, (B, N, k), generator=g)
+    idx = idx.to(dev)
+    outs = []
+    for _ in range(2):
+        r = torch.full_like(x, float("nan"))
+        indeg = torch.empty(B, N, device=dev)
+        ws = torch.empty(_lib.lib().gcn_reverse_sum_ws_bytes(B, N, C, k), dtype=torch.uint8, device=dev)
+        _lib.call("gcn_reverse_sum", _lib.ptr(x), _lib.ptr(idx), B, N, C, k, _lib.ptr(r), _lib.ptr(indeg), _lib.ptr(ws),
+                  _lib.stream_of(x))
+        outs.append((r, indeg))
+    xd = x.double()
+    r_ref = torch.zeros_like(xd)
+    deg_ref = torch.zeros(B, N, dtype=torch.float64, device=dev)
+    for b in range(B):
+        r_ref[b].index_add_(0, idx[b].reshape(-1), xd[b].repeat_interleave(k, 0))
+        deg_ref[b].index_add_(0, idx[b].reshape(-1), torch.ones(N * k, dtype=torch.float64, device=dev))
+    r, indeg = outs[0]
+    assert torch.equal(indeg.double(), deg_ref)
+    assert (r.double() - r_ref).abs().max().item() <= 2e-7 * r_ref.abs().max().item() + 1e-30
+    assert torch.equal(outs[0][0], outs[1][0])
 
 
 @pytest.mark.parametrize("B,N,C,Cout", [(2, 512, 64, 128), (3, 300, 6, 64), (1, 1024, 64, 64), (2, 130, 16, 128)])
