@@ -5,30 +5,31 @@
 // reverse_sum_lds_kernel (edgeconv.hip) lets every destination partition scan the cloud's whole edge list and add
 // the matching source rows into LDS with ds_add_u64 -- bound by the LDS atomic rate (3 lane-operations per clock and
 // CU: 268 M of them at B=8, N=8192, k=64, C=64 = 0.15 ms) plus the scans: 0.35 ms.  Here no accumulator is shared:
-//   1. rsum_fixed_kernel   x -> xq = rint(x * 2^S) as 64-bit integers, S from max|x| and N*k so that no sum can
-//                          overflow (integer sums are order independent: r is bitwise reproducible).
+//   1. (absmax_kernel)     S from max|x| and N*k such that no sum of rint(x * 2^S) can overflow 64 bits (integer sums
+//                          are order independent: r is bitwise reproducible).
 //   2. rsum_file_kernel    one pass over idx: every edge is FILED under its destination partition (R = 16384/C rows):
 //                          a per-workgroup LDS counter per partition hands out the slot in that workgroup's segment of
 //                          the partition's staging area (plain 4-byte stores {row in partition, source n}); segments
 //                          hold twice the mean, the excess of hub graphs goes to a per-cloud overflow list.
 //   3. rsum_gather_kernel  one workgroup per (cloud, partition): LDS counting sort of its ~64 R entries by destination
 //                          row (histogram = the in-degrees, scan, scatter of the 16-bit source ids), then every wave
-//                          takes whole destination rows and GATHERS: 8 source rows in flight, lane = channel, 64-bit
-//                          integer adds in registers, one store per element.  A partition with more entries than the
+//                          takes whole destination rows and GATHERS: 16 source rows in flight and the next 16 already issued,
+//                          lane = channel, each f32 converted to 64-bit fixed point by two 32-bit converts (fixed64),
+//                          integer adds in registers, one store per element; bound by L2 read bandwidth (256-byte rows:
+//                          pre-converted 512-byte integer rows were slower, 0.16 ms vs 0.1).  A partition with more entries than the
 //                          LDS list holds, or a cloud with overflow entries, takes the accumulate-in-LDS path instead
 //                          (ds_add_u64 as before) -- same result.
 #include "common.h"
 
 namespace gcn {
 
-constexpr int RS_SORT_CAP = 40960;           // 16-bit source ids one partition may sort in LDS (80 KB)
+constexpr int RS_SORT_CAP = 32768;           // 16-bit source ids one partition may sort in LDS (64 KB)
 
 struct RsumArgs {
   const float *x;              // (B,N,C)
   const int64_t *idx;          // (B,N,k)
   const unsigned int *absmax;  // max |x| bits (ws header, written by absmax_kernel)
   unsigned int *ovf_cnt;       // (B) zeroed by the host
-  long long *xq;               // (B,N,C)
   int *counts;                 // (B,P,T)
   unsigned int *stag;          // (B,P,T,cap): (row in partition << 16) | n
   unsigned int *ovf;           // (B, N*k): (m << 16) | n
@@ -41,21 +42,25 @@ __device__ __forceinline__ int rsum_shift(const unsigned int *absmax_bits, int N
   int ex = 0;
   if (mx > 0.f) (void)frexpf(mx, &ex);                   // mx < 2^ex
   int S = 62 - ex - (64 - __clzll((long long)N * k));
+  S = S > 50 - ex ? 50 - ex : S;                         // every |x * 2^S| < 2^50: inside the magic-number window
   return S < 0 ? 0 : (S > 40 ? 40 : S);
 }
 
-__global__ __launch_bounds__(256) void rsum_fixed_kernel(RsumArgs a) {
-  const int S = rsum_shift(a.absmax, a.N, a.k);
-  const float scale = ldexpf(1.f, S);
-  const long n4 = (long)a.B * a.N * a.C / 4;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-    const float4 v = reinterpret_cast<const float4 *>(a.x)[i];
-    longlong2 o0, o1;
-    o0.x = __float2ll_rn(v.x * scale); o0.y = __float2ll_rn(v.y * scale);
-    o1.x = __float2ll_rn(v.z * scale); o1.y = __float2ll_rn(v.w * scale);
-    reinterpret_cast<longlong2 *>(a.xq)[2 * i] = o0;
-    reinterpret_cast<longlong2 *>(a.xq)[2 * i + 1] = o1;
-  }
+// Fixed-point conversion by the "magic number" addition: fma(x, 2^S, 1.5 * 2^52) is x * 2^S rounded to the nearest integer
+// (ties to even) sitting in the low mantissa bits -- bits(result) - bits(1.5 * 2^52) is that integer for |x * 2^S| < 2^51
+// (here < 2^43: S leaves 19 bits for the N*k addends).  The subtraction is done once per sum, not per addend.
+constexpr long long RS_MAGIC_BITS = 0x4338000000000000LL;     // bit pattern of 1.5 * 2^52
+__device__ __forceinline__ long long magic_bits(float x, double dscale) {
+  return __double_as_longlong(fma((double)x, dscale, 6755399441055744.0));
+}
+
+// rint(v) of an f32 holding an integer-valued or half-integer-valued product x * 2^S (|v| < 2^62) as a 64-bit integer:
+// hi = floor(v / 2^32) and lo = v - hi * 2^32 are both exact in f32 (24 significant bits), so two 32-bit converts do it
+__device__ __forceinline__ long long fixed64(float v) {
+  const float r = rintf(v);
+  const float hi = floorf(r * 2.3283064365386963e-10f);
+  const float lo = fmaf(hi, -4294967296.f, r);
+  return ((long long)(int)hi << 32) + (long long)(unsigned int)lo;
 }
 
 __global__ __launch_bounds__(256) void rsum_file_kernel(RsumArgs a) {
@@ -130,7 +135,9 @@ __global__ __launch_bounds__(1024) void rsum_gather_kernel(RsumArgs a) {
   const int total = total_s;
   const int S = rsum_shift(a.absmax, a.N, a.k);
   const double inv = ldexp(1.0, -S);
-  const long long *xb = a.xq + (long)b * a.N * C;
+  const float *xb = a.x + (long)b * a.N * C;
+  const float scale = ldexpf(1.f, S);
+  const double dscale = ldexp(1.0, S);
   float *rb = a.r + ((long)b * a.N + m0) * C;
   if (a.indeg)
     for (int i = threadIdx.x; i < R; i += 1024) a.indeg[(long)b * a.N + m0 + i] = (float)hist[i];
@@ -154,62 +161,85 @@ __global__ __launch_bounds__(1024) void rsum_gather_kernel(RsumArgs a) {
       }
     }
     __syncthreads();
-    // 3. a wave takes whole destination rows: gather the source rows, eight in flight
+    // 3. a wave takes whole destination rows: gather the source rows, 16 loads in flight and the next 16 issued before
+    //    the current ones are added (the kernel is bound by the latency of these L2 reads, not by their bandwidth)
+    constexpr int U = 16;
     for (int row = wave; row < R; row += 16) {
       const int cnt = hist[row], off = offs[row];
       long long acc[CW];
 #pragma unroll
       for (int w = 0; w < CW; ++w) acc[w] = 0;
-      for (int e = 0; e < cnt; e += 8) {
-        long long v[8][CW];
+      float cur[U][CW], nxt[U][CW];
+      // ids of the row: one LDS read per 64 entries (lane = entry), then a v_readlane per entry
+      int ids = 0;
+      auto fetch = [&](int e, float (&v)[U][CW]) {
+        if ((e & 63) == 0) ids = (int)sorted[off + min(e + lane, cnt - 1)];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int ee = min(e + u, cnt - 1);
-          const int n = __builtin_amdgcn_readfirstlane((int)sorted[off + ee]);
+        for (int u = 0; u < U; ++u) {
+          const int n = __builtin_amdgcn_readlane(ids, ((e & 63) + u) & 63);
 #pragma unroll
-          for (int w = 0; w < CW; ++w) v[u][w] = xb[(long)n * C + w * 64 + lane];
+          for (int w = 0; w < CW; ++w) v[u][w] = xb[(unsigned int)n * (unsigned int)C + (unsigned int)(w * 64 + lane)];
         }
+      };
+      if (cnt > 0) fetch(0, cur);
+      for (int e = 0; e < cnt; e += U) {
+        if (e + U < cnt) fetch(e + U, nxt);
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < U; ++u)
           if (e + u < cnt) {
 #pragma unroll
-            for (int w = 0; w < CW; ++w) acc[w] += v[u][w];
+            for (int w = 0; w < CW; ++w) acc[w] += magic_bits(cur[u][w], dscale);
           }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int w = 0; w < CW; ++w) cur[u][w] = nxt[u][w];
       }
+      // every addend carried the bit pattern of the magic constant: take cnt of them out again
+#pragma unroll
+      for (int w = 0; w < CW; ++w) acc[w] -= (long long)cnt * RS_MAGIC_BITS;
 #pragma unroll
       for (int w = 0; w < CW; ++w) rb[(long)row * C + w * 64 + lane] = (float)((double)acc[w] * inv);
     }
   } else {
-    // LDS path: more entries than the sort list holds (hub destinations): add the rows up in LDS
+    // LDS path: more entries than the sort list holds (hub destinations): add the rows up in LDS, half the
+    // partition's rows at a time (64 KB of 64-bit sums)
     unsigned long long *qacc = dyn;
-    for (int i = threadIdx.x; i < R * C; i += 1024) qacc[i] = 0ull;
-    __syncthreads();
-    auto add_row = [&](unsigned int row, unsigned int n) {
+    constexpr int RH = R / 2;
+    for (int half = 0; half < 2; ++half) {
+      const unsigned int lo = (unsigned int)(half * RH);
+      __syncthreads();
+      for (int i = threadIdx.x; i < RH * C; i += 1024) qacc[i] = 0ull;
+      __syncthreads();
+      auto add_row = [&](unsigned int row, unsigned int n) {
+        if (row - lo < (unsigned int)RH) {                       // wave-uniform
 #pragma unroll
-      for (int w = 0; w < CW; ++w)
-        atomicAdd(&qacc[row * C + w * 64 + lane], (unsigned long long)xb[(long)n * C + w * 64 + lane]);
-    };
-    for (int t = wave; t < a.T; t += 16) {
-      const int cnt = a.counts[seg0 + t];
-      const unsigned int *sg = a.stag + (seg0 + t) * a.cap;
-      for (int i = 0; i < cnt; ++i) {
-        const unsigned int e = sg[i];
-        add_row(e >> 16, e & 0xffffu);
+          for (int w = 0; w < CW; ++w)
+            atomicAdd(&qacc[(row - lo) * C + w * 64 + lane], (unsigned long long)fixed64(xb[(long)n * C + w * 64 + lane] * scale));
+        }
+      };
+      for (int t = wave; t < a.T; t += 16) {
+        const int cnt = a.counts[seg0 + t];
+        const unsigned int *sg = a.stag + (seg0 + t) * a.cap;
+        for (int i = 0; i < cnt; ++i) {
+          const unsigned int e = sg[i];
+          add_row(e >> 16, e & 0xffffu);
+        }
       }
-    }
-    if (novf) {
-      const unsigned int *ov = a.ovf + (long)b * a.N * a.k;
-      for (unsigned int i = wave; i < novf; i += 16) {
-        const unsigned int e = ov[i], row = (e >> 16) - (unsigned int)m0;
-        if (row < (unsigned int)R) add_row(row, e & 0xffffu);
+      if (novf) {
+        const unsigned int *ov = a.ovf + (long)b * a.N * a.k;
+        for (unsigned int i = wave; i < novf; i += 16) {
+          const unsigned int e = ov[i], row = (e >> 16) - (unsigned int)m0;
+          if (row < (unsigned int)R) add_row(row, e & 0xffffu);
+        }
       }
+      __syncthreads();
+      for (int i = threadIdx.x; i < RH * C; i += 1024) rb[(long)lo * C + i] = (float)((double)(long long)qacc[i] * inv);
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < R * C; i += 1024) rb[i] = (float)((double)(long long)qacc[i] * inv);
   }
 }
 
-struct RsumWs { size_t xq, counts, stag, ovf, total; int P, T, cap, tile_rows, rshift; };
+struct RsumWs { size_t counts, stag, ovf, total; int P, T, cap, tile_rows, rshift; };
 
 static RsumWs rsum_layout(int B, int N, int C, int k) {
   auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
@@ -222,7 +252,6 @@ static RsumWs rsum_layout(int B, int N, int C, int k) {
   const long mean = (long)w.tile_rows * k / w.P;
   w.cap = (int)(2 * mean < 64 ? 64 : 2 * mean);
   size_t o = 256;                                               // zeroed header: max |x| bits, overflow counters
-  w.xq = o; o += al(sizeof(long long) * (size_t)B * N * C);
   w.counts = o; o += al(sizeof(int) * (size_t)B * w.P * w.T);
   w.stag = o; o += al(sizeof(unsigned int) * (size_t)B * w.P * w.T * w.cap);
   w.ovf = o; o += al(sizeof(unsigned int) * (size_t)B * N * k);
@@ -244,12 +273,11 @@ int run_reverse_sum_staged(const float *x, const int64_t *idx, int B, int N, int
   char *base = (char *)ws;
   RsumArgs a{};
   a.x = x; a.idx = idx; a.absmax = (const unsigned int *)base; a.ovf_cnt = (unsigned int *)(base + 16);
-  a.xq = (long long *)(base + w.xq); a.counts = (int *)(base + w.counts); a.stag = (unsigned int *)(base + w.stag);
+  a.counts = (int *)(base + w.counts); a.stag = (unsigned int *)(base + w.stag);
   a.ovf = (unsigned int *)(base + w.ovf); a.r = r; a.indeg = indeg;
   a.B = B; a.N = N; a.C = C; a.k = k; a.P = w.P; a.T = w.T; a.cap = w.cap; a.rshift = w.rshift; a.tile_rows = w.tile_rows;
-  rsum_fixed_kernel<<<1024, 256, 0, st>>>(a);
   rsum_file_kernel<<<dim3(w.T, B), 256, 0, st>>>(a);
-  const int ldsb = 16384 * 8;
+  const int ldsb = 8192 * 8;
   if (C == 64) {
     GCN_HIP(hipFuncSetAttribute((const void *)rsum_gather_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb));
     rsum_gather_kernel<1><<<w.P * B, 1024, ldsb, st>>>(a);
