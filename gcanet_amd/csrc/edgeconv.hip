@@ -539,23 +539,47 @@ __global__ __launch_bounds__(256) void edgeconv_finish_kernel(const float *__res
 
 
 // ------------------------------------------------------------------ graph aggregations for backward
-// s[n] = sum_j x[idx[n,j]]  (neighbour sum, gather) ; one wave per point, lanes across channels
+// s[n] = sum_j x[idx[n,j]]  (neighbour sum, gather).  G lanes per point (channels across lanes; 64/G points per wave, so
+// narrow rows -- the 6-channel input cloud -- still fill the wave); sixteen row loads in flight per lane, the ids of a
+// point read once (G = 64: one coalesced load of 64 ids, then v_readlane); adds stay in neighbour order.
+template <int G>
 __global__ __launch_bounds__(256) void neighbor_sum_kernel(const float *__restrict__ x, const int64_t *__restrict__ idx,
                                                            int N, int C, int k, float *__restrict__ s) {
+  constexpr int PW = 64 / G;
+  constexpr int U = 16;
   const int lane = lane_id();
   int tile, b;
   xcd_tile_cloud(tile, b);
-  const int n = tile * 4 + wave_id();
-  if (n >= N) return;
+  const int p = lane / G, cl = lane % G;
+  const int n = (tile * 4 + wave_id()) * PW + p;
+  if ((tile * 4 + wave_id()) * PW >= N) return;                 // wave-uniform
+  const int nn = min(n, N - 1);
   const float *xb = x + (long)b * N * C;
-  const int64_t *ip = idx + ((long)b * N + n) * k;
-  for (int c0 = 0; c0 < C; c0 += 64) {
-    const int c = c0 + lane;
+  const int64_t *ip = idx + ((long)b * N + nn) * k;
+  for (int c0 = 0; c0 < C; c0 += G) {
+    const int c = c0 + cl;
+    const bool cok = c < C;
+    const int cc = cok ? c : C - 1;
     float acc = 0.f;
-    if (c < C) {
-      for (int j = 0; j < k; ++j) acc += xb[ip[j] * C + c];
-      s[((long)b * N + n) * C + c] = acc;
+    int ids64 = 0;
+    for (int j0 = 0; j0 < k; j0 += U) {
+      int ids[U];
+      if (G == 64) {
+        if ((j0 & 63) == 0) ids64 = (int)ip[min(j0 + lane, k - 1)];
+#pragma unroll
+        for (int u = 0; u < U; ++u) ids[u] = __builtin_amdgcn_readlane(ids64, ((j0 & 63) + u) & 63);
+      } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u) ids[u] = (int)ip[min(j0 + u, k - 1)];
+      }
+      float v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = xb[(unsigned int)ids[u] * (unsigned int)C + (unsigned int)cc];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (j0 + u < k) acc += v[u];
     }
+    if (cok && n < N) s[((long)b * N + n) * C + c] = acc;
   }
 }
 
@@ -1042,7 +1066,12 @@ GCN_EXPORT int gcn_neighbor_sum(const float *x_pm, const int64_t *idx, int B, in
   GCN_REQUIRE(x_pm && idx && s, "gcn_neighbor_sum: null pointer");
   GCN_REQUIRE(B >= 0 && N >= 1 && C >= 1 && k >= 1, "gcn_neighbor_sum: bad shape");
   if (B == 0) return GCN_OK;
-  neighbor_sum_kernel<<<dim3(cdiv(N, 4), B), 256, 0, (hipStream_t)stream>>>(x_pm, idx, N, C, k, s);
+  GCN_REQUIRE((long)N * C < (1L << 32), "gcn_neighbor_sum: N*C must fit 32 bits");
+  hipStream_t st = (hipStream_t)stream;
+  if (C <= 8) neighbor_sum_kernel<8><<<dim3(cdiv(N, 4 * 8), B), 256, 0, st>>>(x_pm, idx, N, C, k, s);
+  else if (C <= 16) neighbor_sum_kernel<16><<<dim3(cdiv(N, 4 * 4), B), 256, 0, st>>>(x_pm, idx, N, C, k, s);
+  else if (C <= 32) neighbor_sum_kernel<32><<<dim3(cdiv(N, 4 * 2), B), 256, 0, st>>>(x_pm, idx, N, C, k, s);
+  else neighbor_sum_kernel<64><<<dim3(cdiv(N, 4), B), 256, 0, st>>>(x_pm, idx, N, C, k, s);
   return check_launch("neighbor_sum_kernel");
 }
 
