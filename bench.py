@@ -31,6 +31,8 @@ def parse_args(argv=None):
     ap.add_argument("--points", type=int, default=8192)
     ap.add_argument("--k", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="launch every kernel of the timed steps from the host instead of replaying one captured HIP graph")
     ap.add_argument("--no-full", action="store_true", help="skip the second workload (literal full forward_train + losses)")
     ap.add_argument("--rehearse-cpu", action="store_true",
                     help="launcher/collective rehearsal on a box WITHOUT a GPU: gloo ranks, a tiny torch stand-in "
@@ -235,6 +237,9 @@ def full_workload(args, dev, steps=5, warmup=2):
     info = {}
 
     def step():
+        from gcanet_amd.layers import ZeroArena
+        if ZeroArena.live is not None:
+            ZeroArena.live.begin_step()
         opt.zero_grad(set_to_none=True)
         casts.refresh()
         with torch.autocast("cuda", dtype=torch.bfloat16):
@@ -441,16 +446,22 @@ def main():
     model = dgcnn.PrimitivesEmbeddingDGCNGn(nn_nb=args.k, dtype="bf16").to(dev)
     dp = parallel.FlatGradDP(model, world, late=model.encoder.parameters())   # heads' all-reduce overlaps the encoder's backward
     dp.sync_params()
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)   # option_new.py:83-90 (one multi-tensor kernel)
+    # one process per GPU; with a single rank the whole step (forward, backward, gradient packing, Adam) is captured once
+    # into a HIP graph and the timed steps are replays: ~390 launches cost the host ~7.7 ms per step otherwise, about as
+    # long as the GPU needs to execute them (the RCCL all-reduce with its backward hook stays on eager launches)
+    use_graph = world == 1 and not args.no_graph
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True, capturable=use_graph)   # option_new.py:83-90
     B, N = args.batch, args.points
     pts, nrm = synth_clouds(range(rank * B, rank * B + B), N, dev)
 
-    from gcanet_amd.layers import CastCache
+    from gcanet_amd.layers import CastCache, ZeroArena
+    arena = ZeroArena(dev)            # the small accumulators of a step come pre-zeroed from one allocation: one fill per step
     # bf16 weight copies (in the GEMM kernel's padded operand layout): one multi-tensor cast per step, not one per layer
     casts = CastCache(model, pad_k={model.conv3.weight: (model.conv3.weight.shape[1] + 15) // 16 * 16})
 
     def step():
         dp.zero_grad()
+        arena.begin_step()
         casts.refresh()
         with torch.autocast("cuda", dtype=torch.bfloat16):
             out = model(pts, nrm)
@@ -464,17 +475,45 @@ def main():
         if world > 1:
             torch.distributed.barrier()
 
-    for _ in range(args.warmup):
-        step()
+    run_step = step
+    if use_graph:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                     # warm-up off the default stream, as graph capture wants it
+            for _ in range(args.warmup):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            loss = step()                                 # not executed: recorded; `loss` is the graph's output buffer
+        run_step = graph.replay
+    else:
+        for _ in range(args.warmup):
+            step()
+        _lib.enable_timing(True)                          # per-kernel HIP events ride along with the timed steps
     torch.cuda.synchronize()
     barrier()
-    _lib.enable_timing(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = step()
+        out_loss = run_step()
+    t_enq = time.perf_counter() - t0          # host time to ENQUEUE the steps (close to dt = the host is the bottleneck)
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
+    if not use_graph:
+        loss = out_loss
+        timed_steps = args.steps
+    else:
+        # per-kernel durations: the same step, launched eagerly with HIP events around every entry point, right after
+        # the timed region (a replayed graph has no host-side call to bracket)
+        timed_steps = 3
+        if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
+            torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)   # the capture ran on a side stream
+        _lib.enable_timing(True)
+        for _ in range(timed_steps):
+            step()
+        torch.cuda.synchronize()
     timing = _lib.timing_results()
     _lib.enable_timing(False)
     if world > 1:
@@ -494,7 +533,7 @@ def main():
     for tag, (n, tot) in sorted(timing.items(), key=lambda kv: -kv[1][1]):
         km = kernel_model(tag)
         avg = tot / n
-        kernels[tag] = {"launches_per_step": n / args.steps, "avg_ms": round(avg, 4),
+        kernels[tag] = {"launches_per_step": n / timed_steps, "avg_ms": round(avg, 4),
                         "tflops": round(km["flops"] / avg / 1e9, 2) if km else None}
     if dom is not None:
         tag, (n, tot) = dom
@@ -503,19 +542,21 @@ def main():
         ach = km["flops"] / avg_ms / 1e9
         roofline = {"kernel": tag, "bound": km["bound"], "achieved": round(ach, 2), "peak": km["peak"],
                     "unit": "TFLOP/s", "frac": round(ach / km["peak"], 4), "traffic": pmc_traffic(tag),
-                    "avg_launch_ms": round(avg_ms, 4), "launches_per_step": n / args.steps}
+                    "avg_launch_ms": round(avg_ms, 4), "launches_per_step": n / timed_steps}
         if tag.startswith("knn_model"):
             # since round 2 the N^2 part of this entry point is a FILTER (bf16 MFMA for feature space, packed f32 VALU
             # for xyz+normal) and only ~3k survivors per query get the exact f32 arithmetic: `achieved` stays the
             # algorithmic 2*B*N^2*C f32 FLOPs of SURVEY 8d over the entry point's whole duration (all its kernels)
             roofline["note"] = ("algorithmic exact-f32 distance FLOPs / time of the whole entry point (prep + threshold + "
                                 "filter + exact re-rank kernels); the N^2 pass itself runs as a bf16-MFMA / packed-f32 filter")
-    knn_ms = sum(tot for tag, (n, tot) in timing.items() if tag.startswith("knn_model")) / args.steps
+    knn_ms = sum(tot for tag, (n, tot) in timing.items() if tag.startswith("knn_model")) / timed_steps
     res = {
         "metric": "point-clouds/sec fwd+bwd (N=%d,k=%d)" % (N, args.k), "value": round(clouds_per_s, 3),
         "unit": "clouds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(dt / args.steps * 1e3, 3), "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "step_launch": "hipgraph replay (captured once after warm-up)" if use_graph else "eager",
         "config": {"workload": "BASELINE configs[1]: %d clouds/GPU, N=%d, k=%d, GCANet hot path (DGCNN encoder 3x"
                                "[kNN+EdgeConv], heads, normal EdgeConv, embedding, offset module; M4:634-747) fwd+bwd"
                                "+Adam; stops before forward_grouping/spconv (third-party, SURVEY 8f)" % (B, N, args.k),

@@ -157,6 +157,16 @@ inline void exscan_rows(hipStream_t st, int rows, int m, int32_t *v, int32_t *bs
 // Zero up to four device spans with as few hipMemsetAsync calls as possible: spans that are adjacent in memory
 // (the Python side allocates the small per-call accumulators back to back) collapse into one fill -- a fill of a few
 // hundred bytes costs ~4.5 us of GPU time like any other launch, and a training step had ~80 of them.
+// Pre-zeroed scratch arena (gcn_zero_arena_register): a span that lies inside it was zeroed by the owner of the arena
+// with ONE fill at the start of the step and has not been handed out since -- the fill is skipped.  Any other pointer
+// is zeroed here as before.
+extern char *g_zero_lo, *g_zero_hi;
+inline hipError_t zero_dev(void *p, size_t n, hipStream_t st) {
+  if (n == 0 || !p) return hipSuccess;
+  if ((char *)p >= g_zero_lo && (char *)p + n <= g_zero_hi) return hipSuccess;
+  return hipMemsetAsync(p, 0, n, st);
+}
+
 struct ZeroSpan { void *p; size_t n; };
 inline hipError_t zero_spans(hipStream_t st, ZeroSpan a, ZeroSpan b = {nullptr, 0}, ZeroSpan c = {nullptr, 0},
                              ZeroSpan d = {nullptr, 0}) {
@@ -175,7 +185,7 @@ inline hipError_t zero_spans(hipStream_t st, ZeroSpan a, ZeroSpan b = {nullptr, 
       if (h2 > hi) hi = h2;
       ++j;
     }
-    hipError_t e = hipMemsetAsync(lo, 0, (size_t)(hi - lo), st);
+    hipError_t e = zero_dev(lo, (size_t)(hi - lo), st);
     if (e != hipSuccess) return e;
     i = j;
   }

@@ -13,7 +13,15 @@ void set_error(const char *fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
+char *g_zero_lo = nullptr, *g_zero_hi = nullptr;
 }  // namespace gcn
+
+GCN_EXPORT int gcn_zero_arena_register(void *base, long bytes) {
+  GCN_REQUIRE(bytes >= 0 && (base || bytes == 0), "gcn_zero_arena_register: bad arena");
+  gcn::g_zero_lo = (char *)base;
+  gcn::g_zero_hi = (char *)base + (base ? bytes : 0);
+  return GCN_OK;
+}
 
 GCN_EXPORT const char *gcn_last_error(void) { return gcn::g_err; }
 GCN_EXPORT int gcn_version(void) { return 100; }

@@ -1015,7 +1015,7 @@ GCN_EXPORT int gcn_edgeconv_fwd(const void *x_pm, const void *w, const int64_t *
   GCN_REQUIRE(G >= 1 && Cout % G == 0, "gcn_edgeconv_fwd: Cout=%d not divisible by G=%d", Cout, G);
   if (B == 0) return GCN_OK;
   hipStream_t st = (hipStream_t)stream;
-  GCN_HIP(hipMemsetAsync(gsum, 0, sizeof(double) * 2 * B * G, st));
+  GCN_HIP(zero_dev(gsum, sizeof(double) * 2 * B * G, st));
   if (dtype == 0) {
     const size_t lds = sizeof(float) * ((size_t)k * 2 * C + 2) + sizeof(double) * 2 * Cout;
     GCN_REQUIRE(lds <= 150 * 1024, "gcn_edgeconv_fwd(f32): k*2C too large for the exact path (%zu B LDS)", lds);
@@ -1098,7 +1098,7 @@ GCN_EXPORT int gcn_reverse_sum(const float *x_pm, const int64_t *idx, int B, int
   GCN_REQUIRE(((uintptr_t)ws & 15) == 0 && ((uintptr_t)idx & 15) == 0, "gcn_reverse_sum: ws/idx must be 16-B aligned");
   if (B == 0) return GCN_OK;
   hipStream_t st = (hipStream_t)stream;
-  GCN_HIP(hipMemsetAsync(ws, 0, 256, st));          // max |x| bits + the staged path's overflow counters
+  GCN_HIP(zero_dev(ws, 256, st));          // max |x| bits + the staged path's overflow counters
   if (C > 0) absmax_kernel<<<512, 256, 0, st>>>(x_pm, (long)B * N * C, (unsigned int *)ws);
   if (C > 0 && rsum_staged_supported(B, N, C, k)) return run_reverse_sum_staged(x_pm, idx, B, N, C, k, r, indeg, ws, st);
   // destination rows per workgroup: ~256 workgroups in total, bounded by 128 KB of LDS
@@ -1142,7 +1142,7 @@ GCN_EXPORT int gcn_keyedge_fwd(const float *att, const int64_t *kidx, const floa
   GCN_REQUIRE(lds <= 150 * 1024, "gcn_keyedge_fwd: key table %zu B exceeds LDS", lds);
   if (B == 0) return GCN_OK;
   hipStream_t st = (hipStream_t)stream;
-  GCN_HIP(hipMemsetAsync(gsum, 0, sizeof(double) * 2 * B * G, st));
+  GCN_HIP(zero_dev(gsum, sizeof(double) * 2 * B * G, st));
   GCN_HIP(hipFuncSetAttribute((const void *)keyedge_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int blocks_per_cloud = (256 + B - 1) / B;               // one 16-wave block per CU (the key table is 61 KB)
   if (blocks_per_cloud > (N + 15) / 16) blocks_per_cloud = (N + 15) / 16;

@@ -487,10 +487,10 @@ GCN_EXPORT int gcn_gemm_wgrad_bf16(const void *dY, const void *X, long M, int N,
   GCN_REQUIRE(((uintptr_t)dY & 15) == 0 && ((uintptr_t)X & 15) == 0, "gcn_gemm_wgrad_bf16: 16-byte aligned operands");
   hipStream_t st = (hipStream_t)stream;
   if (db == dW + (size_t)N * K) {                            // adjacent (the usual case): one fill
-    GCN_HIP(hipMemsetAsync(dW, 0, sizeof(float) * ((size_t)N * K + N), st));
+    GCN_HIP(zero_dev(dW, sizeof(float) * ((size_t)N * K + N), st));
   } else {
-    GCN_HIP(hipMemsetAsync(dW, 0, sizeof(float) * (size_t)N * K, st));
-    if (db) GCN_HIP(hipMemsetAsync(db, 0, sizeof(float) * (size_t)N, st));
+    GCN_HIP(zero_dev(dW, sizeof(float) * (size_t)N * K, st));
+    if (db) GCN_HIP(zero_dev(db, sizeof(float) * (size_t)N, st));
   }
   WgradArgs a{};
   a.dY = (const unsigned short *)dY; a.X = (const unsigned short *)X; a.dW = dW; a.db = db; a.M = M; a.N = N; a.K = K;

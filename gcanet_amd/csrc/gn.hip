@@ -343,44 +343,63 @@ __global__ __launch_bounds__(1024) void gn_max_bwd_sums_kernel(const void *__res
     const float ga = live ? gamma[c] : 0.f, be = live ? beta[c] : 0.f;
     const int g = live ? c / cpg : 0;
     float dg = 0.f, db = 0.f;
-    for (int b = 0; b < B; ++b) {
-      double s1 = 0.0, s2 = 0.0;
-      if (live) {
-        const float mean = mean_rstd[((long)b * G + g) * 2], rstd = mean_rstd[((long)b * G + g) * 2 + 1];
-        const long n = arg[(long)b * C + c];
-        const float xv = load1<BF16>(x, ((long)b * N + n) * C + c);
-        const float xh = (xv - mean) * rstd;
-        const float z = xh * ga + be;
-        const float gz = (relu && !(z > 0.f)) ? 0.f : dout[(long)b * C + c];
-        dg = fmaf(gz, xh, dg);
-        db += gz;
-        s1 = (double)(ga * gz);
-        s2 = (double)(ga * gz) * (double)xh;
-        sp[(long)b * C + c] = rstd * ga * gz;
+    for (int b0 = 0; b0 < B; b0 += 8) {
+      // the kernel is one workgroup of dependent gathers: issue the loads of eight samples before using any
+      long nrow[8];
+      float xv8[8], go8[8], mean8[8], rstd8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int bb = min(b0 + u, B - 1);
+        nrow[u] = live ? arg[(long)bb * C + c] : 0;
+        go8[u] = live ? dout[(long)bb * C + c] : 0.f;
+        mean8[u] = mean_rstd[((long)bb * G + g) * 2];
+        rstd8[u] = mean_rstd[((long)bb * G + g) * 2 + 1];
       }
-      p1[threadIdx.x] = s1;
-      p2[threadIdx.x] = s2;
-      __syncthreads();
-      // groups whose channels lie in this chunk: one thread per group adds its channels in order (deterministic)
-      const int g0 = c0 / cpg, g1 = min(G, (min(C, c0 + 1024) + cpg - 1) / cpg);
-      if ((int)threadIdx.x < g1 - g0) {
-        const int gg = g0 + threadIdx.x;
-        const int lo = max(gg * cpg, c0) - c0, hi = min((gg + 1) * cpg, c0 + 1024) - c0;
-        double a1 = 0.0, a2 = 0.0;
-        for (int i = lo; i < hi; ++i) { a1 += p1[i]; a2 += p2[i]; }
-        // a group may straddle chunks (cpg > 1024): accumulate in AB as raw sums first (f32 pairs hold them below)
-        double *acc = reinterpret_cast<double *>(AB) + ((long)b * G + gg) * 2;   // AB doubles as (B,G,2) f64 scratch
-        if (max(gg * cpg, c0) == gg * cpg) { acc[0] = a1; acc[1] = a2; } else { acc[0] += a1; acc[1] += a2; }
-        if (min((gg + 1) * cpg, c0 + 1024) == (gg + 1) * cpg) {               // group complete: the affine constants
-          const double mu = (double)mean_rstd[((long)b * G + gg) * 2], rs = (double)mean_rstd[((long)b * G + gg) * 2 + 1];
-          const double Bg = (-(rs * rs)) * acc[1] / M;
-          const double Ag = (-(rs * acc[0])) / M - Bg * mu;
-          float *o = AB + ((long)B * G * 2) * 2 + ((long)b * G + gg) * 2;       // floats behind the f64 scratch
-          o[0] = (float)Ag;
-          o[1] = (float)Bg;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int bb = min(b0 + u, B - 1);
+        xv8[u] = live ? load1<BF16>(x, ((long)bb * N + nrow[u]) * C + c) : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int b = b0 + u;
+        if (b >= B) break;                                       // block-uniform
+        double s1 = 0.0, s2 = 0.0;
+        if (live) {
+          const float mean = mean8[u], rstd = rstd8[u];
+          const float xh = (xv8[u] - mean) * rstd;
+          const float z = xh * ga + be;
+          const float gz = (relu && !(z > 0.f)) ? 0.f : go8[u];
+          dg = fmaf(gz, xh, dg);
+          db += gz;
+          s1 = (double)(ga * gz);
+          s2 = (double)(ga * gz) * (double)xh;
+          sp[(long)b * C + c] = rstd * ga * gz;
         }
+        p1[threadIdx.x] = s1;
+        p2[threadIdx.x] = s2;
+        __syncthreads();
+        // groups whose channels lie in this chunk: one thread per group adds its channels in order (deterministic)
+        const int g0 = c0 / cpg, g1 = min(G, (min(C, c0 + 1024) + cpg - 1) / cpg);
+        if ((int)threadIdx.x < g1 - g0) {
+          const int gg = g0 + threadIdx.x;
+          const int lo = max(gg * cpg, c0) - c0, hi = min((gg + 1) * cpg, c0 + 1024) - c0;
+          double a1 = 0.0, a2 = 0.0;
+          for (int i = lo; i < hi; ++i) { a1 += p1[i]; a2 += p2[i]; }
+          // a group may straddle chunks (cpg > 1024): accumulate in AB as raw sums first (f32 pairs hold them below)
+          double *acc = reinterpret_cast<double *>(AB) + ((long)b * G + gg) * 2;   // AB doubles as (B,G,2) f64 scratch
+          if (max(gg * cpg, c0) == gg * cpg) { acc[0] = a1; acc[1] = a2; } else { acc[0] += a1; acc[1] += a2; }
+          if (min((gg + 1) * cpg, c0 + 1024) == (gg + 1) * cpg) {               // group complete: the affine constants
+            const double mu = (double)mean_rstd[((long)b * G + gg) * 2], rs = (double)mean_rstd[((long)b * G + gg) * 2 + 1];
+            const double Bg = (-(rs * rs)) * acc[1] / M;
+            const double Ag = (-(rs * acc[0])) / M - Bg * mu;
+            float *o = AB + ((long)B * G * 2) * 2 + ((long)b * G + gg) * 2;       // floats behind the f64 scratch
+            o[0] = (float)Ag;
+            o[1] = (float)Bg;
+          }
+        }
+        __syncthreads();
       }
-      __syncthreads();
     }
     if (live) { dgamma[c] = dg; dbeta[c] = db; }
   }
@@ -440,7 +459,7 @@ GCN_EXPORT int gcn_gn_fwd(const void *x, int dtype, const float *gamma, const fl
   GCN_REQUIRE(x && gamma && beta && y && gsum_ws, "gcn_gn_fwd: null pointer");
   if (B == 0) return GCN_OK;
   hipStream_t st = (hipStream_t)stream;
-  GCN_HIP(hipMemsetAsync(gsum_ws, 0, sizeof(double) * 2 * B * G, st));
+  GCN_HIP(zero_dev(gsum_ws, sizeof(double) * 2 * B * G, st));
   const int rows = slab_rows(N, B);
   const dim3 g1(cdiv(N, rows), B);
   const int g2 = (int)(((long)N * C / 4 + 255) / 256 > 2048 ? 2048 : ((long)N * C / 4 + 255) / 256);
@@ -497,8 +516,8 @@ GCN_EXPORT int gcn_gn_max_fwd(const void *x, int dtype, const float *gamma, cons
   GCN_REQUIRE(x && gamma && beta && out_max && out_arg && gsum_ws && best_ws, "gcn_gn_max_fwd: null pointer");
   if (B == 0) return GCN_OK;
   hipStream_t st = (hipStream_t)stream;
-  GCN_HIP(hipMemsetAsync(gsum_ws, 0, sizeof(double) * 2 * B * G, st));
-  GCN_HIP(hipMemsetAsync(best_ws, 0, sizeof(unsigned long long) * (size_t)B * C, st));
+  GCN_HIP(zero_dev(gsum_ws, sizeof(double) * 2 * B * G, st));
+  GCN_HIP(zero_dev(best_ws, sizeof(unsigned long long) * (size_t)B * C, st));
   const int rows = slab_rows(N, B);
   const dim3 g1(cdiv(N, rows), B);
   unsigned long long *best = (unsigned long long *)best_ws;

@@ -437,7 +437,7 @@ GCN_EXPORT int gcn_route_bwd(const float *dout_pm, const float *ymax, const floa
   }
   GCN_HIP(zero_spans(st, {dgamma, sizeof(float) * Cout}, {dbeta, sizeof(float) * Cout}, {S, sizeof(double) * 2 * B * G},
                      {lds_scatter ? dsp_ws : nullptr, lds_scatter ? 256u : 0u}));
-  if (dsp && !lds_scatter) GCN_HIP(hipMemsetAsync(dsp, 0, sizeof(float) * (size_t)B * N * Cout, st));
+  if (dsp && !lds_scatter) GCN_HIP(zero_dev(dsp, sizeof(float) * (size_t)B * N * Cout, st));
   route_bwd_kernel<<<dim3(cdiv(N, rows), B), 256, sizeof(double) * 2 * G + sizeof(float) * 2 * Cout, st>>>(
       dout_pm, ymax, ymin, amax, amin, gamma, beta, mean_rstd, idx, N, k, Cout, G, slope, rows, coef, jsel, msel, dsp,
       dgamma, dbeta, S, bk);
@@ -484,7 +484,7 @@ GCN_EXPORT int gcn_edge_wgrad(const float *x_pm, const float *s_pm, const float 
               "gcn_edge_wgrad: supported C <= 16 or C == 64, Cout in {64,128}; got C=%d Cout=%d", C, Cout);
   hipStream_t st = (hipStream_t)stream;
   const long nws = gcn_edge_wgrad_ws_floats(B, C, Cout);
-  GCN_HIP(hipMemsetAsync(ws, 0, sizeof(float) * nws, st));
+  GCN_HIP(zero_dev(ws, sizeof(float) * nws, st));
   float *M1 = ws, *M2 = M1 + (long)Cout * C, *G11 = M2 + (long)Cout * C, *G21 = G11 + (long)B * C * C,
         *ssum = G21 + (long)B * C * C;
   int blocks = (512 + B - 1) / B;

@@ -39,6 +39,7 @@
 #include "common.h"
 #include "knn_topb.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace gcn {
@@ -576,7 +577,9 @@ GCN_EXPORT int gcn_knn_feature(const float *x_pm, int B, int N, int C, int k1, i
   a.kout = (k2 + a.step - 1) / a.step;
   // rank of the sample order statistic: mean k/8 of the true neighbours fall into the 1-in-8 sample
   const double mu = (double)k2 / KNNF_STRIDE;
-  int m = (int)(mu + 6.0 * __builtin_sqrt(mu) + 2.0);
+  double sig = 6.0;
+  if (const char *e = getenv("GCANET_KNN_SIGMA")) sig = atof(e);          // experiment knob (tools/knn_bench.py)
+  int m = (int)(mu + sig * __builtin_sqrt(mu) + 2.0);
   if (m > 96) m = 96;
   a.m_rank = m;
   GCN_HIP(hipMemsetAsync(base + w.msum, 0, w.ut - w.msum, st));

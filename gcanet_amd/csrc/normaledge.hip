@@ -207,7 +207,7 @@ GCN_EXPORT int gcn_normal_edge_fwd(const float *pts, const int64_t *idx, const f
   GCN_REQUIRE(B >= 0 && N >= 1 && k >= 1 && k <= 256 && Cout >= 1 && G >= 1 && G <= 64 && Cout % G == 0, "gcn_normal_edge_fwd: bad shape");
   if (B == 0) return GCN_OK;
   hipStream_t st = (hipStream_t)stream;
-  GCN_HIP(hipMemsetAsync(gsum, 0, sizeof(double) * 2 * B * G, st));
+  GCN_HIP(zero_dev(gsum, sizeof(double) * 2 * B * G, st));
   int blocks_per_cloud = (1024 + B - 1) / B;
   if (blocks_per_cloud > (N + 3) / 4) blocks_per_cloud = (N + 3) / 4;
   const int ppb = (N + blocks_per_cloud - 1) / blocks_per_cloud;

@@ -8,6 +8,11 @@ import torch
 from . import _lib
 
 
+def _zeroed_like(shape, dtype, device):
+    from .layers import zeroed_like
+    return zeroed_like(shape, dtype, device)
+
+
 _KNN_WS = {}
 
 
@@ -115,7 +120,7 @@ def edgeconv_forward_raw(x, idx, weight, gamma, beta, groups, dtype="bf16", eps=
     if need_arg:
         amax = torch.empty(B, N, Cout, dtype=torch.uint8, device=dev)
         amin = torch.empty(B, N, Cout, dtype=torch.uint8, device=dev)
-    gsum = torch.empty(B, groups, 2, dtype=torch.float64, device=dev)
+    gsum = _zeroed_like((B, groups, 2), torch.float64, dev)
     x_pm = torch.empty(B, N, C, **f32)
     if dtype == "bf16":
         Cp = _lib.lib().gcn_edgeconv_padded_channels(C)
@@ -212,7 +217,7 @@ def _edgeconv_backward(saved, cfg, dout, pm, need_dx=True):
         # weight gradients
         if (C <= 16 or C == 64) and Cout in (64, 128):                 # all row reductions in one MFMA pass
             dW = torch.empty(Cout, 2 * C, dtype=torch.float32, device=x.device)
-            wsf = torch.empty(_lib.lib().gcn_edge_wgrad_ws_floats(B, C, Cout), dtype=torch.float32, device=x.device)
+            wsf = _zeroed_like((_lib.lib().gcn_edge_wgrad_ws_floats(B, C, Cout),), torch.float32, x.device)
             _run("gcn_edge_wgrad", x, _lib.ptr(x), _lib.ptr(s), _lib.ptr(Dsp), _lib.ptr(D2), _lib.ptr(indeg),
                  _lib.ptr(W.contiguous()), _lib.ptr(Ac), _lib.ptr(Bc), B, N, C, Cout, _lib.ptr(dW), _lib.ptr(wsf))
             return dx_pm, dW, dgamma, dbeta
@@ -289,7 +294,7 @@ class GroupedBlockFunction(torch.autograd.Function):
         ymax, ymin = torch.empty(B, N, Cout, **f32), torch.empty(B, N, Cout, **f32)
         amax = torch.empty(B, N, Cout, dtype=torch.uint8, device=dev)
         amin = torch.empty(B, N, Cout, dtype=torch.uint8, device=dev)
-        gsum = torch.empty(B, groups, 2, dtype=torch.float64, device=dev)
+        gsum = _zeroed_like((B, groups, 2), torch.float64, dev)
         # N "points" whose k neighbours are rows n*k..n*k+k-1 of the edge-row "cloud"
         if dtype == "bf16":
             Fp = _lib.lib().gcn_edgeconv_padded_channels(F)
@@ -353,7 +358,7 @@ class NormalEdgeBlockFunction(torch.autograd.Function):
         ymax, ymin = torch.empty(B, N, Cout, **f32), torch.empty(B, N, Cout, **f32)
         amax = torch.empty(B, N, Cout, dtype=torch.uint8, device=dev)
         amin = torch.empty(B, N, Cout, dtype=torch.uint8, device=dev)
-        gsum = torch.empty(B, groups, 2, dtype=torch.float64, device=dev)
+        gsum = _zeroed_like((B, groups, 2), torch.float64, dev)
         _run("gcn_normal_edge_fwd", pts, _lib.ptr(pts), _lib.ptr(idx), _lib.ptr(w), B, N, k, Cout, groups, _lib.ptr(ymax),
              _lib.ptr(ymin), _lib.ptr(amax), _lib.ptr(amin), _lib.ptr(gsum))
         ga, be = gamma.float().contiguous(), beta.float().contiguous()
@@ -372,7 +377,7 @@ class NormalEdgeBlockFunction(torch.autograd.Function):
         jsel, coef, Ac, Bc, dgamma, dbeta, _ = _route_backward_fused(dpm, gamma, beta, ymax, ymin, amax, amin, mean_rstd, G,
                                                                      slope, float((Cout // G) * N * k), want_jsel=True)
         f32 = dict(dtype=torch.float32, device=pts.device)
-        raw = torch.empty(Cout * 7 + B * 7 + B * 49, **f32)        # adjacent accumulators: one zero fill in the library
+        raw = _zeroed_like((Cout * 7 + B * 7 + B * 49,), torch.float32, pts.device)        # adjacent accumulators: one zero fill in the library
         dWsp, esum, gram = raw[:Cout * 7].view(Cout, 7), raw[Cout * 7:Cout * 7 + B * 7].view(B, 7), raw[Cout * 7 + B * 7:].view(B, 7, 7)
         _run("gcn_normal_edge_bwd", pts, _lib.ptr(pts), _lib.ptr(idx), _lib.ptr(coef), _lib.ptr(jsel), B, N, k, Cout,
              _lib.ptr(dWsp), _lib.ptr(esum), _lib.ptr(gram))
@@ -473,7 +478,7 @@ class KeyEdgeBlockFunction(torch.autograd.Function):
         ymax, ymin = torch.empty(B, N, Cout, **f32), torch.empty(B, N, Cout, **f32)
         amax = torch.empty(B, N, Cout, dtype=torch.uint8, device=dev)
         amin = torch.empty(B, N, Cout, dtype=torch.uint8, device=dev)
-        gsum = torch.empty(B, groups, 2, dtype=torch.float64, device=dev)
+        gsum = _zeroed_like((B, groups, 2), torch.float64, dev)
         _run("gcn_keyedge_fwd", att, _lib.ptr(att), _lib.ptr(kidx), _lib.ptr(U), _lib.ptr(V), B, N, k, NK, Cout, groups,
              _lib.ptr(ymax), _lib.ptr(ymin), _lib.ptr(amax), _lib.ptr(amin), _lib.ptr(gsum),
              tag="keyedge_fwd[B=%d,N=%d,k=%d,NK=%d,Cout=%d]" % (B, N, k, NK, Cout))
@@ -497,7 +502,7 @@ class KeyEdgeBlockFunction(torch.autograd.Function):
             X = (V * Bc.unsqueeze(1)) @ U.transpose(1, 2)                   # (B,N,NK)
             datt, dV = torch.empty_like(att), torch.empty_like(V)
             A2 = torch.empty(B, N, NK, dtype=torch.float32, device=att.device)
-            raw = torch.empty(U.numel() + B * 2 * NK, dtype=torch.float32, device=att.device)   # adjacent: one zero fill
+            raw = _zeroed_like((U.numel() + B * 2 * NK,), torch.float32, att.device)   # adjacent: one zero fill
             dUsp, T12 = raw[:U.numel()].view_as(U), raw[U.numel():].view(B, 2, NK)
             _run("gcn_keyedge_bwd", att, _lib.ptr(att), _lib.ptr(kidx), _lib.ptr(U), _lib.ptr(V), _lib.ptr(coef.contiguous()),
                  _lib.ptr(jsel.contiguous()), _lib.ptr(Ac.contiguous()), _lib.ptr(Bc.contiguous()), _lib.ptr(X.contiguous()),
@@ -850,7 +855,7 @@ class EdgeConvPMFunction(torch.autograd.Function):
         ymax = torch.empty(B, N, Cout, **f32)
         amax = torch.empty(B, N, Cout, dtype=torch.uint8, device=dev)
         ymin = amin = None
-        gsum = torch.empty(B, groups, 2, dtype=torch.float64, device=dev)
+        gsum = _zeroed_like((B, groups, 2), torch.float64, dev)
         if dtype == "bf16":
             Cp = _lib.lib().gcn_edgeconv_padded_channels(C)
             x_bf = torch.empty(B, N, Cp, dtype=torch.bfloat16, device=dev)

@@ -17,12 +17,67 @@ def _run(name, like, *args):
         _lib.call(name, *args, _lib.stream_of(like))
 
 
+class ZeroArena:
+    """One pre-zeroed device allocation for the small accumulators the library is asked to zero ("zeroed by the call":
+    GroupNorm sums, weight-gradient tiles, dgamma/dbeta, ...): ~35 fills of ~4.5 us each per training step become ONE
+    fill of the bytes handed out in the previous step.  Registered with the library (gcn_zero_arena_register), which
+    then skips the fill of any span inside it.  Contract: call begin_step() once per step before the first forward and
+    use zeroed_scratch() buffers only within the step that took them."""
+    live = None
+
+    def __init__(self, device, nbytes=96 << 20):
+        self.buf = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+        self.off = 0
+        self.dirty = 0
+        with torch.cuda.device(device):
+            _lib.call("gcn_zero_arena_register", _lib.ptr(self.buf), nbytes)
+        ZeroArena.live = self
+
+    def begin_step(self):
+        if self.dirty:
+            self.buf[:self.dirty].zero_()
+        self.off = 0
+        self.dirty = 0
+
+    def take(self, nbytes):
+        off = (self.off + 255) & ~255
+        if off + nbytes > self.buf.numel():
+            return None
+        self.off = off + nbytes
+        self.dirty = max(self.dirty, self.off)
+        return self.buf[off:off + nbytes]
+
+    def close(self):
+        with torch.cuda.device(self.buf.device):
+            _lib.call("gcn_zero_arena_register", None, 0)
+        if ZeroArena.live is self:
+            ZeroArena.live = None
+
+
+def zeroed_scratch(nbytes, device):
+    """uint8 scratch for an accumulator the library zeroes: from the live ZeroArena (already zero, the library skips its
+    fill) or a plain allocation (the library fills it)."""
+    a = ZeroArena.live
+    if a is not None and a.buf.device == torch.device(device):
+        t = a.take(nbytes)
+        if t is not None:
+            return t
+    return torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+
+def zeroed_like(shape, dtype, device):
+    n = 1
+    for d in shape:
+        n *= d
+    return zeroed_scratch(n * torch.empty((), dtype=dtype).element_size(), device).view(dtype).view(*shape)
+
+
 def _acc_buffers(n_f64, C, device, tail_bytes=0):
     """(S (n_f64,) f64, dgamma (C,) f32, dbeta (C,) f32) carved back to back from ONE allocation, so that the library
     zeroes them with a single fill (csrc/common.h:zero_spans) instead of three 4.5-us launches.  tail_bytes > 0: a
     fourth return value, a uint8 scratch view that starts right behind dbeta (its zeroed header joins the same fill)."""
     head = n_f64 * 8 + 2 * C * 4
-    raw = torch.empty(head + tail_bytes, dtype=torch.uint8, device=device)
+    raw = torch.empty(head + tail_bytes, dtype=torch.uint8, device=device) if tail_bytes else zeroed_scratch(head, device)
     S = raw[:n_f64 * 8].view(torch.float64)
     dg = raw[n_f64 * 8:n_f64 * 8 + C * 4].view(torch.float32)
     db = raw[n_f64 * 8 + C * 4:head].view(torch.float32)
@@ -46,7 +101,7 @@ class GroupNormReLUFunction(torch.autograd.Function):
             _run("gcn_gn_apply", x, _lib.ptr(x), dt, _lib.ptr(gsum), _lib.ptr(ga), _lib.ptr(be), B, N, C, groups, float(eps),
                  int(relu), _lib.ptr(y), _lib.ptr(mean_rstd))
         else:
-            ws = torch.empty(B, groups, 2, dtype=torch.float64, device=x.device)
+            ws = zeroed_like((B, groups, 2), torch.float64, x.device)
             _run("gcn_gn_fwd", x, _lib.ptr(x), dt, _lib.ptr(ga), _lib.ptr(be), B, N, C, groups, float(eps), int(relu),
                  _lib.ptr(y), _lib.ptr(mean_rstd), _lib.ptr(ws))
         ctx.save_for_backward(x, ga, be, mean_rstd)
@@ -206,7 +261,7 @@ def _wgrad_own(dy2, x2, with_bias):
     no split-K partial products to add up, no separate reduction for the bias gradient."""
     M, N = dy2.shape
     K = x2.shape[1]
-    raw = torch.empty(N * K + (N if with_bias else 0), dtype=torch.float32, device=dy2.device)
+    raw = zeroed_like((N * K + (N if with_bias else 0),), torch.float32, dy2.device)
     dw = raw[:N * K].view(N, K)
     db = raw[N * K:] if with_bias else None
     with torch.cuda.device_of(dy2):
@@ -345,8 +400,8 @@ class GroupNormReLUMaxFunction(torch.autograd.Function):
         vals = torch.empty(B, C, dtype=torch.float32, device=x.device)
         arg = torch.empty(B, C, dtype=torch.int64, device=x.device)
         mean_rstd = torch.empty(B, groups, 2, dtype=torch.float32, device=x.device)
-        ws = torch.empty(B, groups, 2, dtype=torch.float64, device=x.device)
-        best = torch.empty(B, C, dtype=torch.int64, device=x.device)
+        ws = zeroed_like((B, groups, 2), torch.float64, x.device)
+        best = zeroed_like((B, C), torch.int64, x.device)
         _run("gcn_gn_max_fwd", x, _lib.ptr(x), dt, _lib.ptr(ga), _lib.ptr(be), B, N, C, groups, float(eps), int(relu),
              _lib.ptr(vals), _lib.ptr(arg), _lib.ptr(mean_rstd), _lib.ptr(ws), _lib.ptr(best))
         ctx.save_for_backward(x, ga, be, mean_rstd, arg)

@@ -557,6 +557,14 @@ int gcn_attention_bwd_f16(const float *q, const float *k, const float *v, const 
  *   rows are `pitch` elements apart (pitch == cols for plain copies). */
 int gcn_multi_cast_bf16(const void *segs_dev, int nseg, void *stream);
 
+/* Optional pre-zeroed scratch arena.  Many entry points zero small accumulators they are handed ("zeroed by the call"):
+ * ~45 fills of a few hundred bytes to a few MB per training step, ~4.5 us of GPU time each.  A caller that carves those
+ * buffers out of ONE device allocation, zeroes the used part of it once per step and never hands the same bytes out
+ * twice within a step may register the allocation here: a span that lies inside [base, base + bytes) is then trusted to
+ * be zero and its fill is skipped (gcanet_amd/layers.py:ZeroArena).  bytes == 0 unregisters.  Process-wide setting, not
+ * thread safe; every other pointer is zeroed by the call exactly as before. */
+int gcn_zero_arena_register(void *base, long bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -77,6 +77,52 @@ def test_hot_path_model_fwd_bwd_runs_and_is_finite(dev):
         assert p_.grad is not None and torch.isfinite(p_.grad).all(), n_
 
 
+def test_zero_arena_steps_match_plain_steps(dev):
+    """layers.ZeroArena (pre-zeroed accumulators, the library skips their fills): three training steps with the arena give
+    the gradients of three steps without it.  f32 model: only the order of atomics differs between the runs -- 1e-4 of
+    the largest gradient after the first step; by the third step that noise has gone through two parameter updates
+    (arg-max and near-tie selections may flip), hence the looser 5e-3 there.  A stale (non-zero) accumulator would be
+    off by O(1)."""
+    from gcanet_amd import dgcnn
+    from gcanet_amd.layers import ZeroArena
+    g = torch.Generator().manual_seed(2)
+    pts = torch.rand(2, 1024, 3, generator=g).to(dev)
+    nrm = torch.nn.functional.normalize(torch.randn(2, 1024, 3, generator=g), dim=-1).to(dev)
+
+    def run(use_arena):
+        torch.manual_seed(0)
+        m = dgcnn.PrimitivesEmbeddingDGCNGn(nn_nb=16, dtype="f32").to(dev)
+        opt = torch.optim.SGD(m.parameters(), lr=1e-3)
+        arena = ZeroArena(dev, 32 << 20) if use_arena else None
+        try:
+            first = None
+            for _ in range(3):
+                if arena is not None:
+                    arena.begin_step()
+                opt.zero_grad(set_to_none=True)
+                out = m(pts, nrm)
+                loss = sum(v.float().pow(2).mean() for v in out.values())
+                loss.backward()
+                if first is None:
+                    first = {n_: p_.grad.clone() for n_, p_ in m.named_parameters() if p_.grad is not None}
+                opt.step()
+            if arena is not None:
+                assert arena.dirty > 0                      # buffers really came from the arena
+        finally:
+            if arena is not None:
+                arena.close()
+        return float(loss), first, {n_: p_.grad.clone() for n_, p_ in m.named_parameters() if p_.grad is not None}
+
+    l1, f1, g1 = run(True)
+    l0, f0, g0 = run(False)
+    assert ZeroArena.live is None
+    assert abs(l1 - l0) <= 1e-4 * abs(l0)
+    for ga, gb, tol in ((f1, f0, 1e-4), (g1, g0, 5e-3)):
+        for n_ in gb:
+            d = (ga[n_] - gb[n_]).abs().max().item()
+            assert d <= tol * max(gb[n_].abs().max().item(), 1e-6) + 1e-7, (n_, tol)
+
+
 def test_hot_path_model_matches_cpu_oracle(dev):
     """Whole hot-path module (f32 exact path) vs oracle/ref_model.hot_path with the same weights; the
     oracle is fed the neighbour lists the GPU kNN produced (kNN parity itself is tested bit-exactly in
