@@ -17,6 +17,7 @@
 // accumulator group: 8- or 16-byte stores instead of 2-byte ones.
 #include "common.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace gcn {
@@ -47,28 +48,31 @@ __device__ __forceinline__ unsigned short gemm_f2bf(float f) {
 // K is walked in steps of 32 through a ring of four LDS stages with THREE stages in flight (the layers are only
 // 4-26 steps deep: a two-buffer scheme pays a full memory latency per step).  Counted s_waitcnt vmcnt + raw
 // s_barrier: __syncthreads() would drain the ring.
-template <int BN>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs a) {
-  constexpr bool SQ = BN == 128;                // 2 x 2 waves
-  constexpr int RB = SQ ? 2 : 1;                // 32-row blocks per wave
-  constexpr int CB = SQ ? 2 : BN / 32;          // 32-column blocks per wave
+// BM = 256, BN = 256 (one workgroup per CU, 256 accumulator registers per lane, opt-in): a wave owns 128 x 128, so every
+// LDS fragment feeds FOUR MFMAs instead of two.
+template <int BN, int BM = 128>
+__global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void gemm_bf16_kernel(GemmArgs a) {
+  constexpr bool SQ = BN >= 128;                // 2 x 2 waves
+  constexpr int RB = SQ ? BM / 64 : 1;          // 32-row blocks per wave
+  constexpr int CB = SQ ? BN / 64 : BN / 32;    // 32-column blocks per wave
   constexpr int WCOLS = CB * 32;                // columns per wave
   constexpr int NST = 4;
-  constexpr int A_BYTES = 128 * 64;             // 128 rows x 32 k x 2 B
+  constexpr int A_BYTES = BM * 64;              // BM rows x 32 k x 2 B
   constexpr int B_BYTES = BN * 64;
   constexpr int ST_BYTES = A_BYTES + B_BYTES;
-  constexpr int WPW = BN >= 64 ? BN / 64 : 1;   // W pieces (16 rows x 64 B) per wave and stage; BN = 32: waves 2,3 repeat 0,1
-  constexpr int DPS = 2 + WPW;                  // DMA instructions per wave and stage (the vmcnt unit)
+  constexpr int APW = BM / 64;                  // A pieces (16 rows x 64 B) per wave and stage
+  constexpr int WPW = BN >= 64 ? BN / 64 : 1;   // W pieces per wave and stage; BN = 32: waves 2,3 repeat 0,1
+  constexpr int DPS = APW + WPW;                // DMA instructions per wave and stage (the vmcnt unit)
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
   const int lane = lane_id(), wave = wave_id();
   const int lr = lane & 31, lh = lane >> 5;
-  const int wrow0 = SQ ? (wave >> 1) * 64 : wave * 32;       // this wave's first row / column inside the tile
-  const int wcol0 = SQ ? (wave & 1) * 64 : 0;
+  const int wrow0 = SQ ? (wave >> 1) * (BM / 2) : wave * 32;  // this wave's first row / column inside the tile
+  const int wcol0 = SQ ? (wave & 1) * (BN / 2) : 0;
   // Workgroups are dealt to the 8 XCDs round robin by linear id.  The column blocks of one 128-row tile all read the
   // same A rows: give them to ONE XCD, back to back, so that the tile comes from HBM once and from that XCD's L2 for
   // the other column blocks.
   const int ncb = (a.N + BN - 1) / BN;
-  const long nrt = (a.M + 127) / 128;
+  const long nrt = (a.M + BM - 1) / BM;
   const long id = blockIdx.x;
   long rt;
   int cbk;
@@ -80,16 +84,16 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs a) {
     cbk = (int)(id % ncb);
     rt = id / ncb;
   }
-  const long m0 = rt * 128;
+  const long m0 = rt * BM;
   const int n0 = cbk * BN;
   const int K = a.K;
   const int ktiles = (K + 31) / 32;
 
   // DMA pieces: 1 KiB = 16 rows x 64 B (4 chunks of 16 B); chunk swizzle (row/4)&3 on the source side
   const int prow = lane >> 2, cs = lane & 3;
-  const unsigned short *arow[2];
+  const unsigned short *arow[APW];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < APW; ++i) {
     const int row = (wave + i * 4) * 16 + prow;
     long m = m0 + row;
     if (m >= a.M) m = a.M - 1;
@@ -108,7 +112,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs a) {
     const bool ok = kbase + cl * 8 < K;                       // K % 16 == 0: the last step may hold two chunks only
     unsigned char *dst = lds + stg * ST_BYTES;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < APW; ++i)
       if (ok)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(arow[i] + kbase),
                                          (__attribute__((address_space(3))) void *)(dst + (wave + i * 4) * 1024), 16, 0, 0);
@@ -139,27 +143,43 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs a) {
     constexpr int STG = decltype(stgc)::value;
     // stage kt must have landed: the younger stages in flight are min(NST-2, ktiles-1-kt)
     const int later = min(NST - 2, ktiles - 1 - kt);
-    if (later >= 2) { if (DPS == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
-    else if (later == 1) { if (DPS == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    static_assert(DPS == 3 || DPS == 4 || DPS == 8, "vmcnt literals below");
+    if (later >= 2) {
+      if (DPS == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if (DPS == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    } else if (later == 1) {
+      if (DPS == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else if (DPS == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();                            // every wave's share of stage kt is in; stage kt-1 is free
     if (kt + NST - 1 < ktiles) issue(kt + NST - 1, (STG + NST - 1) % NST);
     const unsigned char *ta = lds + STG * ST_BYTES + wrow0 * 64;
     const unsigned char *tw = lds + STG * ST_BYTES + A_BYTES + wcol0 * 64;
     const int ksteps = min(2, (K - kt * 32) >> 4);             // wave-uniform
+    // both k-steps' fragments are requested before the first MFMA: the second step's LDS reads complete under the
+    // first step's matrix work (one wave per SIMD at the 256 x 256 tile: nobody else would hide them)
+    bf16x8 xf[2][RB], wf[2][CB];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       if (s < ksteps) {
-        bf16x8 xf[RB], wf[CB];
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb) xf[rb] = *reinterpret_cast<const bf16x8 *>(ta + frag[s] + rb * 32 * 64);
+        for (int rb = 0; rb < RB; ++rb) xf[s][rb] = *reinterpret_cast<const bf16x8 *>(ta + frag[s] + rb * 32 * 64);
 #pragma unroll
-        for (int cb = 0; cb < CB; ++cb) wf[cb] = *reinterpret_cast<const bf16x8 *>(tw + frag[s] + cb * 32 * 64);
+        for (int cb = 0; cb < CB; ++cb) wf[s][cb] = *reinterpret_cast<const bf16x8 *>(tw + frag[s] + cb * 32 * 64);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      if (s < ksteps) {
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
           for (int cb = 0; cb < CB; ++cb)
-            acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cb], xf[rb], acc[rb][cb], 0, 0, 0);   // D[n][m]
+            acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][cb], xf[s][rb], acc[rb][cb], 0, 0, 0);   // D[n][m]
       }
     }
   };
@@ -178,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs a) {
   __builtin_amdgcn_s_barrier();                               // every wave is done with the ring
   const int esz = a.out_f32 ? 4 : 2;
   const int rstride = WCOLS * esz + 16;                       // + 16 B: the column-wise writes below spread over the banks
-  unsigned char *tile = lds + wave * (RB * 32 * (WCOLS * 4 + 16));
+  unsigned char *tile = lds + wave * (32 * (WCOLS * 4 + 16));   // one 32-row slab of the wave's tile at a time
   const bool vec_ok = (a.N % (16 / esz)) == 0;                // rows are 16-byte aligned and chunks never straddle N
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
@@ -209,10 +229,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs a) {
         }
         if (vec_ok) {
           if (a.out_f32) {
-            *reinterpret_cast<float4 *>(tile + (rb * 32 + lr) * rstride + nl * 4) = v;
+            *reinterpret_cast<float4 *>(tile + lr * rstride + nl * 4) = v;
           } else {
             bf16x4 h = {(short)gemm_f2bf(v.x), (short)gemm_f2bf(v.y), (short)gemm_f2bf(v.z), (short)gemm_f2bf(v.w)};
-            *reinterpret_cast<bf16x4 *>(tile + (rb * 32 + lr) * rstride + nl * 2) = h;
+            *reinterpret_cast<bf16x4 *>(tile + lr * rstride + nl * 2) = h;
           }
         } else if (mv) {                                      // narrow odd-width heads (10, 22, 3 columns): element stores
           const float vv[4] = {v.x, v.y, v.z, v.w};
@@ -240,19 +260,20 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs a) {
         }
       }
     }
-  }
-  if (vec_ok) {
-    __builtin_amdgcn_wave_barrier();                          // same wave wrote the tile: in-order LDS queue
-    const int cpr = WCOLS * esz / 16;                         // 16-byte chunks per tile row (4 ... 32)
-    const int rpi = 64 / cpr;                                 // rows per store instruction
-    for (int r0 = 0; r0 < RB * 32; r0 += rpi) {
-      const int r = r0 + lane / cpr, ch = lane % cpr;
-      const int ncol = n0 + wcol0 + ch * (16 / esz);
-      const long mrow = m0 + wrow0 + r;
-      if (mrow < a.M && ncol < a.N) {
-        const uint4 d = *reinterpret_cast<const uint4 *>(tile + r * rstride + ch * 16);
-        *reinterpret_cast<uint4 *>(reinterpret_cast<unsigned char *>(a.out) + (mrow * a.N + ncol) * esz) = d;
+    if (vec_ok) {
+      __builtin_amdgcn_wave_barrier();                        // same wave wrote the slab: in-order LDS queue
+      const int cpr = WCOLS * esz / 16;                       // 16-byte chunks per tile row (4 ... 32)
+      const int rpi = 64 / cpr;                               // rows per store instruction
+      for (int r0 = 0; r0 < 32; r0 += rpi) {
+        const int r = r0 + lane / cpr, ch = lane % cpr;
+        const int ncol = n0 + wcol0 + ch * (16 / esz);
+        const long mr = m0 + wrow0 + rb * 32 + r;
+        if (mr < a.M && ncol < a.N) {
+          const uint4 d = *reinterpret_cast<const uint4 *>(tile + r * rstride + ch * 16);
+          *reinterpret_cast<uint4 *>(reinterpret_cast<unsigned char *>(a.out) + (mr * a.N + ncol) * esz) = d;
+        }
       }
+      __builtin_amdgcn_wave_barrier();                        // the next slab overwrites the tile after these reads
     }
   }
 }
@@ -464,16 +485,25 @@ GCN_EXPORT int gcn_gemm_bf16(const void *A, const void *W, const float *bias, vo
   a.A = (const unsigned short *)A; a.W = (const unsigned short *)W; a.bias = bias; a.out = out; a.gsum = gsum;
   a.M = M; a.N = N; a.Np = Np; a.K = K; a.out_f32 = out_f32; a.rows_per_cloud = rows_per_cloud; a.G = G;
   a.part = (double *)stats_ws;
-  const int mblocks = (int)((M + 127) / 128);
-#define GEMM_LAUNCH(BNV)                                                                                           \
+#define GEMM_LAUNCH(BNV, BMV)                                                                                      \
   {                                                                                                                 \
-    constexpr int RING = 4 * (128 * 64 + BNV * 64);                                                                 \
-    constexpr int EPI = BNV == 128 ? 4 * 64 * (64 * 4 + 16) : 4 * 32 * (BNV * 4 + 16);                              \
+    constexpr int RING = 4 * (BMV * 64 + BNV * 64);                                                                 \
+    constexpr int WC = BNV >= 128 ? BNV / 2 : BNV;                                                                  \
+    constexpr int EPI = 4 * 32 * (WC * 4 + 16);                                                                     \
     constexpr int LDSB = RING > EPI ? RING : EPI;                                                                   \
-    GCN_HIP(hipFuncSetAttribute((const void *)gemm_bf16_kernel<BNV>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB)); \
-    gemm_bf16_kernel<BNV><<<mblocks * ((N + BNV - 1) / BNV), 256, LDSB, st>>>(a);                                \
+    const int mblocks = (int)((M + BMV - 1) / BMV);                                                                 \
+    GCN_HIP(hipFuncSetAttribute((const void *)gemm_bf16_kernel<BNV, BMV>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB)); \
+    gemm_bf16_kernel<BNV, BMV><<<mblocks * ((N + BNV - 1) / BNV), 256, LDSB, st>>>(a);                           \
   }
-  if (N > 64) GEMM_LAUNCH(128) else if (N > 32) GEMM_LAUNCH(64) else GEMM_LAUNCH(32)
+  // 256 x 256 tiles (128 x 128 per wave): opt-in (GCANET_GEMM_TILE=256).  Measured at M = 65536 it is no faster than
+  // the 128 x 128 tile at K = 1280 (147 us both, 585 TF: PMC says the matrix pipe is busy 30 % and waves sit in
+  // s_waitcnt 40 % of their cycles with LDS conflicts at zero -- the LDS-DMA ring, not the LDS read rate, is what
+  // starves it) and slower at K = 256, where eight k-steps cannot amortise a 256-register epilogue with one workgroup
+  // per CU (77 vs 49 us at N = 512).
+  const char *tile_env = getenv("GCANET_GEMM_TILE");
+  const bool big_ok = tile_env && atoi(tile_env) == 256;
+  if (N >= 256 && M >= 256 * 128 && big_ok) GEMM_LAUNCH(256, 256)
+  else if (N > 64) GEMM_LAUNCH(128, 128) else if (N > 32) GEMM_LAUNCH(64, 128) else GEMM_LAUNCH(32, 128)
 #undef GEMM_LAUNCH
   int rc = check_launch("gemm_bf16_kernel");
   if (rc || !gsum) return rc;

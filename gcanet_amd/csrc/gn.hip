@@ -376,14 +376,26 @@ __global__ __launch_bounds__(1024) void gn_max_bwd_sums_kernel(const void *__res
           s2 = (double)(ga * gz) * (double)xh;
           sp[(long)b * C + c] = rstd * ga * gz;
         }
-        p1[threadIdx.x] = s1;
-        p2[threadIdx.x] = s2;
+        // group sums in a fixed order (deterministic): whole waves per group -> butterfly inside the wave, then one
+        // thread per group adds the wave partials; otherwise one thread per group walks its channels
+        const bool by_wave = cpg % 64 == 0;
+        if (by_wave) {
+#pragma unroll
+          for (int o = 32; o >= 1; o >>= 1) {
+            s1 += __shfl_xor(s1, o);
+            s2 += __shfl_xor(s2, o);
+          }
+          if (lane_id() == 0) { p1[wave_id()] = s1; p2[wave_id()] = s2; }
+        } else {
+          p1[threadIdx.x] = s1;
+          p2[threadIdx.x] = s2;
+        }
         __syncthreads();
-        // groups whose channels lie in this chunk: one thread per group adds its channels in order (deterministic)
         const int g0 = c0 / cpg, g1 = min(G, (min(C, c0 + 1024) + cpg - 1) / cpg);
         if ((int)threadIdx.x < g1 - g0) {
           const int gg = g0 + threadIdx.x;
-          const int lo = max(gg * cpg, c0) - c0, hi = min((gg + 1) * cpg, c0 + 1024) - c0;
+          int lo = max(gg * cpg, c0) - c0, hi = min((gg + 1) * cpg, c0 + 1024) - c0;
+          if (by_wave) { lo /= 64; hi /= 64; }
           double a1 = 0.0, a2 = 0.0;
           for (int i = lo; i < hi; ++i) { a1 += p1[i]; a2 += p2[i]; }
           // a group may straddle chunks (cpg > 1024): accumulate in AB as raw sums first (f32 pairs hold them below)

@@ -15,8 +15,23 @@ def _bf(t):
 @pytest.mark.parametrize("M,N,K,bias,out_f32", [
     (1024, 512, 256, True, 0), (1024, 256, 512, True, 0), (1000, 256, 832, True, 0), (640, 64, 256, True, 1),
     (384, 10, 256, True, 1), (384, 22, 256, False, 1), (300, 3, 256, True, 1), (512, 128, 272, True, 0),
-    (256, 1024, 256, True, 0), (512, 256, 16, False, 0), (512, 256, 32, True, 0), (129, 96, 80, True, 1)])
+    (256, 1024, 256, True, 0), (512, 256, 16, False, 0), (512, 256, 32, True, 0), (129, 96, 80, True, 1),
+    # M >= 32768 and N >= 256 also run with the opt-in 256 x 256 tile (128 x 128 per wave): ragged M, N not a multiple of
+    # the tile, short K
+    (32768, 512, 256, True, 0), (32768 + 100, 256, 1280, True, 0), (40000, 320, 48, True, 1), (32768, 1024, 272, False, 0)])
 def test_gemm_forward(dev, M, N, K, bias, out_f32):
+    _check_forward(dev, M, N, K, bias, out_f32)
+
+
+@pytest.mark.parametrize("M,N,K,bias,out_f32", [(32768, 512, 256, True, 0), (32768 + 100, 256, 1280, True, 0),
+                                                (40000, 320, 48, True, 1), (32768, 1024, 272, False, 0)])
+def test_gemm_forward_tile256(dev, monkeypatch, M, N, K, bias, out_f32):
+    """The opt-in 256 x 256 workgroup tile (GCANET_GEMM_TILE=256; serves M >= 32768, N >= 256)."""
+    monkeypatch.setenv("GCANET_GEMM_TILE", "256")
+    _check_forward(dev, M, N, K, bias, out_f32)
+
+
+def _check_forward(dev, M, N, K, bias, out_f32):
     from gcanet_amd import _lib
     g = torch.Generator().manual_seed(M + N + K)
     A = _bf(torch.randn(M, K, generator=g)).to(dev)
@@ -35,7 +50,8 @@ def test_gemm_forward(dev, M, N, K, bias, out_f32):
     np.testing.assert_allclose(out.float().cpu().numpy(), ref.cpu().numpy(), rtol=tol, atol=tol * float(ref.abs().max()))
 
 
-@pytest.mark.parametrize("B,Npts,N,K,G", [(2, 256, 512, 256, 8), (3, 128, 256, 512, 4), (2, 384, 128, 272, 4), (1, 256, 1024, 256, 8)])
+@pytest.mark.parametrize("B,Npts,N,K,G", [(2, 256, 512, 256, 8), (3, 128, 256, 512, 4), (2, 384, 128, 272, 4), (1, 256, 1024, 256, 8),
+                                          (8, 4096, 512, 256, 8), (5, 8192, 256, 64, 4)])
 def test_gemm_fused_groupnorm_statistics(dev, B, Npts, N, K, G):
     from gcanet_amd import _lib
     g = torch.Generator().manual_seed(N + K + G)
