@@ -97,7 +97,8 @@ __global__ void cluster_classify_kernel(int n, const int32_t *__restrict__ comp,
       } else {
         const float mean = class_mean[cls];
         const float low = (float)(0.05 * mean), high = (float)(0.3 * mean);    // hierarchical_aggregation.cpp:60-61
-        if (sz < high) { if (sz >= low) ks = sz; }
+        const bool all_fragments = size_threshold < -1.5f;                     // set aggregation needs the dropped ones too
+        if (sz < high) { if (sz >= low || all_fragments) ks = sz; }
         else ps = sz;
       }
     }
@@ -233,6 +234,166 @@ __global__ void cluster_emit_kernel(int n, const int32_t *__restrict__ counters,
   cluster_idxs[2 * q + 1] = v < (unsigned int)n ? point_index[v] : -1;
 }
 
+
+// ---------------------------------------------------------------- set aggregation (using_set_aggr = True, evaluation)
+// hierarchical_aggregation.cu:22-196 + the merge of functions.py:52-72: every fragment (component below 0.3*mean points)
+// looks for the nearest primary of its (cloud, class) subset; if that centroid lies within 0.01*sqrt(|primary|) it is
+// absorbed -- its points are appended to the primary's cluster, fragments in index order, at most 1000 fragments and
+// 3000 points per primary.  Input: ALL components of every segment from gcn_cluster_components(size_threshold = -2):
+// per segment the fragments in discovery order, then the primaries, members in BFS order (rows hold the sorted-array
+// index v of each member).  Centroids are sequential f32 sums in member order, distances (dx*dx + dy*dy) + dz*dz, the
+// absorption order is the fragment index order: the oracle's arithmetic and order (oracle/gcanet_oracle.c:
+// orc_hier_set_aggr; the reference's own order comes from atomicAdd and is unspecified).
+struct SetAggrArgs {
+  const int32_t *counts_in;     // (2) device: rows, clusters of the input
+  const int32_t *rows;          // (rows,2): (cluster id, v)
+  const int32_t *offs;          // (clusters+1)
+  const int32_t *seg_of;        // (n)
+  const int32_t *seg_cls;       // (S)
+  const float *xyz;             // (n,3) shifted coordinates in sorted order
+  const int32_t *point_index;   // (n) caller's index of sorted position v
+  int n, S;
+  int32_t *cfirst, *cend;       // (S) cluster range of a segment (cfirst = INT_MAX when it has none)
+  float *cen;                   // (n,3)
+  int32_t *owner, *take, *apos, *nfrag, *apts, *oloc, *ooff;   // (n) each
+  int32_t *segcl, *segpts, *basecl, *basepts;                  // (S) each
+  int32_t *out_idxs, *out_offs, *out_counts;
+};
+
+__device__ __forceinline__ bool sa_is_primary(int cls, int sz) {
+  const float class_mean[10] = {-1.f, -1.f, 3917.f, 12056.f, 2303.f, 8331.f, 3948.f, 3166.f, 5629.f, 11719.f};
+  const float high = (float)(0.3 * class_mean[cls]);
+  return !(sz < high);
+}
+__device__ __forceinline__ bool sa_is_kept(int cls, int sz) {
+  const float class_mean[10] = {-1.f, -1.f, 3917.f, 12056.f, 2303.f, 8331.f, 3948.f, 3166.f, 5629.f, 11719.f};
+  const float low = (float)(0.05 * class_mean[cls]), high = (float)(0.3 * class_mean[cls]);
+  return sz < high && sz >= low;
+}
+
+__global__ void sa_init_kernel(SetAggrArgs a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < a.S) { a.cfirst[i] = 0x7fffffff; a.cend[i] = 0; a.segcl[i] = 0; a.segpts[i] = 0; }
+}
+
+__global__ void sa_ranges_kernel(SetAggrArgs a) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= a.counts_in[1]) return;
+  const int s = a.seg_of[a.rows[2L * a.offs[c] + 1]];
+  atomicMin(a.cfirst + s, c);
+  atomicMax(a.cend + s, c + 1);
+}
+
+// one workgroup per segment
+__global__ __launch_bounds__(256) void sa_segment_kernel(SetAggrArgs a) {
+  const int s = blockIdx.x;
+  const int c0 = a.cfirst[s], c1 = a.cend[s];
+  if (c0 >= c1) return;
+  const int cls = a.seg_cls[s];
+  // centroids: sequential f32 sums in member (BFS) order, as the reference accumulates them
+  for (int c = c0 + threadIdx.x; c < c1; c += 256) {
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    const int b = a.offs[c], e = a.offs[c + 1];
+    for (int q = b; q < e; ++q) {
+      const int v = a.rows[2L * q + 1];
+      ax += a.xyz[3L * v]; ay += a.xyz[3L * v + 1]; az += a.xyz[3L * v + 2];
+    }
+    const float sz = (float)(e - b);
+    a.cen[3L * c] = ax / sz; a.cen[3L * c + 1] = ay / sz; a.cen[3L * c + 2] = az / sz;
+    a.nfrag[c] = 0; a.apts[c] = 0; a.take[c] = 0; a.apos[c] = 0; a.owner[c] = -1; a.oloc[c] = -1; a.ooff[c] = 0;
+  }
+  __syncthreads();
+  // primaries are the tail of the segment's cluster range
+  __shared__ int p0_s;
+  if (threadIdx.x == 0) {
+    int p0 = c1;
+    while (p0 > c0 && sa_is_primary(cls, a.offs[p0] - a.offs[p0 - 1])) --p0;
+    p0_s = p0;
+  }
+  __syncthreads();
+  const int p0 = p0_s;
+  for (int f = c0 + threadIdx.x; f < p0; f += 256) {             // hierarchical_aggregation.cu:22-75
+    float nearest = 10000.f;
+    int ni = -1;
+    for (int i = p0; i < c1; ++i) {
+      const float dx = a.cen[3L * i] - a.cen[3L * f], dy = a.cen[3L * i + 1] - a.cen[3L * f + 1],
+                  dz = a.cen[3L * i + 2] - a.cen[3L * f + 2];
+      const float d = (dx * dx + dy * dy) + dz * dz;
+      if (d < nearest) { nearest = d; ni = i; }
+    }
+    if (ni >= 0) {
+      const int pn = a.offs[ni + 1] - a.offs[ni];
+      const float r = (float)(0.01 * sqrtf((float)pn));
+      if (nearest < r * r) a.owner[f] = ni;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    // absorption in fragment index order with the reference's caps (hierarchical_aggregation.cu:9-12)
+    for (int f = c0; f < p0; ++f) {
+      const int o = a.owner[f];
+      if (o < 0 || a.nfrag[o] >= 1000) continue;
+      a.nfrag[o] += 1;
+      const int sz = a.offs[f + 1] - a.offs[f];
+      int t = 3000 - a.apts[o];
+      t = t < 0 ? 0 : (t > sz ? sz : t);
+      a.take[f] = t;
+      a.apos[f] = a.apts[o];
+      a.apts[o] += t;
+    }
+    // layout inside the segment: kept fragments, then primaries (each with what it absorbed)
+    int ncl = 0, npt = 0;
+    for (int c = c0; c < c1; ++c) {
+      const int sz = a.offs[c + 1] - a.offs[c];
+      const bool prim = c >= p0;
+      if (!prim && !sa_is_kept(cls, sz)) continue;
+      a.oloc[c] = ncl++;
+      a.ooff[c] = npt;
+      npt += sz + (prim ? a.apts[c] : 0);
+    }
+    a.segcl[s] = ncl;
+    a.segpts[s] = npt;
+  }
+}
+
+__global__ void sa_scan_kernel(SetAggrArgs a) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  int cl = 0, pt = 0;
+  for (int s = 0; s < a.S; ++s) {
+    a.basecl[s] = cl; a.basepts[s] = pt;
+    cl += a.segcl[s]; pt += a.segpts[s];
+  }
+  a.out_offs[cl] = pt;
+  a.out_counts[0] = pt;
+  a.out_counts[1] = cl;
+}
+
+// one workgroup per input cluster: its own copy (kept fragment / primary) and, for an absorbed fragment, the copy
+// behind its owner's points
+__global__ __launch_bounds__(256) void sa_emit_kernel(SetAggrArgs a) {
+  const int c = blockIdx.x;
+  if (c >= a.counts_in[1]) return;
+  const int b = a.offs[c], sz = a.offs[c + 1] - b;
+  const int s = a.seg_of[a.rows[2L * b + 1]];
+  if (a.oloc[c] >= 0) {
+    const int id = a.basecl[s] + a.oloc[c], start = a.basepts[s] + a.ooff[c];
+    if (threadIdx.x == 0) a.out_offs[id] = start;
+    for (int t = threadIdx.x; t < sz; t += 256) {
+      a.out_idxs[2L * (start + t)] = id;
+      a.out_idxs[2L * (start + t) + 1] = a.point_index[a.rows[2L * (b + t) + 1]];
+    }
+  }
+  const int o = a.owner[c], tk = a.take[c];
+  if (o >= 0 && tk > 0) {
+    const int id = a.basecl[s] + a.oloc[o];
+    const int start = a.basepts[s] + a.ooff[o] + (a.offs[o + 1] - a.offs[o]) + a.apos[c];
+    for (int t = threadIdx.x; t < tk; t += 256) {
+      a.out_idxs[2L * (start + t)] = id;
+      a.out_idxs[2L * (start + t) + 1] = a.point_index[a.rows[2L * (b + t) + 1]];
+    }
+  }
+}
+
 }  // namespace gcn
 
 using namespace gcn;
@@ -272,4 +433,34 @@ GCN_EXPORT int gcn_cluster_components(int n, const int32_t *nbr, const int32_t *
   cluster_emit_kernel<<<cdiv(n, 256), 256, 0, st>>>(n, counters, cluster_offsets, out, point_index, cluster_idxs);
   GCN_HIP(hipMemcpyAsync(counts, counters + 2, 2 * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
   return check_launch("cluster kernels");
+}
+
+GCN_EXPORT long gcn_set_aggregation_ws_bytes(int n, int S) {
+  if (n < 0 || S < 1) return -1;
+  return 4L * (10L * n + 6L * S + 64);
+}
+
+GCN_EXPORT int gcn_set_aggregation(int n, int S, const int32_t *counts_in, const int32_t *rows, const int32_t *offs,
+                                   const int32_t *seg_of, const int32_t *seg_cls, const float *xyz,
+                                   const int32_t *point_index, void *ws, int32_t *out_idxs, int32_t *out_offs,
+                                   int32_t *out_counts, void *stream) {
+  GCN_REQUIRE(n >= 1 && S >= 1 && counts_in && rows && offs && seg_of && seg_cls && xyz && point_index && ws && out_idxs &&
+              out_offs && out_counts, "gcn_set_aggregation: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  SetAggrArgs a{};
+  a.counts_in = counts_in; a.rows = rows; a.offs = offs; a.seg_of = seg_of; a.seg_cls = seg_cls; a.xyz = xyz;
+  a.point_index = point_index; a.n = n; a.S = S;
+  int32_t *w = (int32_t *)ws;
+  a.cfirst = w; a.cend = w + S; a.segcl = w + 2 * S; a.segpts = w + 3 * S; a.basecl = w + 4 * S; a.basepts = w + 5 * S;
+  int32_t *p = w + 6 * S + 8;
+  a.cen = (float *)p; p += 3L * n;
+  a.owner = p; p += n; a.take = p; p += n; a.apos = p; p += n; a.nfrag = p; p += n; a.apts = p; p += n;
+  a.oloc = p; p += n; a.ooff = p;
+  a.out_idxs = out_idxs; a.out_offs = out_offs; a.out_counts = out_counts;
+  sa_init_kernel<<<cdiv(S, 256), 256, 0, st>>>(a);
+  sa_ranges_kernel<<<cdiv(n, 256), 256, 0, st>>>(a);
+  sa_segment_kernel<<<S, 256, 0, st>>>(a);
+  sa_scan_kernel<<<1, 64, 0, st>>>(a);
+  sa_emit_kernel<<<n, 256, 0, st>>>(a);
+  return check_launch("set aggregation kernels");
 }

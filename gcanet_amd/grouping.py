@@ -108,12 +108,10 @@ def forward_grouping_device(semantic_scores, pt_offsets, batch_idxs, coords_floa
     Same return value as forward_grouping (CPU int32 tensors; device tensors with to_cpu=False).  Pairs whose
     similarity lies within float rounding of a threshold can fall on the other side than with the dense path, which
     takes its distances from torch.cdist's matmul form; the reference's own result moves with the torch version there.
-    If a neighbour list hits the 3000 cap (bfs_cluster.cu:54: lists stop being symmetric) or set aggregation is
-    requested (evaluation only), the literal path is taken."""
-    if training_mode != 'train' and using_set_aggr:
-        return forward_grouping(semantic_scores, pt_offsets, batch_idxs, coords_float, type_per_point, param_per_point,
-                                feature_per_point, semantic_classes, training_mode, using_set_aggr, radius,
-                                similarity_threshold_inst, similarity_threshold_para, mean_active, min_npoint)
+    Set aggregation (evaluation: `training_mode != 'train' and using_set_aggr`, hierarchical_aggregation.cu:22-196) runs
+    on the device as well (csrc/cluster_dev.hip: gcn_set_aggregation).  If a neighbour list hits the 3000 cap
+    (bfs_cluster.cu:54: lists stop being symmetric) the literal path is taken."""
+    set_aggr = training_mode != 'train' and bool(using_set_aggr)
     _lib.require_cuda(semantic_scores, pt_offsets, coords_float, param_per_point, feature_per_point)
     B, N = type_per_point.shape[0], type_per_point.shape[1]
     P = int(semantic_classes)
@@ -154,9 +152,24 @@ def forward_grouping_device(semantic_scores, pt_offsets, batch_idxs, coords_floa
                       _lib.ptr(seg_cls), S, _lib.ptr(fi), fi.shape[1], _lib.ptr(dm[0]), float(similarity_threshold_inst),
                       _lib.ptr(fp), fp.shape[1], _lib.ptr(dm[1]), float(similarity_threshold_para), _lib.ptr(nbr),
                       capacity, _lib.ptr(start_len), _lib.ptr(status), _lib.ptr(grid_ws), st)
-            _lib.call("gcn_cluster_components", n, _lib.ptr(nbr), _lib.ptr(start_len), _lib.ptr(seg_of),
-                      _lib.ptr(seg_offsets), _lib.ptr(seg_cls), S, _lib.ptr(point_index), -1.0, _lib.ptr(ws),
-                      _lib.ptr(cluster_idxs), _lib.ptr(cluster_offsets), _lib.ptr(status[4:]), st)
+            if not set_aggr:
+                _lib.call("gcn_cluster_components", n, _lib.ptr(nbr), _lib.ptr(start_len), _lib.ptr(seg_of),
+                          _lib.ptr(seg_offsets), _lib.ptr(seg_cls), S, _lib.ptr(point_index), -1.0, _lib.ptr(ws),
+                          _lib.ptr(cluster_idxs), _lib.ptr(cluster_offsets), _lib.ptr(status[4:]), st)
+            else:
+                # every component (dropped fragments too) in sorted positions, then the absorption pass
+                ident = torch.arange(n, dtype=torch.int32, device=dev)
+                all_idxs = torch.empty(n, 2, dtype=torch.int32, device=dev)
+                all_offs = torch.empty(n + 1, dtype=torch.int32, device=dev)
+                all_counts = torch.empty(2, dtype=torch.int32, device=dev)
+                _lib.call("gcn_cluster_components", n, _lib.ptr(nbr), _lib.ptr(start_len), _lib.ptr(seg_of),
+                          _lib.ptr(seg_offsets), _lib.ptr(seg_cls), S, _lib.ptr(ident), -2.0, _lib.ptr(ws),
+                          _lib.ptr(all_idxs), _lib.ptr(all_offs), _lib.ptr(all_counts), st)
+                cluster_idxs = torch.empty(2 * n, 2, dtype=torch.int32, device=dev)      # absorbed points appear twice
+                sa_ws = torch.empty(lib.gcn_set_aggregation_ws_bytes(n, S), dtype=torch.uint8, device=dev)
+                _lib.call("gcn_set_aggregation", n, S, _lib.ptr(all_counts), _lib.ptr(all_idxs), _lib.ptr(all_offs),
+                          _lib.ptr(seg_of), _lib.ptr(seg_cls), _lib.ptr(shifted), _lib.ptr(point_index), _lib.ptr(sa_ws),
+                          _lib.ptr(cluster_idxs), _lib.ptr(cluster_offsets), _lib.ptr(status[4:]), st)
             total, capped, overflow, _, nsum, ncl = status.cpu().tolist()[:6]       # the one host synchronisation
             if not overflow:
                 break

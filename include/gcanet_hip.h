@@ -193,6 +193,7 @@ int gcn_ballquery_sim(int n, float radius, const float *xyz, const int32_t *seg_
  * reference's BFS dequeue order, segment by segment, kept fragments before primaries.  cluster_idxs (n,2) gets
  * (cluster id, point_index[member]) rows, cluster_offsets (n+1); counts (2 ints, device) = (rows, clusters) that are
  * valid.  No host synchronisation.  seg_cls (S): semantic class 0..9 of the segment or < 0 to skip it.  n < 2^20.
+ * size_threshold = -2: as -1 but the fragments below 0.05*mean are listed as well (input of gcn_set_aggregation).
  * size_threshold < 0: the kept/primary rule above; >= 0: `bfs_cluster` (bfs_cluster.cpp:48-143) -- every component of at
  * least size_threshold points, in discovery order (one segment: S = 1, seg_cls[0] = 0). */
 long gcn_cluster_components_ws_bytes(int n);
@@ -200,6 +201,18 @@ int gcn_cluster_components(int n, const int32_t *nbr, const int32_t *start_len, 
                            const int32_t *seg_offsets, const int32_t *seg_cls, int S, const int32_t *point_index,
                            float size_threshold, void *ws, int32_t *cluster_idxs, int32_t *cluster_offsets,
                            int32_t *counts, void *stream);
+/* Set aggregation of hierarchical_aggregation (hierarchical_aggregation.cu:22-196, using_set_aggr = True: evaluation) on
+ * the device.  Input: gcn_cluster_components(size_threshold = -2) -- ALL components per segment (fragments in discovery
+ * order, then primaries; pass point_index = 0..n-1 there so that rows carry sorted positions), counts_in (2) device.
+ * Every fragment joins the nearest primary of its segment if the centroids are closer than 0.01*sqrt(|primary|) (at
+ * most 1000 fragments / 3000 points per primary, fragment index order -- the oracle's order; the reference's comes from
+ * atomicAdd).  Output as gcn_cluster_components: kept fragments then primaries (with their absorbed points) per
+ * segment, out_counts (2) device = (rows, clusters).  xyz (n,3) = the shifted coordinates in sorted order. */
+long gcn_set_aggregation_ws_bytes(int n, int S);
+int gcn_set_aggregation(int n, int S, const int32_t *counts_in, const int32_t *rows, const int32_t *offs,
+                        const int32_t *seg_of, const int32_t *seg_cls, const float *xyz, const int32_t *point_index,
+                        void *ws, int32_t *out_idxs, int32_t *out_offs, int32_t *out_counts, void *stream);
+
 /* ---- sparse 3-D convolutions of the instance "tiny U-Net" (softgroup/model/blocks.py:44-143; M4:611-616,1379-1392;
  * the reference calls the un-vendored third-party spconv package: SubMConv3d / SparseConv3d(k=2,s=2) /
  * SparseInverseConv3d).  Sparse tensor = features (M,C) f32 + coords (M,4) int32 [sample,x,y,z] with 0 <= x,y,z < D,

@@ -17,7 +17,8 @@ def test_adjacency_matches_reference_golden(dev, golden):
     np.testing.assert_allclose(out.cpu().numpy(), golden["adj_out"], rtol=1e-5, atol=1e-6)
 
 
-def _oracle_forward_grouping(sem, off, bidx, xyz, B, N, par, feat, P, radius, thr_i, thr_p, mean_active, min_npoint):
+def _oracle_forward_grouping(sem, off, bidx, xyz, B, N, par, feat, P, radius, thr_i, thr_p, mean_active, min_npoint,
+                             mode="train", set_aggr=False):
     """M4:1123-1295 restated on the CPU oracle (numpy + oracle C ops)."""
     sm = torch.from_numpy(sem).softmax(-1).view(B, N, -1)
     plist, olist = [], []
@@ -34,7 +35,7 @@ def _oracle_forward_grouping(sem, off, bidx, xyz, B, N, par, feat, P, radius, th
             a1 = R.compute_batch_adjacency_matrix(torch.from_numpy(feat[b][obj]).unsqueeze(0))[0].numpy()
             a2 = R.compute_batch_adjacency_matrix(torch.from_numpy(par[b][obj]).unsqueeze(0))[0].numpy()
             idx, sl = oracle.ballquery_batch_p(sh, bi, boffs, radius, mean_active, a1, thr_i, a2, thr_p)
-            pi, po = oracle.hierarchical_aggregation(np.full(obj.size, cid, np.int32), sh, idx, sl, bi, "train", False)
+            pi, po = oracle.hierarchical_aggregation(np.full(obj.size, cid, np.int32), sh, idx, sl, bi, mode, set_aggr)
             pi = pi.copy()
             pi[:, 1] = obj[pi[:, 1]]
             if olist:
@@ -149,6 +150,49 @@ def test_forward_grouping_device_matches_oracle(dev, case):
     rpi, rpo = _oracle_forward_grouping(sem, off, bidx, xyz.reshape(-1, 3), B, N, par, feat, P, 0.03, 0.9, 0.0, 50,
                                         kw["min_npoint"])
     assert rpo.size > 4, "test data produced no clusters"
+    np.testing.assert_array_equal(po.numpy(), rpo)
+    np.testing.assert_array_equal(pi.numpy(), rpi)
+
+
+def test_forward_grouping_device_set_aggregation(dev):
+    """using_set_aggr (evaluation) on the device (gcn_set_aggregation) against the oracle (hierarchical_aggregation.cu:
+    22-196 restated): class 4 (mean 2303: fragments below 691 points, kept from 116).  Cloud 0: a 900-point primary with
+    eight 450-point fragments inside its 0.3 radius (3600 > the 3000-point cap: the seventh is cut, the eighth dropped), a
+    40-point fragment (dropped as a cluster, still absorbed if in reach... here out of reach) and a far 200-point fragment
+    (kept, not absorbed).  Cloud 1: two primaries, each fragment joins the nearer one."""
+    from gcanet_amd.grouping import forward_grouping_device
+    rng = np.random.default_rng(7)
+    P, E = 5, 16
+    scenes = [
+        dict(centers=[(0.5, 0.5, 0.5)] + [(0.5 + 0.2 * np.cos(a), 0.5 + 0.2 * np.sin(a), 0.5) for a in np.arange(8) * 0.785]
+             + [(0.05, 0.05, 0.95), (0.95, 0.95, 0.05)], sizes=[900] + [450] * 8 + [40, 200]),
+        dict(centers=[(0.3, 0.5, 0.5), (0.7, 0.5, 0.5), (0.38, 0.5, 0.5), (0.62, 0.5, 0.5), (0.5, 0.9, 0.5), (0.33, 0.45, 0.5)],
+             sizes=[800, 1000, 300, 250, 120, 60]),
+    ]
+    N = max(sum(sc["sizes"]) for sc in scenes)
+    B = len(scenes)
+    xyz = np.zeros((B, N, 3), np.float32)
+    which = np.zeros((B, N), np.int64)
+    for b, sc in enumerate(scenes):
+        ids = np.repeat(np.arange(len(sc["sizes"])), sc["sizes"])
+        ids = np.concatenate([ids, np.full(N - ids.size, len(sc["sizes"]) - 1)])    # pad with the last blob
+        ids = rng.permutation(ids)
+        which[b] = ids
+        xyz[b] = np.asarray(sc["centers"], np.float32)[ids] + 0.004 * rng.standard_normal((N, 3))
+    sem = (rng.standard_normal((B * N, P)) * 0.3).astype(np.float32)
+    sem[:, 4] += 6.0
+    off = (0.001 * rng.standard_normal((B * N, 3))).astype(np.float32)
+    bidx = np.repeat(np.arange(B), N).astype(np.int64)
+    par = (rng.standard_normal((B, N, 22)) * 0.01).astype(np.float32)
+    feat = (np.eye(E, dtype=np.float32)[which % E] + 0.01 * rng.standard_normal((B, N, E))).astype(np.float32)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    common = dict(radius=0.03, similarity_threshold_inst=0.9, similarity_threshold_para=0.0, mean_active=60, min_npoint=50)
+    pi, po = forward_grouping_device(t(sem), t(off), t(bidx), t(xyz.reshape(-1, 3)), torch.zeros(B, N, P), t(par), t(feat),
+                                     semantic_classes=P, training_mode="test", using_set_aggr=True, **common)
+    rpi, rpo = _oracle_forward_grouping(sem, off, bidx, xyz.reshape(-1, 3), B, N, par, feat, P, 0.03, 0.9, 0.0, 60, 50,
+                                        mode="test", set_aggr=True)
+    plain_pi, plain_po = _oracle_forward_grouping(sem, off, bidx, xyz.reshape(-1, 3), B, N, par, feat, P, 0.03, 0.9, 0.0, 60, 50)
+    assert rpi.shape[0] > plain_pi.shape[0] + 3000, "the scene must really absorb fragments (and hit the point cap)"
     np.testing.assert_array_equal(po.numpy(), rpo)
     np.testing.assert_array_equal(pi.numpy(), rpi)
 
