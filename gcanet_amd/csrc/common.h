@@ -192,4 +192,51 @@ inline hipError_t zero_spans(hipStream_t st, ZeroSpan a, ZeroSpan b = {nullptr, 
   return hipSuccess;
 }
 
+
+// Fold per-workgroup partial sums in a FIXED order (deterministic, no same-address atomics):
+//   part_c (K, 2C) f32 -> out_a[0..C) = column sums of the first C columns, out_b[0..C) of the last C   (K = B * nblk)
+//   part_s (B, nblk, 2G) f64 -> S (B, 2G)
+// Workgroup = 64 outputs x 4 waves, each wave walks a quarter of the partials sixteen loads at a time; the four
+// quarter sums meet in LDS.  grid = cdiv(2C, 64) + cdiv(B*2G, 64).
+static __global__ __launch_bounds__(256) void fold_partials_kernel(const double *__restrict__ part_s, const float *__restrict__ part_c,
+                                                                   int nblk, int B, int C, int G, double *__restrict__ S,
+                                                                   float *__restrict__ out_a, float *__restrict__ out_b) {
+  __shared__ double red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cblocks = (2 * C + 63) / 64;
+  if ((int)blockIdx.x < cblocks) {
+    const int t = blockIdx.x * 64 + lane;
+    const long K = (long)B * nblk;
+    const long k0 = K * wave / 4, k1 = K * (wave + 1) / 4;
+    float acc = 0.f;
+    if (t < 2 * C) {
+      long k = k0;
+      for (; k + 16 <= k1; k += 16) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = part_c[(k + u) * 2 * C + t];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc += v[u];
+      }
+      for (; k < k1; ++k) acc += part_c[k * 2 * C + t];
+    }
+    red[wave][lane] = (double)acc;
+    __syncthreads();
+    if (wave == 0 && t < 2 * C) {
+      const float r = (((float)red[0][lane] + (float)red[1][lane]) + (float)red[2][lane]) + (float)red[3][lane];
+      if (t < C) out_a[t] = r; else out_b[t - C] = r;
+    }
+  } else {
+    const int i = ((int)blockIdx.x - cblocks) * 64 + lane;        // (b, j) pair
+    const int b = i / (2 * G), j = i % (2 * G);
+    const int k0 = nblk * wave / 4, k1 = nblk * (wave + 1) / 4;
+    double acc = 0.0;
+    if (i < B * 2 * G)
+      for (int k = k0; k < k1; ++k) acc += part_s[((long)b * nblk + k) * 2 * G + j];
+    red[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && i < B * 2 * G) S[(long)b * 2 * G + j] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+  }
+}
+
 }  // namespace gcn

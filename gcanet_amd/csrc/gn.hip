@@ -12,6 +12,8 @@
 // dtype 0 = f32, 1 = bf16 (statistics and arithmetic always in f32).
 #include "common.h"
 
+#include <type_traits>
+
 namespace gcn {
 
 __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned int)h) << 16); }
@@ -72,12 +74,12 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const void *__restrict__ 
     float a1 = 0.f, a2 = 0.f;
     // four rows in flight per thread (8-byte loads: one row at a time leaves the memory system idle -- 3 TB/s)
     int r = r0 + s.row0;
-    for (; r + 3 * s.rstep < r1; r += 4 * s.rstep) {
-      float v[4][4];
+    for (; r + 7 * s.rstep < r1; r += 8 * s.rstep) {
+      float v[8][4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) load4<BF16>(x, ((long)b * N + r + u * s.rstep) * C + c, v[u]);
+      for (int u = 0; u < 8; ++u) load4<BF16>(x, ((long)b * N + r + u * s.rstep) * C + c, v[u]);
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < 8; ++u)
 #pragma unroll
         for (int i = 0; i < 4; ++i) { a1 += v[u][i]; a2 = fmaf(v[u][i], v[u][i], a2); }
     }
@@ -100,20 +102,60 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const void *__restrict__ 
                                                        const float *__restrict__ gamma, const float *__restrict__ beta,
                                                        int N, int C, int G, float eps, int relu, void *__restrict__ y,
                                                        float *__restrict__ mean_rstd) {
+  // mean / rstd of the sample's groups once per workgroup (the f64 divide + sqrt per 4 elements made this kernel
+  // arithmetic-bound), then 16 bytes per lane and iteration
+  __shared__ float mean_s[64], rstd_s[64];
   const int b = blockIdx.y;
-  const long per = (long)N * C / 4;
   const int cpg = C / G;
   const double cnt = (double)cpg * N;
-  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < per; e += (long)gridDim.x * 256) {
-    const int c = (int)((e * 4) % C);
-    const int g = c / cpg;
+  for (int g = threadIdx.x; g < G; g += 256) {
     const double m = gsum[((long)b * G + g) * 2] / cnt;
     double var = gsum[((long)b * G + g) * 2 + 1] / cnt - m * m;
     if (var < 0.0) var = 0.0;
     const float mean = (float)m, rstd = (float)(1.0 / sqrt(var + (double)eps));
-    if (mean_rstd && e * 4 < C && (c % cpg) == 0) {
+    if (g < 64) { mean_s[g] = mean; rstd_s[g] = rstd; }
+    if (mean_rstd && blockIdx.x == 0) {
       mean_rstd[((long)b * G + g) * 2] = mean;
       mean_rstd[((long)b * G + g) * 2 + 1] = rstd;
+    }
+  }
+  __syncthreads();
+  constexpr int V = BF16 ? 8 : 4;                              // elements per lane and iteration
+  const bool wide = (C % V) == 0 && (cpg % V) == 0 && G <= 64;
+  if (wide) {
+    const long per = (long)N * C / V;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < per; e += (long)gridDim.x * 256) {
+      const int c = (int)((e * V) % C);
+      const int g = c / cpg;
+      const float mean = mean_s[g], rstd = rstd_s[g];
+#pragma unroll
+      for (int h = 0; h < V / 4; ++h) {
+        float v[4];
+        load4<BF16>(x, (long)b * N * C + e * V + 4 * h, v);
+        const float4 ga = *reinterpret_cast<const float4 *>(gamma + c + 4 * h);
+        const float4 be = *reinterpret_cast<const float4 *>(beta + c + 4 * h);
+        const float gg[4] = {ga.x, ga.y, ga.z, ga.w}, bb[4] = {be.x, be.y, be.z, be.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float z = (v[i] - mean) * rstd * gg[i] + bb[i];
+          v[i] = (relu && !(z > 0.f)) ? 0.f : z;
+        }
+        store4<BF16>(y, (long)b * N * C + e * V + 4 * h, v);
+      }
+    }
+    return;
+  }
+  const long per = (long)N * C / 4;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < per; e += (long)gridDim.x * 256) {
+    const int c = (int)((e * 4) % C);
+    const int g = c / cpg;
+    float mean, rstd;
+    if (G <= 64) { mean = mean_s[g]; rstd = rstd_s[g]; }
+    else {
+      const double m = gsum[((long)b * G + g) * 2] / cnt;
+      double var = gsum[((long)b * G + g) * 2 + 1] / cnt - m * m;
+      if (var < 0.0) var = 0.0;
+      mean = (float)m; rstd = (float)(1.0 / sqrt(var + (double)eps));
     }
     float v[4];
     load4<BF16>(x, (long)b * N * C + e * 4, v);
@@ -209,8 +251,8 @@ template <bool BF16>
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const void *__restrict__ dy, const void *__restrict__ x,
                                                             const float *__restrict__ gamma, const float *__restrict__ beta,
                                                             const float *__restrict__ mean_rstd, int N, int C, int G,
-                                                            int relu, int rows_per_block, double *__restrict__ S,
-                                                            float *__restrict__ dgamma, float *__restrict__ dbeta) {
+                                                            int relu, int rows_per_block, double *__restrict__ part_s,
+                                                            float *__restrict__ part_c) {
   extern __shared__ double sm[];
   for (int i = threadIdx.x; i < 2 * G; i += 256) sm[i] = 0.0;
   {
@@ -244,16 +286,16 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const void *__restri
       }
     };
     int r = r0 + s.row0;
-    for (; r + 3 * s.rstep < r1; r += 4 * s.rstep) {           // four rows (eight loads) in flight per thread
-      float xv[4][4], gv[4][4];
+    for (; r + 7 * s.rstep < r1; r += 8 * s.rstep) {           // eight rows (sixteen loads) in flight per thread
+      float xv[8][4], gv[8][4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 8; ++u) {
         const long o = ((long)b * N + r + u * s.rstep) * C + c;
         load4<BF16>(x, o, xv[u]);
         load4<BF16>(dy, o, gv[u]);
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) accum(xv[u], gv[u]);
+      for (int u = 0; u < 8; ++u) accum(xv[u], gv[u]);
     }
     for (; r < r1; r += s.rstep) {
       float xv[4], gv[4];
@@ -274,15 +316,16 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const void *__restri
     atomicAdd(&sm[g * 2 + 1], (double)s2);
   }
   __syncthreads();
-  if ((int)threadIdx.x < 2 * G) atomicAdd(S + (long)b * G * 2 + threadIdx.x, sm[threadIdx.x]);
+  // per-workgroup partials, folded by fold_partials_kernel (common.h): 512 workgroups adding to the same 2C + 2G addresses
+  // cost ~25 us of contention per launch, whatever the tensor size (and made the sums order-dependent)
+  const long blk = (long)b * gridDim.x + blockIdx.x;
+  if ((int)threadIdx.x < 2 * G) part_s[blk * 2 * G + threadIdx.x] = sm[threadIdx.x];
   {
     const float *cs = reinterpret_cast<const float *>(sm + 2 * G);
-    for (int i = threadIdx.x; i < C; i += 256) {
-      atomicAdd(dgamma + i, cs[i]);
-      atomicAdd(dbeta + i, cs[C + i]);
-    }
+    for (int i = threadIdx.x; i < 2 * C; i += 256) part_c[blk * 2 * C + i] = cs[i];
   }
 }
+
 
 // backward pass 2: dx = rstd * (gamma*g - S1/M - xhat*S2/M)
 template <bool BF16>
@@ -291,29 +334,43 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const void *__restric
                                                            const float *__restrict__ mean_rstd, const double *__restrict__ S,
                                                            int N, int C, int G, int relu, void *__restrict__ dx) {
   const int b = blockIdx.y;
-  const long per = (long)N * C / 4;
   const int cpg = C / G;
   const float invM = 1.f / ((float)cpg * (float)N);
-  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < per; e += (long)gridDim.x * 256) {
-    const int c = (int)((e * 4) % C);
-    const int g = c / cpg;
-    const float mean = mean_rstd[((long)b * G + g) * 2], rstd = mean_rstd[((long)b * G + g) * 2 + 1];
-    const float m1 = (float)S[((long)b * G + g) * 2] * invM, m2 = (float)S[((long)b * G + g) * 2 + 1] * invM;
-    const float4 ga = *reinterpret_cast<const float4 *>(gamma + c);
-    const float4 be = *reinterpret_cast<const float4 *>(beta + c);
-    const float gg[4] = {ga.x, ga.y, ga.z, ga.w}, bb[4] = {be.x, be.y, be.z, be.w};
-    float xv[4], gv[4], o[4];
-    load4<BF16>(x, (long)b * N * C + e * 4, xv);
-    load4<BF16>(dy, (long)b * N * C + e * 4, gv);
+  constexpr int V = BF16 ? 8 : 4;                              // 16 bytes per lane and iteration
+  const bool wide = (C % V) == 0 && (cpg % V) == 0;
+  auto body = [&](auto wc) {
+    constexpr int W = decltype(wc)::value;
+    const long per = (long)N * C / W;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < per; e += (long)gridDim.x * 256) {
+      const int c = (int)((e * W) % C);
+      const int g = c / cpg;
+      const float mean = mean_rstd[((long)b * G + g) * 2], rstd = mean_rstd[((long)b * G + g) * 2 + 1];
+      const float m1 = (float)S[((long)b * G + g) * 2] * invM, m2 = (float)S[((long)b * G + g) * 2 + 1] * invM;
+      float xv[W / 4][4], gv[W / 4][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float xh = (xv[i] - mean) * rstd;
-      const float z = xh * gg[i] + bb[i];
-      const float gz = (relu && !(z > 0.f)) ? 0.f : gv[i];
-      o[i] = rstd * (gg[i] * gz - m1 - xh * m2);
+      for (int h = 0; h < W / 4; ++h) {
+        load4<BF16>(x, (long)b * N * C + e * W + 4 * h, xv[h]);
+        load4<BF16>(dy, (long)b * N * C + e * W + 4 * h, gv[h]);
+      }
+#pragma unroll
+      for (int h = 0; h < W / 4; ++h) {
+        const float4 ga = *reinterpret_cast<const float4 *>(gamma + c + 4 * h);
+        const float4 be = *reinterpret_cast<const float4 *>(beta + c + 4 * h);
+        const float gg[4] = {ga.x, ga.y, ga.z, ga.w}, bb[4] = {be.x, be.y, be.z, be.w};
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float xh = (xv[h][i] - mean) * rstd;
+          const float z = xh * gg[i] + bb[i];
+          const float gz = (relu && !(z > 0.f)) ? 0.f : gv[h][i];
+          o[i] = rstd * (gg[i] * gz - m1 - xh * m2);
+        }
+        store4<BF16>(dx, (long)b * N * C + e * W + 4 * h, o);
+      }
     }
-    store4<BF16>(dx, (long)b * N * C + e * 4, o);
-  }
+  };
+  if (wide) body(std::integral_constant<int, V>{});
+  else body(std::integral_constant<int, 4>{});
 }
 
 // ---------------------------------------------------------------- backward of  max_n [ReLU](GroupNorm(x))
@@ -498,6 +555,12 @@ GCN_EXPORT int gcn_gn_apply(const void *x, int dtype, const double *gsum, const 
   return check_launch("gn_apply_kernel");
 }
 
+GCN_EXPORT long gcn_gn_bwd_ws_bytes(int B, int N, int C, int G) {
+  if (B < 0 || N < 1 || C < 1 || G < 1) return -1;
+  const long nblk = cdiv(N, slab_rows(N, B > 0 ? B : 1));
+  return 8L * (2L * B * G) * (1 + nblk) + 4L * 2 * C * B * nblk;
+}
+
 GCN_EXPORT int gcn_gn_bwd(const void *dy, const void *x, int dtype, const float *gamma, const float *beta,
                           const float *mean_rstd, int B, int N, int C, int G, int relu, void *dx, float *dgamma,
                           float *dbeta, double *s_ws, void *stream) {
@@ -506,16 +569,22 @@ GCN_EXPORT int gcn_gn_bwd(const void *dy, const void *x, int dtype, const float 
   GCN_REQUIRE(dy && x && gamma && beta && mean_rstd && dx && dgamma && dbeta && s_ws, "gcn_gn_bwd: null pointer");
   hipStream_t st = (hipStream_t)stream;
   if (B == 0) { GCN_HIP(zero_spans(st, {dgamma, sizeof(float) * C}, {dbeta, sizeof(float) * C})); return GCN_OK; }
-  GCN_HIP(zero_spans(st, {dgamma, sizeof(float) * C}, {dbeta, sizeof(float) * C}, {s_ws, sizeof(double) * 2 * B * G}));
+  GCN_REQUIRE(((uintptr_t)s_ws & 7) == 0, "gcn_gn_bwd: s_ws must be 8-byte aligned");
   const int rows = slab_rows(N, B);
-  const dim3 g1(cdiv(N, rows), B);
+  const int nblk = cdiv(N, rows);
+  double *S = s_ws;                                             // (B,G,2), then the per-workgroup partials
+  double *part_s = S + 2L * B * G;
+  float *part_c = reinterpret_cast<float *>(part_s + 2L * G * B * nblk);
+  const dim3 g1(nblk, B);
   const int g2 = (int)(((long)N * C / 4 + 255) / 256 > 2048 ? 2048 : ((long)N * C / 4 + 255) / 256);
   if (dtype == 1) {
-    gn_bwd_reduce_kernel<true><<<g1, 256, sizeof(double) * 2 * G + sizeof(float) * 2 * C, st>>>(dy, x, gamma, beta, mean_rstd, N, C, G, relu, rows, s_ws, dgamma, dbeta);
-    gn_bwd_apply_kernel<true><<<dim3(g2, B), 256, 0, st>>>(dy, x, gamma, beta, mean_rstd, s_ws, N, C, G, relu, dx);
+    gn_bwd_reduce_kernel<true><<<g1, 256, sizeof(double) * 2 * G + sizeof(float) * 2 * C, st>>>(dy, x, gamma, beta, mean_rstd, N, C, G, relu, rows, part_s, part_c);
+    fold_partials_kernel<<<cdiv(2 * C, 64) + cdiv(B * 2 * G, 64), 256, 0, st>>>(part_s, part_c, nblk, B, C, G, S, dgamma, dbeta);
+    gn_bwd_apply_kernel<true><<<dim3(g2, B), 256, 0, st>>>(dy, x, gamma, beta, mean_rstd, S, N, C, G, relu, dx);
   } else {
-    gn_bwd_reduce_kernel<false><<<g1, 256, sizeof(double) * 2 * G + sizeof(float) * 2 * C, st>>>(dy, x, gamma, beta, mean_rstd, N, C, G, relu, rows, s_ws, dgamma, dbeta);
-    gn_bwd_apply_kernel<false><<<dim3(g2, B), 256, 0, st>>>(dy, x, gamma, beta, mean_rstd, s_ws, N, C, G, relu, dx);
+    gn_bwd_reduce_kernel<false><<<g1, 256, sizeof(double) * 2 * G + sizeof(float) * 2 * C, st>>>(dy, x, gamma, beta, mean_rstd, N, C, G, relu, rows, part_s, part_c);
+    fold_partials_kernel<<<cdiv(2 * C, 64) + cdiv(B * 2 * G, 64), 256, 0, st>>>(part_s, part_c, nblk, B, C, G, S, dgamma, dbeta);
+    gn_bwd_apply_kernel<false><<<dim3(g2, B), 256, 0, st>>>(dy, x, gamma, beta, mean_rstd, S, N, C, G, relu, dx);
   }
   return check_launch("gn_bwd");
 }

@@ -32,7 +32,8 @@ __global__ __launch_bounds__(256) void route_bwd_kernel(const float *__restrict_
                                                         int64_t *__restrict__ jsel, int64_t *__restrict__ msel,
                                                         float *__restrict__ dsp, float *__restrict__ dgamma,
                                                         float *__restrict__ dbeta, double *__restrict__ S,
-                                                        DspBuckets bk) {
+                                                        DspBuckets bk, double *__restrict__ part_s,
+                                                        float *__restrict__ part_c) {
   extern __shared__ double sm[];             // 2*G doubles, then 2*Cout floats
   __shared__ float amax_s[4];
   __shared__ int bcnt[64];                   // entries this workgroup has filed per destination partition
@@ -106,12 +107,21 @@ __global__ __launch_bounds__(256) void route_bwd_kernel(const float *__restrict_
       atomicMax(bk.absmax, __float_as_uint(fmaxf(fmaxf(amax_s[0], amax_s[1]), fmaxf(amax_s[2], amax_s[3]))));
     if ((int)threadIdx.x < bk.P) bk.counts[((long)b * bk.P + threadIdx.x) * gridDim.x + tile] = min(bcnt[threadIdx.x], DSP_CAP);
   }
+  if (part_s) {
+    // per-workgroup partials, folded by fold_partials_kernel (common.h; 512 workgroups adding to the same 2 Cout + 2 G addresses
+    // cost ~25 us of contention per launch and made the sums order-dependent)
+    const long blk = (long)b * gridDim.x + tile;
+    if ((int)threadIdx.x < 2 * G) part_s[blk * 2 * G + threadIdx.x] = sm[threadIdx.x];
+    for (int i = threadIdx.x; i < 2 * Cout; i += 256) part_c[blk * 2 * Cout + i] = cs[i];
+    return;
+  }
   if ((int)threadIdx.x < 2 * G) atomicAdd(S + (long)b * G * 2 + threadIdx.x, sm[threadIdx.x]);
   for (int i = threadIdx.x; i < Cout; i += 256) {
     atomicAdd(dgamma + i, cs[i]);
     atomicAdd(dbeta + i, cs[Cout + i]);
   }
 }
+
 
 // Dsp[m,c] = sum over the points n whose selected neighbour for channel c is m of coef[n,c] -- the sparse part of the
 // EdgeConv input gradient.  As 8.4 M scattered global f32 atomics (one per (n,c), every one to a different line) it
@@ -390,6 +400,15 @@ static DspWs dsp_ws_layout(int B, int N, int Cout, int tiles) {
 
 using namespace gcn;
 
+GCN_EXPORT long gcn_route_bwd_part_bytes(int B, int N, int Cout, int G) {
+  if (B < 0 || N < 1 || Cout < 1 || G < 1) return -1;
+  int blocks = (512 + (B > 0 ? B : 1) - 1) / (B > 0 ? B : 1);
+  int rows = (N + blocks - 1) / blocks;
+  if (rows < 8) rows = 8;
+  const long tiles = cdiv(N, rows);
+  return 8L * 2 * G * B * tiles + 4L * 2 * Cout * B * tiles;
+}
+
 GCN_EXPORT long gcn_route_bwd_ws_bytes(int B, int N, int Cout) {
   if (B < 0 || N < 1 || Cout < 1) return -1;
   if (!(Cout == 64 || Cout == 128) || N % (16384 / Cout) != 0) return 256;
@@ -403,7 +422,7 @@ GCN_EXPORT int gcn_route_bwd(const float *dout_pm, const float *ymax, const floa
                              const uint8_t *amin, const float *gamma, const float *beta, const float *mean_rstd,
                              const int64_t *idx, int B, int N, int k, int Cout, int G, float slope, float *coef,
                              int64_t *jsel, int64_t *msel, float *dsp, float *dgamma, float *dbeta, double *S,
-                             double count_per_group, float *Ac, float *Bc, void *dsp_ws, void *stream) {
+                             double count_per_group, float *Ac, float *Bc, void *dsp_ws, void *part_ws, void *stream) {
   GCN_REQUIRE(dout_pm && ymax && amax && gamma && beta && mean_rstd && coef && dgamma && dbeta && S,
               "gcn_route_bwd: null pointer");
   GCN_REQUIRE(B >= 0 && N >= 1 && Cout >= 1 && G >= 1 && Cout % G == 0, "gcn_route_bwd: bad shape");
@@ -435,13 +454,26 @@ GCN_EXPORT int gcn_route_bwd(const float *dout_pm, const float *ymax, const floa
     bk.P = N / (16384 / Cout);
     bk.rshift = Cout == 64 ? 8 : 7;
   }
-  GCN_HIP(zero_spans(st, {dgamma, sizeof(float) * Cout}, {dbeta, sizeof(float) * Cout}, {S, sizeof(double) * 2 * B * G},
-                     {lds_scatter ? dsp_ws : nullptr, lds_scatter ? 256u : 0u}));
+  double *part_s = nullptr;
+  float *part_c = nullptr;
+  if (part_ws) {                              // gcn_route_bwd_part_bytes: the sums are written, nothing to zero
+    GCN_REQUIRE(((uintptr_t)part_ws & 7) == 0, "gcn_route_bwd: part_ws must be 8-byte aligned");
+    part_s = (double *)part_ws;
+    part_c = (float *)(part_s + 2L * G * B * tiles);
+    GCN_HIP(zero_spans(st, {lds_scatter ? dsp_ws : nullptr, lds_scatter ? 256u : 0u}));
+  } else {
+    GCN_HIP(zero_spans(st, {dgamma, sizeof(float) * Cout}, {dbeta, sizeof(float) * Cout}, {S, sizeof(double) * 2 * B * G},
+                       {lds_scatter ? dsp_ws : nullptr, lds_scatter ? 256u : 0u}));
+  }
   if (dsp && !lds_scatter) GCN_HIP(zero_dev(dsp, sizeof(float) * (size_t)B * N * Cout, st));
   route_bwd_kernel<<<dim3(cdiv(N, rows), B), 256, sizeof(double) * 2 * G + sizeof(float) * 2 * Cout, st>>>(
       dout_pm, ymax, ymin, amax, amin, gamma, beta, mean_rstd, idx, N, k, Cout, G, slope, rows, coef, jsel, msel, dsp,
-      dgamma, dbeta, S, bk);
+      dgamma, dbeta, S, bk, part_s, part_c);
   int rc = check_launch("route_bwd_kernel");
+  if (!rc && part_ws) {
+    fold_partials_kernel<<<cdiv(2 * Cout, 64) + cdiv(B * 2 * G, 64), 256, 0, st>>>(part_s, part_c, tiles, B, Cout, G, S, dgamma, dbeta);
+    rc = check_launch("fold_partials_kernel");
+  }
   if (!rc && lds_scatter) {
     const int ldsb = 16384 * 8;
     if (Cout == 64) {

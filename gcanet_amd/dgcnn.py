@@ -420,10 +420,11 @@ def _route_backward_fused(dout_pm, gamma, beta, ymax, ymin, amax, amin, mean_rst
     amin = amin if (amin is not None and amin.numel()) else None
     Ac = torch.empty(B, Cout, dtype=torch.float32, device=dev)
     Bc = torch.empty(B, Cout, dtype=torch.float32, device=dev)
+    part_ws = torch.empty(_lib.lib().gcn_route_bwd_part_bytes(B, N, Cout, G), dtype=torch.uint8, device=dev)
     _run("gcn_route_bwd", ymax, _lib.ptr(dout_pm), _lib.ptr(ymax), _lib.ptr(ymin), _lib.ptr(amax), _lib.ptr(amin),
          _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(mean_rstd), _lib.ptr(idx), B, N, k, Cout, G, float(slope),
          _lib.ptr(coef), _lib.ptr(jsel), None, _lib.ptr(dsp), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(S),
-         float(count_per_group), _lib.ptr(Ac), _lib.ptr(Bc), _lib.ptr(dsp_ws))
+         float(count_per_group), _lib.ptr(Ac), _lib.ptr(Bc), _lib.ptr(dsp_ws), _lib.ptr(part_ws))
     return jsel, coef, Ac, Bc, dgamma, dbeta, dsp
 
 

@@ -115,7 +115,9 @@ class GroupNormReLUFunction(torch.autograd.Function):
         B, N, C = x.shape
         dy = dy.to(x.dtype).contiguous()
         dx = torch.empty_like(x)
-        ws, dgamma, dbeta = _acc_buffers(B * groups * 2, C, x.device)
+        dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+        ws = torch.empty(_lib.lib().gcn_gn_bwd_ws_bytes(B, N, C, groups), dtype=torch.uint8, device=x.device)
         _run("gcn_gn_bwd", x, _lib.ptr(dy), _lib.ptr(x), dt, _lib.ptr(ga), _lib.ptr(be), _lib.ptr(mean_rstd), B, N, C,
              groups, int(relu), _lib.ptr(dx), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ws))
         return dx, dgamma, dbeta, None, None, None, None

@@ -437,13 +437,17 @@ int gcn_topk_rows(const void *x, int dtype, long R, int NK, int k, float *vals, 
  * dsp_ws: NULL, or gcn_route_bwd_ws_bytes(B,N,Cout) bytes of scratch (16-byte aligned; its first 4 bytes are zeroed by
  * the call -- place it right behind dbeta and the fill merges with the other accumulators').  With it, and Cout in
  * {64,128}, N <= 65536, N*Cout % 65536 == 0, dsp is built by a destination-partitioned LDS scatter in 64-bit fixed
- * point (bitwise reproducible, every element written, no zero fill) instead of B*N*Cout global f32 atomics. */
+ * point (bitwise reproducible, every element written, no zero fill) instead of B*N*Cout global f32 atomics.
+ * part_ws: NULL (dgamma/dbeta/S are zeroed and accumulated with atomics), or gcn_route_bwd_part_bytes(B,N,Cout,G) bytes
+ * of 8-byte aligned scratch: workgroups write partial sums there and a second small kernel folds them in a fixed order
+ * (no contention on the few shared addresses: ~25 us per launch; dgamma/dbeta/S are then written, not accumulated). */
+long gcn_route_bwd_part_bytes(int B, int N, int Cout, int G);
 long gcn_route_bwd_ws_bytes(int B, int N, int Cout);
 int gcn_route_bwd(const float *dout_pm, const float *ymax, const float *ymin, const uint8_t *amax,
                   const uint8_t *amin, const float *gamma, const float *beta, const float *mean_rstd,
                   const int64_t *idx, int B, int N, int k, int Cout, int G, float slope, float *coef,
                   int64_t *jsel, int64_t *msel, float *dsp, float *dgamma, float *dbeta, double *S,
-                  double count_per_group, float *Ac, float *Bc, void *dsp_ws, void *stream);
+                  double count_per_group, float *Ac, float *Bc, void *dsp_ws, void *part_ws, void *stream);
 
 /* Weight gradient of the fused EdgeConv block from the pieces above, all row reductions in one pass on the
  * f32 matrix cores:  dW (Cout,2C) = [dW1 - dWd | dWd] with dWd = D2^T x and
@@ -471,8 +475,10 @@ int gcn_edge_combine(const float *coef, const float *dsp, const float *indeg, co
 int gcn_gn_fwd(const void *x, int dtype, const float *gamma, const float *beta, int B, int N, int C,
                int G, float eps, int relu, void *y, float *mean_rstd, double *gsum_ws, void *stream);
 
-/* Backward of the above: dx (same dtype as x), dgamma/dbeta (C) f32 (zeroed by the call),
- * s_ws (B,G,2) f64 workspace. */
+/* Backward of the above: dx (same dtype as x), dgamma/dbeta (C) f32 (written),
+ * s_ws: gcn_gn_bwd_ws_bytes(B,N,C,G) bytes of scratch, 8-byte aligned (the (B,G,2) f64 sums, then per-workgroup
+ * partials that a second small kernel folds in a fixed order: no same-address atomics, deterministic, no zero fill). */
+long gcn_gn_bwd_ws_bytes(int B, int N, int C, int G);
 int gcn_gn_bwd(const void *dy, const void *x, int dtype, const float *gamma, const float *beta,
                const float *mean_rstd, int B, int N, int C, int G, int relu, void *dx, float *dgamma,
                float *dbeta, double *s_ws, void *stream);

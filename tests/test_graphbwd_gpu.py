@@ -194,6 +194,7 @@ def test_route_bwd_lds_scatter_matches_definition(dev, B, N, k, Cout, kind):
         coef = torch.empty(B, N, Cout, device=dev)
         dsp = torch.full((B, N, Cout), float("nan"), device=dev)
         Ac, Bc = torch.empty(B, Cout, device=dev), torch.empty(B, Cout, device=dev)
+        part = torch.empty(_lib.lib().gcn_route_bwd_part_bytes(B, N, Cout, G), dtype=torch.uint8, device=dev)
         if with_ws:
             S, dg, db, ws = _acc_buffers(B * G * 2, Cout, dev, tail_bytes=_lib.lib().gcn_route_bwd_ws_bytes(B, N, Cout))
         else:
@@ -201,7 +202,7 @@ def test_route_bwd_lds_scatter_matches_definition(dev, B, N, k, Cout, kind):
         _lib.call("gcn_route_bwd", _lib.ptr(dout), _lib.ptr(ymax), None, _lib.ptr(amax), None, _lib.ptr(gamma), _lib.ptr(beta),
                   _lib.ptr(mean_rstd), _lib.ptr(idx), B, N, k, Cout, G, 0.2, _lib.ptr(coef), None, None, _lib.ptr(dsp),
                   _lib.ptr(dg), _lib.ptr(db), _lib.ptr(S), float((Cout // G) * N * k), _lib.ptr(Ac), _lib.ptr(Bc),
-                  _lib.ptr(ws), _lib.stream_of(dout))
+                  _lib.ptr(ws), _lib.ptr(part) if with_ws else None, _lib.stream_of(dout))
         return coef, dsp, dg.clone(), db.clone(), S.clone()
 
     coef1, dsp1, dg1, db1, S1 = run(True)
