@@ -91,6 +91,16 @@ def _run(name, like, *args, tag=None):
         _lib.call(name, *args, _lib.stream_of(like), tag=tag)
 
 
+def _edgeconv_dtype(dtype, C, Cout, groups):
+    """The kernel that serves this layer: the bf16 matrix-core kernel needs Cout in {64,128}, (Cout/groups) % 32 == 0 and
+    at most 128 (padded) input channels; any other width (M4:493-505 takes arbitrary channels) runs on the exact f32
+    kernel -- same op, same signature, no error."""
+    if dtype == "bf16" and not (Cout in (64, 128) and (Cout // groups) % 32 == 0 and Cout % groups == 0
+                                and _lib.lib().gcn_edgeconv_padded_channels(C) <= 128):
+        return "f32"
+    return dtype
+
+
 def _center_term(x_bf, wp, rows, C, Cout, k):
     """q (rows, Cout) f32 = x . (W2 - W1)^T, the per-point half of the EdgeConv contraction (csrc/edgeconv_fwd.hip);
     None for k > 128, where the kernel contracts full [x_j ; x_i] rows."""
@@ -122,6 +132,7 @@ def edgeconv_forward_raw(x, idx, weight, gamma, beta, groups, dtype="bf16", eps=
         amin = torch.empty(B, N, Cout, dtype=torch.uint8, device=dev)
     gsum = _zeroed_like((B, groups, 2), torch.float64, dev)
     x_pm = torch.empty(B, N, C, **f32)
+    dtype = _edgeconv_dtype(dtype, C, Cout, groups)
     if dtype == "bf16":
         Cp = _lib.lib().gcn_edgeconv_padded_channels(C)
         x_bf = torch.empty(B, N, Cp, dtype=torch.bfloat16, device=dev)
@@ -296,6 +307,7 @@ class GroupedBlockFunction(torch.autograd.Function):
         amin = torch.empty(B, N, Cout, dtype=torch.uint8, device=dev)
         gsum = _zeroed_like((B, groups, 2), torch.float64, dev)
         # N "points" whose k neighbours are rows n*k..n*k+k-1 of the edge-row "cloud"
+        dtype = _edgeconv_dtype(dtype, F, Cout, groups)
         if dtype == "bf16":
             Fp = _lib.lib().gcn_edgeconv_padded_channels(F)
             x_bf = torch.empty(B, N * k, Fp, dtype=torch.bfloat16, device=dev)
@@ -406,6 +418,18 @@ def _route_backward_fused(dout_pm, gamma, beta, ymax, ymin, amax, amin, mean_rst
     k = idx.shape[2] if idx is not None else 1
     cpg = Cout // G
     dout_pm = dout_pm.float().contiguous()
+    if not ((Cout <= 256 and 256 % Cout == 0) or Cout % 256 == 0):
+        # widths the fused kernel's thread mapping does not cover (it wants Cout | 256 or 256 | Cout): the same
+        # quantities in torch ops -- arbitrary channel counts stay usable, only slower
+        ymin_t = ymin if (ymin is not None and ymin.numel()) else ymax
+        amin_t = amin if (amin is not None and amin.numel()) else amax
+        jsel, coef, Ac, Bc, dgamma, dbeta = _gn_route_backward(dout_pm, gamma, beta, ymax, ymin_t, amax, amin_t, mean_rstd,
+                                                               G, slope, count_per_group, pm=True)
+        dsp = None
+        if want_dsp:
+            msel = torch.gather(idx, 2, jsel)
+            dsp = torch.zeros(B, N, Cout, dtype=torch.float32, device=dev).scatter_add_(1, msel, coef)
+        return (jsel if want_jsel else None), coef.contiguous(), Ac.contiguous(), Bc.contiguous(), dgamma, dbeta, dsp
     coef = torch.empty(B, N, Cout, dtype=torch.float32, device=dev)
     jsel = torch.empty(B, N, Cout, dtype=torch.int64, device=dev) if want_jsel else None
     dsp = torch.empty(B, N, Cout, dtype=torch.float32, device=dev) if want_dsp else None
@@ -857,6 +881,7 @@ class EdgeConvPMFunction(torch.autograd.Function):
         amax = torch.empty(B, N, Cout, dtype=torch.uint8, device=dev)
         ymin = amin = None
         gsum = _zeroed_like((B, groups, 2), torch.float64, dev)
+        dtype = _edgeconv_dtype(dtype, C, Cout, groups)
         if dtype == "bf16":
             Cp = _lib.lib().gcn_edgeconv_padded_channels(C)
             x_bf = torch.empty(B, N, Cp, dtype=torch.bfloat16, device=dev)

@@ -147,3 +147,28 @@ def test_graph_feature_functions_match_golden(dev, golden):
     xp, ip = t(golden["knnpn_rand_x"]), t(golden["knnpn_rand_idx_k16"])
     np.testing.assert_array_equal(dgcnn.get_graph_feature_with_normals(xp, idx=ip).cpu().numpy(), golden["ggfn_out"])
     np.testing.assert_allclose(dgcnn.get_graph_feature_with_normals_g(xp, idx=ip).cpu().numpy(), golden["ggfng_out"], rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("C,Cout,G", [(6, 96, 2), (20, 48, 3), (64, 256, 2), (160, 64, 2)])
+def test_edge_conv_any_width_routes_to_the_exact_kernel(dev, C, Cout, G):
+    """M4:493-505 takes arbitrary channel counts; widths the bf16 matrix-core kernel does not serve (Cout not in
+    {64,128}, Cout/G % 32 != 0, C > 128) run on the exact f32 kernel behind the same `edge_conv(..., dtype="bf16")`
+    call: forward and gradients vs the oracle at 1e-4."""
+    from gcanet_amd import dgcnn
+    g = torch.Generator().manual_seed(C * 7 + Cout)
+    B, N, k = 2, 200, 12
+    x = torch.randn(B, C, N, generator=g)
+    idx = torch.stack([torch.stack([torch.randperm(N, generator=g)[:k] for _ in range(N)]) for _ in range(B)])
+    w = torch.randn(Cout, 2 * C, generator=g) / (2 * C) ** 0.5
+    ga, be = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+    xd, wd, gd, bd = (t.clone().to(dev).requires_grad_(True) for t in (x, w, ga, be))
+    out = dgcnn.edge_conv(xd, idx.to(dev), wd, gd, bd, groups=G, dtype="bf16")
+    go = torch.randn(B, Cout, N, generator=g)
+    out.backward(go.to(dev))
+    xr, wr, gr, br = (t.clone().requires_grad_(True) for t in (x, w, ga, be))
+    ref = R.edgeconv_block(xr, idx, wr, gr, br, G)
+    ref.backward(go)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-4, atol=1e-4)
+    for a, b, name in ((xd, xr, "dx"), (wd, wr, "dW"), (gd, gr, "dgamma"), (bd, br, "dbeta")):
+        r = b.grad.numpy()
+        np.testing.assert_allclose(a.grad.cpu().numpy(), r, rtol=1e-3, atol=2e-4 * max(1.0, float(np.abs(r).max())), err_msg=name)
