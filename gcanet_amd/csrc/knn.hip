@@ -860,6 +860,16 @@ GCN_EXPORT int gcn_knn_cuda(const float *ref, const float *query, int B, int dim
   a.o_sb = (long)k * nq;
   a.dist = dist; a.ind = ind;
   hipStream_t st = (hipStream_t)stream;
+  // a 3-D cloud searched against itself at filter-friendly sizes: threshold + filter + re-rank (knn_normal.hip), then the
+  // exhaustive kernel for the few queries it flags
+  if (tile_ws && ref == query && nr == nq && dim == 3 && knn_normal_supported(B, nr, k)) {
+    const unsigned char *flag = nullptr;
+    int rc = run_knn_normal(0, ref, a.ref_sb, a.ref_sd, a.ref_sn, nullptr, B, 3, nr, k, 1, a.o_sb, a.o_sk, a.o_sq, ind, dist,
+                            tile_ws, &flag, st);
+    if (rc) return rc;
+    a.only = flag;
+    return launch_knn<0, 3>(a, B, st);
+  }
   // a 3-D cloud searched against itself: the Morton-tiled kernel (same results, box pruning)
   if (tile_ws && ref == query && nr == nq && dim == 3 && k <= 64 && nr >= 512)
     return run_knn_tiles(ref, a.ref_sb, a.ref_sd, a.ref_sn, nullptr, B, 3, nr, k, 1, 0, a.o_sb, a.o_sk, a.o_sq, ind, dist, tile_ws, st);
@@ -884,7 +894,7 @@ int launch_knn_flagged(const float *x_pm, const float *xx, const unsigned char *
 GCN_EXPORT long gcn_knn_tiles_ws_bytes(int B, int C, int N) {
   if (B < 0 || C < 1 || N < 1) return -1;
   size_t need = tile_ws_layout(nullptr, B, C, N).total;
-  if (C == 6 && knn_normal_supported(B, N, 1)) need = std::max(need, knn_normal_ws_bytes(B, N));
+  if ((C == 6 || C == 3) && knn_normal_supported(B, N, 1)) need = std::max(need, knn_normal_ws_bytes(B, N));
   return (long)need;
 }
 
@@ -916,7 +926,7 @@ GCN_EXPORT int gcn_knn_model(const float *x, int B, int C, int N, int k1, int k2
   // kernel for the few queries it flags
   if (metric == 1 && C == 6 && tile_ws && knn_normal_supported(B, N, k2)) {
     const unsigned char *flag = nullptr;
-    rc = run_knn_normal(x, xx_ws, B, N, k2, step, kout, idx, val, tile_ws, &flag, st);
+    rc = run_knn_normal(1, x, (long)C * N, N, 1, xx_ws, B, C, N, k2, step, (long)N * kout, 1, kout, idx, val, tile_ws, &flag, st);
     if (rc) return rc;
     a.only = flag;
     return launch_knn<2, 6>(a, B, st);

@@ -34,9 +34,17 @@ constexpr int KNNN_STRIDE = 8;
 constexpr int KNNN_PHASE = 3;
 constexpr int KNNN_CS = 8;           // candidate ranges per query block in the filter pass
 
-// oracle/gcanet_oracle.c:model_pd metric 1 (M4:62-75): q = query i, c = candidate j
+// M = 1: oracle/gcanet_oracle.c:model_pd metric 1 (M4:62-75): q = query i, c = candidate j; rows {x y z nx | ny nz xx 0}
+// M = 0: KNN_CUDA's squared distance (knn.cu:73-77), differences candidate - query summed by fmaf in x, y, z order
+template <int M>
 __device__ __forceinline__ float knnn_key(const float4 q0, const float4 q1, const float4 c0, const float4 c1) {
-  // rows: q0 = {x, y, z, nx}, q1 = {ny, nz, xx, 0}
+  if (M == 0) {
+    const float tx = c0.x - q0.x, ty = c0.y - q0.y, tz = c0.z - q0.z;
+    float acc = fmaf(tx, tx, 0.f);
+    acc = fmaf(ty, ty, acc);
+    acc = fmaf(tz, tz, acc);
+    return acc;
+  }
   float dp = fmaf(q0.x, c0.x, 0.f);
   dp = fmaf(q0.y, c0.y, dp);
   dp = fmaf(q0.z, c0.z, dp);
@@ -50,14 +58,16 @@ __device__ __forceinline__ float knnn_key(const float4 q0, const float4 q1, cons
 
 // ------------------------------------------------------------------ 1. rows
 __global__ __launch_bounds__(256) void knnn_prep_kernel(const float *__restrict__ x, const float *__restrict__ xx,
-                                                        float *__restrict__ rows, int N) {
+                                                        float *__restrict__ rows, int N, int C, long sb, long sd, long sn) {
   const int j = blockIdx.x * 256 + threadIdx.x;
   const int b = blockIdx.y;
   if (j >= N) return;
-  const float *p = x + (long)b * 6 * N + j;
+  const float *p = x + (long)b * sb + (long)j * sn;         // element (b, d, j) at b*sb + d*sd + j*sn
   float4 r0, r1;
-  r0.x = p[0]; r0.y = p[(long)N]; r0.z = p[2L * N]; r0.w = p[3L * N];
-  r1.x = p[4L * N]; r1.y = p[5L * N]; r1.z = xx[(long)b * N + j]; r1.w = 0.f;
+  r0.x = p[0]; r0.y = p[sd]; r0.z = p[2 * sd];
+  r0.w = C >= 6 ? p[3 * sd] : 0.f;
+  r1.x = C >= 6 ? p[4 * sd] : 0.f; r1.y = C >= 6 ? p[5 * sd] : 0.f;
+  r1.z = xx ? xx[(long)b * N + j] : 0.f; r1.w = 0.f;
   float4 *o = reinterpret_cast<float4 *>(rows + ((long)b * N + j) * 8);
   o[0] = r0;
   o[1] = r1;
@@ -66,6 +76,7 @@ __global__ __launch_bounds__(256) void knnn_prep_kernel(const float *__restrict_
 // ------------------------------------------------------------------ 2. thresholds from the strided sample
 // workgroup = 64 queries; lane l of wave w: query 16 w + (l & 15), sample quarter l >> 4.  The N/8 sample rows sit in
 // LDS; the four quarters of a wave read rows one apart (different banks), every 16-lane group the same address.
+template <int M>
 __global__ __launch_bounds__(256) void knnn_sample_kernel(const float *__restrict__ rows, float *__restrict__ tau, int N,
                                                           int m_rank) {
   extern __shared__ __attribute__((aligned(16))) float4 smp[];      // (N/8, 2)
@@ -89,7 +100,7 @@ __global__ __launch_bounds__(256) void knnn_sample_kernel(const float *__restric
       int ss = s + part;
       ss = ss >= gs ? ss - gs : ss;
       const float4 c0 = smp[(base + ss) * 2], c1 = smp[(base + ss) * 2 + 1];
-      const float key = knnn_key(q0, q1, c0, c1);
+      const float key = knnn_key<M>(q0, q1, c0, c1);
       const float x1 = fmaxf(t0[g], key);
       t0[g] = fminf(t0[g], key);
       const float x2 = fmaxf(t1[g], x1);
@@ -118,6 +129,7 @@ __global__ __launch_bounds__(256) void knnn_sample_kernel(const float *__restric
 // ------------------------------------------------------------------ 3. filter: one bit per (query, candidate)
 // workgroup = 4 waves x 128 queries (lane: q and q + 64) x one of KNNN_CS candidate ranges.  The candidate row is
 // wave-uniform: the loads below are scalar (s_load_dwordx8 through the scalar cache).
+template <int M>
 __global__ __launch_bounds__(256) void knnn_filter_kernel(const float *__restrict__ rows, const float *__restrict__ tau,
                                                           unsigned int *__restrict__ bitmap, int N, int B) {
   const int lane = lane_id(), wave = wave_id();
@@ -153,17 +165,25 @@ __global__ __launch_bounds__(256) void knnn_filter_kernel(const float *__restric
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-          const f32x2 cx = {r0[u].x, r0[u].x}, cy = {r0[u].y, r0[u].y}, cz = {r0[u].z, r0[u].z}, cnx = {r0[u].w, r0[u].w},
-                      cny = {r1[u].x, r1[u].x}, cnz = {r1[u].y, r1[u].y}, cxx = {r1[u].z, r1[u].z};
-          f32x2 dp = __builtin_elementwise_fma(qx, cx, zero2);
-          dp = __builtin_elementwise_fma(qy, cy, dp);
-          dp = __builtin_elementwise_fma(qz, cz, dp);
-          f32x2 dn = __builtin_elementwise_fma(qnx, cnx, zero2);
-          dn = __builtin_elementwise_fma(qny, cny, dn);
-          dn = __builtin_elementwise_fma(qnz, cnz, dn);
-          const f32x2 p_pd = __builtin_elementwise_fma(m2, dp, cxx) + qxx;
-          const f32x2 n_pd = __builtin_elementwise_fma(m2, dn, two2);
-          const f32x2 key = p_pd * (one2 + n_pd);
+          const f32x2 cx = {r0[u].x, r0[u].x}, cy = {r0[u].y, r0[u].y}, cz = {r0[u].z, r0[u].z};
+          f32x2 key;
+          if (M == 0) {                                      // six packed operations + the test
+            const f32x2 tx = cx - qx, ty = cy - qy, tz = cz - qz;
+            key = __builtin_elementwise_fma(tx, tx, zero2);
+            key = __builtin_elementwise_fma(ty, ty, key);
+            key = __builtin_elementwise_fma(tz, tz, key);
+          } else {
+            const f32x2 cnx = {r0[u].w, r0[u].w}, cny = {r1[u].x, r1[u].x}, cnz = {r1[u].y, r1[u].y}, cxx = {r1[u].z, r1[u].z};
+            f32x2 dp = __builtin_elementwise_fma(qx, cx, zero2);
+            dp = __builtin_elementwise_fma(qy, cy, dp);
+            dp = __builtin_elementwise_fma(qz, cz, dp);
+            f32x2 dn = __builtin_elementwise_fma(qnx, cnx, zero2);
+            dn = __builtin_elementwise_fma(qny, cny, dn);
+            dn = __builtin_elementwise_fma(qnz, cnz, dn);
+            const f32x2 p_pd = __builtin_elementwise_fma(m2, dp, cxx) + qxx;
+            const f32x2 n_pd = __builtin_elementwise_fma(m2, dn, two2);
+            key = p_pd * (one2 + n_pd);
+          }
           // w = 2 w + (key <= tau): the first candidate of a word ends in bit 31 (reversed on store)
           asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(ua) : "v"(key.x), "v"(tauA) : "vcc");
           asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(ub) : "v"(key.y), "v"(tauB) : "vcc");
@@ -180,9 +200,11 @@ __global__ __launch_bounds__(256) void knnn_filter_kernel(const float *__restric
 }
 
 // ------------------------------------------------------------------ 4. re-rank
+template <int M>
 __global__ __launch_bounds__(256) void knnn_rerank_kernel(const float *__restrict__ rows, const unsigned int *__restrict__ bitmap,
                                                           unsigned char *__restrict__ flag, int64_t *__restrict__ idx,
-                                                          float *__restrict__ val, int N, int k, int step, int kout) {
+                                                          float *__restrict__ val, int N, int k, int step, long o_sb, long o_sk,
+                                                          long o_sq) {
   __shared__ unsigned short cand_s[4][KNNN_CAP];
   const int lane = lane_id(), wave = wave_id();
   const int lin = blockIdx.x + gridDim.x * blockIdx.y;
@@ -237,7 +259,7 @@ __global__ __launch_bounds__(256) void knnn_rerank_kernel(const float *__restric
       const int c = bt * 64 + lane;
       const bool valid = c < total;
       const int j = valid ? (int)cand[c] : q;
-      const float key = knnn_key(q0, q1, rb[(long)j * 2], rb[(long)j * 2 + 1]);
+      const float key = knnn_key<M>(q0, q1, rb[(long)j * 2], rb[(long)j * 2 + 1]);
       kf[bt] = valid ? key_f2u(key) : 0xFFFFFFFFu;
       cj[bt] = j;
     }
@@ -245,9 +267,10 @@ __global__ __launch_bounds__(256) void knnn_rerank_kernel(const float *__restric
   TopB tb;
   rank_candidates(kf, cj, total, k, lane, tb);
   if (lane < k && (lane % step) == 0) {
-    const long o = ((long)b * N + q) * kout + lane / step;
+    const long o = (long)b * o_sb + (long)(lane / step) * o_sk + (long)q * o_sq;    // output element (b, t, q)
     idx[o] = (int64_t)(unsigned int)tb.lst;
-    if (val) val[o] = -key_u2f((unsigned int)(tb.lst >> 32));
+    const float kv = key_u2f((unsigned int)(tb.lst >> 32));
+    if (val) val[o] = M == 0 ? sqrtf(kv) : -kv;
   }
 }
 
@@ -262,25 +285,36 @@ size_t knn_normal_ws_bytes(int B, int N) {
   return knnn_align(n * 32) + knnn_align(n * 4) + knnn_align(n) + knnn_align(n * (size_t)(N / 8));
 }
 
-// x (B,6,N) channel-major, xx (B,N) |xyz|^2 in the oracle's order.  Writes idx/val of every query the filter settled
-// and a flag byte per query (returned through *flag_out) for the exhaustive fallback the caller launches.
-int run_knn_normal(const float *x, const float *xx, int B, int N, int k, int step, int kout, int64_t *idx, float *val,
-                   void *ws, const unsigned char **flag_out, hipStream_t st) {
+// metric 1: x (B,6,N) xyz + normal, xx (B,N) |xyz|^2 in the oracle's order (knn_points_normals); metric 0: the first three
+// channels, squared Euclidean distance by differences (KNN_CUDA; val = sqrt).  x element (b, d, j) at b*sb + d*sd + j*sn;
+// output element (b, t, q) at b*o_sb + t*o_sk + q*o_sq.  Writes idx/val of every query the filter settled and a flag
+// byte per query (returned through *flag_out) for the exhaustive fallback the caller launches.
+int run_knn_normal(int metric, const float *x, long sb, long sd, long sn, const float *xx, int B, int C, int N, int k, int step,
+                   long o_sb, long o_sk, long o_sq, int64_t *idx, float *val, void *ws, const unsigned char **flag_out,
+                   hipStream_t st) {
   char *base = (char *)ws;
   const size_t n = (size_t)B * N;
   float *rows = (float *)base; base += knnn_align(n * 32);
   float *tau = (float *)base; base += knnn_align(n * 4);
   unsigned char *flag = (unsigned char *)base; base += knnn_align(n);
   unsigned int *bitmap = (unsigned int *)base;
-  knnn_prep_kernel<<<dim3(cdiv(N, 256), B), 256, 0, st>>>(x, xx, rows, N);
+  knnn_prep_kernel<<<dim3(cdiv(N, 256), B), 256, 0, st>>>(x, xx, rows, N, metric == 1 ? 6 : 3, sb, sd, sn);
   const double mu = (double)k / KNNN_STRIDE;
   int m = (int)(mu + 6.0 * __builtin_sqrt(mu) + 2.0);
   if (m > 96) m = 96;
   const int lds = (N / KNNN_STRIDE) * 32;
-  GCN_HIP(hipFuncSetAttribute((const void *)knnn_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  knnn_sample_kernel<<<dim3(N / 64, B), 256, lds, st>>>(rows, tau, N, m);
-  knnn_filter_kernel<<<dim3((N / 512) * KNNN_CS * B), 256, 0, st>>>(rows, tau, bitmap, N, B);
-  knnn_rerank_kernel<<<dim3(N / 4, B), 256, 0, st>>>(rows, bitmap, flag, idx, val, N, k, step, kout);
+  const dim3 gs(N / 64, B), gf((N / 512) * KNNN_CS * B), gr(N / 4, B);
+  if (metric == 1) {
+    GCN_HIP(hipFuncSetAttribute((const void *)knnn_sample_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    knnn_sample_kernel<1><<<gs, 256, lds, st>>>(rows, tau, N, m);
+    knnn_filter_kernel<1><<<gf, 256, 0, st>>>(rows, tau, bitmap, N, B);
+    knnn_rerank_kernel<1><<<gr, 256, 0, st>>>(rows, bitmap, flag, idx, val, N, k, step, o_sb, o_sk, o_sq);
+  } else {
+    GCN_HIP(hipFuncSetAttribute((const void *)knnn_sample_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    knnn_sample_kernel<0><<<gs, 256, lds, st>>>(rows, tau, N, m);
+    knnn_filter_kernel<0><<<gf, 256, 0, st>>>(rows, tau, bitmap, N, B);
+    knnn_rerank_kernel<0><<<gr, 256, 0, st>>>(rows, bitmap, flag, idx, val, N, k, step, o_sb, o_sk, o_sq);
+  }
   *flag_out = flag;
   return check_launch("knnn_rerank_kernel");
 }

@@ -150,7 +150,8 @@ int launch_knn_flagged(const float *x_pm, const float *xx, const unsigned char *
 // set) through knn_select_kernel afterwards.
 bool knn_normal_supported(int B, int N, int k);
 size_t knn_normal_ws_bytes(int B, int N);
-int run_knn_normal(const float *x, const float *xx, int B, int N, int k, int step, int kout, int64_t *idx, float *val,
-                   void *ws, const unsigned char **flag_out, hipStream_t st);
+int run_knn_normal(int metric, const float *x, long sb, long sd, long sn, const float *xx, int B, int C, int N, int k, int step,
+                   long o_sb, long o_sk, long o_sq, int64_t *idx, float *val, void *ws, const unsigned char **flag_out,
+                   hipStream_t st);
 
 }  // namespace gcn

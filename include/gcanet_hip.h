@@ -68,7 +68,9 @@ long gcn_knn_tiles_ws_bytes(int B, int C, int N);
 /* knn_points_normals (metric 1, C == 6) is served by threshold + filter + re-rank in the reference's exact arithmetic
  * (csrc/knn_normal.hip: sampled order statistic -> one bit per pair -> exact ranking of ~3k survivors; identical
  * indices/values) when this returns 1 (N % 1024 == 0, 1024 <= N <= 16384, k2 <= 64) AND tile_ws is given:
- * gcn_knn_tiles_ws_bytes(B, 6, N) then includes the B*N*N/8-byte bitmap. */
+ * gcn_knn_tiles_ws_bytes(B, 6, N) then includes the B*N*N/8-byte bitmap.  The same scheme serves gcn_knn_cuda for a
+ * 3-D cloud searched against itself (KNN(k)(x, x), squared distances by differences) under the same size conditions,
+ * with gcn_knn_tiles_ws_bytes(B, 3, nr) bytes of workspace. */
 int gcn_knn_normal_supported(int B, int N, int k2);
 
 /* Feature-space kNN of the in-model `knn` (models/dgcnn-hais-concat-direct-4.py:30-47) for C in {32,64,128} as a
