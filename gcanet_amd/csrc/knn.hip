@@ -931,6 +931,13 @@ GCN_EXPORT int gcn_knn_model(const float *x, int B, int C, int N, int k1, int k2
     a.only = flag;
     return launch_knn<2, 6>(a, B, st);
   }
+  if (metric == 0 && C == 3 && tile_ws && knn_normal_supported(B, N, k2)) {      // the same scheme for `knn` on xyz
+    const unsigned char *flag = nullptr;
+    rc = run_knn_normal(2, x, (long)C * N, N, 1, xx_ws, B, C, N, k2, step, (long)N * kout, 1, kout, idx, val, tile_ws, &flag, st);
+    if (rc) return rc;
+    a.only = flag;
+    return launch_knn<1, 3>(a, B, st);
+  }
   // 3-D clouds: Morton-tiled kernel with bounding-box pruning (identical results, ~5x fewer candidates)
   const bool tiled = tile_ws && k2 <= 64 && N >= 512 && ((metric == 1 && C == 6) || (metric == 0 && C == 3));
   if (tiled)

@@ -36,6 +36,7 @@ constexpr int KNNN_CS = 8;           // candidate ranges per query block in the 
 
 // M = 1: oracle/gcanet_oracle.c:model_pd metric 1 (M4:62-75): q = query i, c = candidate j; rows {x y z nx | ny nz xx 0}
 // M = 0: KNN_CUDA's squared distance (knn.cu:73-77), differences candidate - query summed by fmaf in x, y, z order
+// M = 2: the in-model `knn` on a 3-D cloud (M4:36-38, metric 0 of model_pd): -(fl(fl(2 dot - xx_j) - xx_i)); rows carry xx
 template <int M>
 __device__ __forceinline__ float knnn_key(const float4 q0, const float4 q1, const float4 c0, const float4 c1) {
   if (M == 0) {
@@ -44,6 +45,13 @@ __device__ __forceinline__ float knnn_key(const float4 q0, const float4 q1, cons
     acc = fmaf(ty, ty, acc);
     acc = fmaf(tz, tz, acc);
     return acc;
+  }
+  if (M == 2) {
+    float d3 = fmaf(q0.x, c0.x, 0.f);
+    d3 = fmaf(q0.y, c0.y, d3);
+    d3 = fmaf(q0.z, c0.z, d3);
+    const float t = fmaf(2.f, d3, -c1.z);                    // fl(2 dot - xx_j): 2 dot is exact
+    return q1.z - t;                                         // -(t - xx_i)
   }
   float dp = fmaf(q0.x, c0.x, 0.f);
   dp = fmaf(q0.y, c0.y, dp);
@@ -172,6 +180,12 @@ __global__ __launch_bounds__(256) void knnn_filter_kernel(const float *__restric
             key = __builtin_elementwise_fma(tx, tx, zero2);
             key = __builtin_elementwise_fma(ty, ty, key);
             key = __builtin_elementwise_fma(tz, tz, key);
+          } else if (M == 2) {
+            const f32x2 cxx = {r1[u].z, r1[u].z};
+            f32x2 d3 = __builtin_elementwise_fma(qx, cx, zero2);
+            d3 = __builtin_elementwise_fma(qy, cy, d3);
+            d3 = __builtin_elementwise_fma(qz, cz, d3);
+            key = qxx - __builtin_elementwise_fma(two2, d3, -cxx);
           } else {
             const f32x2 cnx = {r0[u].w, r0[u].w}, cny = {r1[u].x, r1[u].x}, cnz = {r1[u].y, r1[u].y}, cxx = {r1[u].z, r1[u].z};
             f32x2 dp = __builtin_elementwise_fma(qx, cx, zero2);
@@ -285,7 +299,8 @@ size_t knn_normal_ws_bytes(int B, int N) {
   return knnn_align(n * 32) + knnn_align(n * 4) + knnn_align(n) + knnn_align(n * (size_t)(N / 8));
 }
 
-// metric 1: x (B,6,N) xyz + normal, xx (B,N) |xyz|^2 in the oracle's order (knn_points_normals); metric 0: the first three
+// metric 1: x (B,6,N) xyz + normal, xx (B,N) |xyz|^2 in the oracle's order (knn_points_normals); metric 2: the in-model
+// `knn` on a 3-D cloud (needs xx as well); metric 0: the first three
 // channels, squared Euclidean distance by differences (KNN_CUDA; val = sqrt).  x element (b, d, j) at b*sb + d*sd + j*sn;
 // output element (b, t, q) at b*o_sb + t*o_sk + q*o_sq.  Writes idx/val of every query the filter settled and a flag
 // byte per query (returned through *flag_out) for the exhaustive fallback the caller launches.
@@ -309,6 +324,11 @@ int run_knn_normal(int metric, const float *x, long sb, long sd, long sn, const 
     knnn_sample_kernel<1><<<gs, 256, lds, st>>>(rows, tau, N, m);
     knnn_filter_kernel<1><<<gf, 256, 0, st>>>(rows, tau, bitmap, N, B);
     knnn_rerank_kernel<1><<<gr, 256, 0, st>>>(rows, bitmap, flag, idx, val, N, k, step, o_sb, o_sk, o_sq);
+  } else if (metric == 2) {
+    GCN_HIP(hipFuncSetAttribute((const void *)knnn_sample_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    knnn_sample_kernel<2><<<gs, 256, lds, st>>>(rows, tau, N, m);
+    knnn_filter_kernel<2><<<gf, 256, 0, st>>>(rows, tau, bitmap, N, B);
+    knnn_rerank_kernel<2><<<gr, 256, 0, st>>>(rows, bitmap, flag, idx, val, N, k, step, o_sb, o_sk, o_sq);
   } else {
     GCN_HIP(hipFuncSetAttribute((const void *)knnn_sample_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     knnn_sample_kernel<0><<<gs, 256, lds, st>>>(rows, tau, N, m);

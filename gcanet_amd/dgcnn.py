@@ -32,9 +32,10 @@ def _knn_model(x, k1, k2, metric):
     # normals (the synthetic benchmark clouds) more than half of the tiles survive -- slower than the full scan.
     if k2 <= 64 and N >= 512 and metric == 0 and C == 3:
         tile_ws = torch.empty(_lib.lib().gcn_knn_tiles_ws_bytes(B, C, N), dtype=torch.uint8, device=x.device)
-    # xyz + normal clouds at N % 1024 == 0: threshold + filter + re-rank in exact arithmetic (csrc/knn_normal.hip)
-    if metric == 1 and C == 6 and _lib.lib().gcn_knn_normal_supported(B, N, k2):
-        key = ("normal", B, N, x.device)
+    # 3-D clouds (xyz, or xyz + normal) at N % 1024 == 0: threshold + filter + re-rank in exact arithmetic
+    # (csrc/knn_normal.hip)
+    if ((metric == 1 and C == 6) or (metric == 0 and C == 3)) and _lib.lib().gcn_knn_normal_supported(B, N, k2):
+        key = ("normal", B, C, N, x.device)
         if key not in _KNN_WS:        # one scratch buffer per shape and device (calls are stream-ordered)
             _KNN_WS[key] = torch.empty(_lib.lib().gcn_knn_tiles_ws_bytes(B, C, N), dtype=torch.uint8, device=x.device)
         tile_ws = _KNN_WS[key]

@@ -171,4 +171,4 @@ def test_edge_conv_any_width_routes_to_the_exact_kernel(dev, C, Cout, G):
     np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-4, atol=1e-4)
     for a, b, name in ((xd, xr, "dx"), (wd, wr, "dW"), (gd, gr, "dgamma"), (bd, br, "dbeta")):
         r = b.grad.numpy()
-        np.testing.assert_allclose(a.grad.cpu().numpy(), r, rtol=1e-3, atol=2e-4 * max(1.0, float(np.abs(r).max())), err_msg=name)
+        np.testing.assert_allclose(a.grad.cpu().numpy(), r, rtol=1e-4, atol=1e-4 * max(1e-6, float(np.abs(r).max())), err_msg=name)
