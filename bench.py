@@ -450,7 +450,10 @@ def main():
     # into a HIP graph and the timed steps are replays: ~390 launches cost the host ~7.7 ms per step otherwise, about as
     # long as the GPU needs to execute them (the RCCL all-reduce with its backward hook stays on eager launches)
     use_graph = world == 1 and not args.no_graph
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True, capturable=use_graph)   # option_new.py:83-90
+    # option_new.py:83-90 trains with Adam(lr=1e-3): the same rule as ONE elementwise kernel over the flat parameter /
+    # gradient / moment buffers (gcanet_amd/optim.py; torch's multi-tensor launches take 0.2 ms for these 57 tensors)
+    from gcanet_amd.optim import FlatAdam
+    opt = FlatAdam(dp, lr=1e-3)
     B, N = args.batch, args.points
     pts, nrm = synth_clouds(range(rank * B, rank * B + B), N, dev)
 

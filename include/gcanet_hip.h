@@ -578,6 +578,13 @@ int gcn_attention_bwd_f16(const float *q, const float *k, const float *v, const 
  *   rows are `pitch` elements apart (pitch == cols for plain copies). */
 int gcn_multi_cast_bf16(const void *segs_dev, int nseg, void *stream);
 
+/* Adam (torch.optim.Adam's rule: exp_avg lerp, exp_avg_sq, bias corrections, p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps),
+ * optional L2 weight decay folded into the gradient) over flat f32 buffers of n elements, 16-byte aligned.  state: 4
+ * floats on the device, zero before the first step: [0] the step count (incremented by the call: graph-capturable),
+ * [1], [2] the bias corrections.  The reference's trainer: option_new.py:83-90. */
+int gcn_adam_flat(float *p, const float *g, float *m, float *v, long n, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, float *state, void *stream);
+
 /* Optional pre-zeroed scratch arena.  Many entry points zero small accumulators they are handed ("zeroed by the call"):
  * ~45 fills of a few hundred bytes to a few MB per training step, ~4.5 us of GPU time each.  A caller that carves those
  * buffers out of ONE device allocation, zeroes the used part of it once per step and never hands the same bytes out
