@@ -607,11 +607,32 @@ __global__ __launch_bounds__(256) void idx_to_u16_kernel(const int64_t *__restri
 }
 
 __global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ x, long n, unsigned int *__restrict__ out) {
+  // 16 bytes per lane, four loads in flight; ONE atomic per workgroup (2048 same-address atomics from the waves of a
+  // 512-workgroup grid cost more than the 16 MB read)
+  __shared__ float red[4];
   float m = 0.f;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+  const long n4 = n >> 2;
+  const float4 *x4 = reinterpret_cast<const float4 *>(x);
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long stride = (long)gridDim.x * 256;
+  for (; i + 3 * stride < n4; i += 4 * stride) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = x4[i + u * stride];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) m = fmaxf(m, fmaxf(fmaxf(fabsf(v[u].x), fabsf(v[u].y)), fmaxf(fabsf(v[u].z), fabsf(v[u].w))));
+  }
+  for (; i < n4; i += stride) {
+    const float4 v = x4[i];
+    m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+  }
+  if (blockIdx.x == 0 && (long)threadIdx.x < n - (n4 << 2)) m = fmaxf(m, fabsf(x[(n4 << 2) + threadIdx.x]));
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-  if (lane_id() == 0) atomicMax(out, __float_as_uint(m));      // non-negative floats order like their bit patterns
+  if (lane_id() == 0) red[wave_id()] = m;
+  __syncthreads();
+  if (threadIdx.x == 0)                                  // non-negative floats order like their bit patterns
+    atomicMax(out, __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
 }
 
 template <typename IdxT, bool C64>
@@ -1099,7 +1120,7 @@ GCN_EXPORT int gcn_reverse_sum(const float *x_pm, const int64_t *idx, int B, int
   if (B == 0) return GCN_OK;
   hipStream_t st = (hipStream_t)stream;
   GCN_HIP(zero_dev(ws, 256, st));          // max |x| bits + the staged path's overflow counters
-  if (C > 0) absmax_kernel<<<512, 256, 0, st>>>(x_pm, (long)B * N * C, (unsigned int *)ws);
+  if (C > 0) absmax_kernel<<<256, 256, 0, st>>>(x_pm, (long)B * N * C, (unsigned int *)ws);
   if (C > 0 && rsum_staged_supported(B, N, C, k)) return run_reverse_sum_staged(x_pm, idx, B, N, C, k, r, indeg, ws, st);
   // destination rows per workgroup: ~256 workgroups in total, bounded by 128 KB of LDS
   int R = (int)(((long)N * B + 255) / 256);

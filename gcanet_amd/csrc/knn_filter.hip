@@ -87,15 +87,36 @@ __device__ __forceinline__ unsigned int upper_half_u(unsigned int u) {
 
 // ------------------------------------------------------------------ 1. prep
 __global__ __launch_bounds__(256) void knnf_colsum_kernel(KnnfArgs a) {
+  // thread = (row slot, 4 channels): 16-byte loads, four rows in flight; the row slots of a workgroup meet in LDS and
+  // ONE atomic per (workgroup, channel) goes out
+  __shared__ float part[256][4];
   const int b = blockIdx.y;
-  const int c = threadIdx.x & 127, rl = threadIdx.x >> 7;
+  const int q = a.C / 4;                                  // C in {32,64,128}: 8, 16 or 32 threads per row
+  const int c4 = (threadIdx.x % q) * 4, slot = threadIdx.x / q, nslot = 256 / q;
   const int rows = (a.N + gridDim.x - 1) / gridDim.x;
   const int r0 = blockIdx.x * rows, r1 = min(a.N, r0 + rows);
-  if (c >= a.C) return;
   const float *xb = a.x + (long)b * a.N * a.C;
-  float s = 0.f;
-  for (int r = r0 + rl; r < r1; r += 2) s += xb[(long)r * a.C + c];
-  atomicAdd(a.msum + (long)b * a.Cp + c, s);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int r = r0 + slot;
+  for (; r + 3 * nslot < r1; r += 4 * nslot) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4 *>(xb + (long)(r + u * nslot) * a.C + c4);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { s0 += v[u].x; s1 += v[u].y; s2 += v[u].z; s3 += v[u].w; }
+  }
+  for (; r < r1; r += nslot) {
+    const float4 v = *reinterpret_cast<const float4 *>(xb + (long)r * a.C + c4);
+    s0 += v.x; s1 += v.y; s2 += v.z; s3 += v.w;
+  }
+  part[threadIdx.x][0] = s0; part[threadIdx.x][1] = s1; part[threadIdx.x][2] = s2; part[threadIdx.x][3] = s3;
+  __syncthreads();
+  if ((int)threadIdx.x < a.C) {
+    const int c = threadIdx.x;
+    float t = 0.f;
+    for (int sl = 0; sl < nslot; ++sl) t += part[sl * q + c / 4][c & 3];
+    atomicAdd(a.msum + (long)b * a.Cp + c, t);
+  }
 }
 
 // 64 rows per workgroup.  Phase 1: a wave walks 16 rows, lanes across channels: centred bf16 row and hn.  Phase 2:
@@ -107,34 +128,33 @@ __global__ __launch_bounds__(256) void knnf_prep_kernel(KnnfArgs a) {
   const int b = blockIdx.y;
   const int r0 = blockIdx.x * 64;
   const float invn = 1.f / (float)a.N;
-  float mean[2];
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int c = lane + 64 * h;
-    mean[h] = c < a.C ? a.msum[(long)b * a.Cp + c] * invn : 0.f;
-  }
+  // phase 1: C/4 lanes per row (16-byte loads, 8-byte bf16 stores), 64/(C/4) rows per wave and iteration, all of a
+  // wave's iterations issued together; C == Cp here (C in {32, 64, 128})
+  const int lpr = a.C / 4, rpi = 64 / lpr;                  // lanes per row, rows per iteration
+  const int c4 = (lane % lpr) * 4, rsub = lane / lpr;
+  const float4 mean4 = make_float4(a.msum[(long)b * a.Cp + c4] * invn, a.msum[(long)b * a.Cp + c4 + 1] * invn,
+                                   a.msum[(long)b * a.Cp + c4 + 2] * invn, a.msum[(long)b * a.Cp + c4 + 3] * invn);
   float ntmax = 0.f;
-  for (int i = 0; i < 16; ++i) {
-    const int r = r0 + wave * 16 + i;
-    if (r >= a.N) break;
-    const float *row = a.x + ((long)b * a.N + r) * a.C;
-    float nt = 0.f;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int c = lane + 64 * h;
-      if (c < a.Cp) {
-        const float u = c < a.C ? row[c] - mean[h] : 0.f;
-        const unsigned short hb = f2bf(u);
-        a.ut[((long)b * a.N + r) * a.Cp + c] = hb;
-        const float v = bf2f(hb);
-        nt = fmaf(v, v, nt);
-      }
+  for (int i = 0; i < 16; i += rpi) {
+    const int r = r0 + wave * 16 + i + rsub;
+    const bool live = r < a.N;
+    const int rr = live ? r : a.N - 1;
+    const float4 v = *reinterpret_cast<const float4 *>(a.x + ((long)b * a.N + rr) * a.C + c4);
+    const unsigned short h0 = f2bf(v.x - mean4.x), h1 = f2bf(v.y - mean4.y), h2 = f2bf(v.z - mean4.z), h3 = f2bf(v.w - mean4.w);
+    if (live) {
+      uint2 o;
+      o.x = (unsigned int)h0 | ((unsigned int)h1 << 16);
+      o.y = (unsigned int)h2 | ((unsigned int)h3 << 16);
+      *reinterpret_cast<uint2 *>(a.ut + ((long)b * a.N + r) * a.Cp + c4) = o;
     }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) nt += __shfl_xor(nt, o);
-    if (lane == 0) a.hn[(long)b * a.N + r] = 0.5f * nt;
-    ntmax = fmaxf(ntmax, nt);
+    const float u0 = bf2f(h0), u1 = bf2f(h1), u2 = bf2f(h2), u3 = bf2f(h3);
+    float nt = fmaf(u3, u3, fmaf(u2, u2, fmaf(u1, u1, u0 * u0)));
+    for (int o = lpr >> 1; o >= 1; o >>= 1) nt += __shfl_xor(nt, o);
+    if (live && (lane % lpr) == 0) a.hn[(long)b * a.N + r] = 0.5f * nt;
+    if (live) ntmax = fmaxf(ntmax, nt);
   }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) ntmax = fmaxf(ntmax, __shfl_xor(ntmax, o));
   float xmax = 0.f;
   if (threadIdx.x < 64 && r0 + (int)threadIdx.x < a.N) {
     const float *row = a.x + ((long)b * a.N + r0 + threadIdx.x) * a.C;
