@@ -66,6 +66,9 @@ struct KnnfArgs {
   unsigned int *nflag;       // [0] number of flagged queries
   unsigned int *flist;       // (B*N) flagged queries (b*N + q), in arrival order
   int64_t *idx;              // (B,N,kout)
+  float *keys;               // (B,N,KNNF_CAP) exact keys of a query's candidates (two-kernel re-rank)
+  unsigned short *cjs;       // (B,N,KNNF_CAP) their indices
+  int *ccnt;                 // (B,N) number of candidates (0: the query went to the fallback list)
   int B, N, C, Cp, NW, k, step, kout, m_rank;
 };
 
@@ -482,6 +485,195 @@ __global__ __launch_bounds__(256) void knnf_rerank_kernel(KnnfArgs a) {
     a.idx[((long)b * N + q) * a.kout + lane / a.step] = (int64_t)(unsigned int)tb.lst;
 }
 
+// ------------------------------------------------------------------ 4'. re-rank in two kernels (default)
+// knnf_rerank_kernel above fetches a candidate's 256-byte row with sixteen 16-byte loads of ONE lane: every
+// instruction touches 64 different 128-byte lines and the texture-address unit takes a clock per line -- 0.36 of the
+// kernel's 0.43 ms at C = 64 (PMC: 69 such loads per query, waves waiting 60 % of their cycles).  Here the rows are
+// fetched COOPERATIVELY -- 16 lanes per 256-byte row piece, four rows per instruction: 8 lines instead of 64 -- and
+// pass through a per-wave LDS stage with the 16-byte chunks XOR-swizzled by the row number, so that the write (lane =
+// chunk of a row) and the read (lane = its own candidate's row, chunk after chunk) are both conflict-free; the next
+// piece's loads are issued before the current piece is consumed.  The query row sits in scalar registers.  The 16-KB
+// stage caps occupancy at 8 waves per CU, which the ranking epilogue (bisections, a bitonic sort: long dependent
+// chains) could not live with -- so the exact keys go to memory (~1.3 KB per query) and knnf_rank_kernel ranks them at
+// full occupancy.
+typedef float knnf_v4 __attribute__((ext_vector_type(4)));
+
+template <int CC, int NI, int RPI, int PCH>
+__device__ __forceinline__ void knnf_fetch_piece(knnf_v4 (&v)[NI], const float *__restrict__ xb, const unsigned short *cand, int bt,
+                                                 int p, int lrow, int lch, int total) {
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int ci = min(bt * 64 + i * RPI + lrow, total - 1);
+    const int j = (int)cand[ci];
+    v[i] = *reinterpret_cast<const knnf_v4 *>(xb + (long)j * CC + p * (PCH * 4) + lch * 4);
+  }
+}
+
+template <int CC>
+__global__ __launch_bounds__(256) void knnf_keys_kernel(KnnfArgs a) {
+  constexpr int PCH = CC >= 64 ? 16 : 8;       // 16-byte chunks per row piece (256 or 128 bytes)
+  constexpr int NP = CC / (4 * PCH);            // pieces per row
+  constexpr int RPI = 64 / PCH;                 // rows per cooperative load instruction
+  constexpr int NI = 64 / RPI;                  // load instructions per piece of a 64-row batch
+  constexpr int PB = PCH * 16;                  // bytes per row piece
+  constexpr int WAVE_LDS = 64 * PB + 2 * KNNF_CAP;
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+  const int lane = lane_id(), wave = wave_id();
+  unsigned char *stage = dyn_lds + wave * WAVE_LDS;
+  unsigned short *cand = reinterpret_cast<unsigned short *>(stage + 64 * PB);
+  const int lin = blockIdx.x + gridDim.x * blockIdx.y;
+  const int b = lin % (int)gridDim.y;
+  const int q = __builtin_amdgcn_readfirstlane((lin / (int)gridDim.y) * 4 + wave);
+  const int N = a.N, NW = a.NW;
+  if (q >= N) return;
+  const unsigned int *bm = a.bitmap + ((long)b * N + q) * NW;
+  unsigned int words[8];
+  int cnt = 0;
+#pragma unroll
+  for (int w = 0; w < 8; ++w) {
+    const int wi = lane + 64 * w;
+    words[w] = wi < NW ? bm[wi] : 0u;
+    cnt += __popc(words[w]);
+  }
+  int incl = cnt;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int y = __shfl_up(incl, d);
+    if (lane >= d) incl += y;
+  }
+  const int total = __builtin_amdgcn_readlane(incl, 63);
+  const bool bad = total < a.k || total > KNNF_CAP;
+  if (bad) {                                                 // the fallback handles this query exhaustively
+    if (lane == 0) {
+      a.flag[(long)b * N + q] = 1;
+      a.ccnt[(long)b * N + q] = 0;
+      a.flist[atomicAdd(a.nflag, 1u)] = (unsigned int)(b * N + q);
+    }
+    return;
+  }
+  if (lane == 0) a.ccnt[(long)b * N + q] = total;
+  int pos = incl - cnt;
+#pragma unroll
+  for (int w = 0; w < 8; ++w) {
+    unsigned int word = words[w];
+    const int base = (lane + 64 * w) * 32;
+    while (word) {
+      const int p = __ffs((int)word) - 1;
+      word &= word - 1;
+      const int i = p & 15;
+      cand[pos++] = (unsigned short)(base + 4 * (p >> 4) + (i & 3) + 8 * (i >> 2));
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+
+  const float *xb = a.x + (long)b * N * CC;
+  // the query row as scalars: lane c loads channel c (+64), v_readlane spreads it over SGPRs (a plain uniform load is
+  // not turned into s_load here -- the kernel stores to memory the compiler cannot tell apart from x)
+  float qrow[CC];
+  {
+    const float qv0 = xb[(long)q * CC + (lane < CC ? lane : 0)];
+    const float qv1 = CC > 64 ? xb[(long)q * CC + 64 + lane] : 0.f;
+#pragma unroll
+    for (int c = 0; c < CC; ++c)
+      qrow[c] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c < 64 ? qv0 : qv1), c & 63));
+  }
+  const float xxq = a.xx[(long)b * N + q];
+  const int nb = (total + 63) >> 6;
+  const int lrow = lane / PCH, lch = lane % PCH;             // cooperative role: row inside the instruction's group, chunk
+  // pieces t = 0 .. nb*NP - 1 (batch t / NP, row piece t % NP) alternate between two register sets: while one is
+  // staged and consumed, the loads of the next piece fill the other (no copies between the sets: they stay registers)
+  knnf_v4 ra[NI], rb[NI];
+  float *kout = a.keys + ((long)b * N + q) * KNNF_CAP;
+  unsigned short *jout = a.cjs + ((long)b * N + q) * KNNF_CAP;
+  const int npieces = nb * NP;
+  float dot = 0.f;
+  auto consume = [&](int t, const knnf_v4 (&v)[NI]) __attribute__((always_inline)) {
+    const int bt = t / NP, p = t % NP;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int r = i * RPI + lrow;
+      *reinterpret_cast<knnf_v4 *>(stage + r * PB + ((lch ^ (r & (PCH - 1))) << 4)) = v[i];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (p == 0) dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < PCH; ++c) {
+      if ((c & 3) == 0) __builtin_amdgcn_sched_barrier(0);     // four LDS reads in flight, not sixteen (register pressure)
+      const knnf_v4 w4 = *reinterpret_cast<const knnf_v4 *>(stage + lane * PB + ((c ^ (lane & (PCH - 1))) << 4));
+      const float *qk = qrow + (NP == 1 ? 0 : p * (PCH * 4)) + c * 4;
+      dot = fmaf(qk[0], w4.x, dot);
+      dot = fmaf(qk[1], w4.y, dot);
+      dot = fmaf(qk[2], w4.z, dot);
+      dot = fmaf(qk[3], w4.w, dot);
+    }
+    __builtin_amdgcn_wave_barrier();                           // the next piece overwrites the stage after these reads
+    if (p == NP - 1) {
+      const int c = bt * 64 + lane;
+      if (c < total) {
+        const int j = (int)cand[c];
+        const float tt = 2.f * dot - a.xx[(long)b * N + j];
+        const float pd = tt - xxq;
+        kout[c] = -pd;
+        jout[c] = (unsigned short)j;
+      }
+    }
+  };
+  knnf_fetch_piece<CC, NI, RPI, PCH>(ra, xb, cand, 0, 0, lrow, lch, total);
+  for (int t = 0; t < npieces; t += 2) {
+    if (t + 1 < npieces) knnf_fetch_piece<CC, NI, RPI, PCH>(rb, xb, cand, (t + 1) / NP, (t + 1) % NP, lrow, lch, total);
+    consume(t, ra);
+    if (t + 1 < npieces) {
+      if (t + 2 < npieces) knnf_fetch_piece<CC, NI, RPI, PCH>(ra, xb, cand, (t + 2) / NP, (t + 2) % NP, lrow, lch, total);
+      consume(t + 1, rb);
+    }
+  }
+}
+
+template <int CC>
+__global__ __launch_bounds__(256) void knnf_rank_kernel(KnnfArgs a) {
+  const int lane = lane_id(), wave = wave_id();
+  const int lin = blockIdx.x + gridDim.x * blockIdx.y;
+  const int b = lin % (int)gridDim.y;
+  const int q = (lin / (int)gridDim.y) * 4 + wave;
+  const int N = a.N;
+  if (q >= N) return;
+  const int total = a.ccnt[(long)b * N + q];
+  if (total == 0) return;                                    // on the fallback list
+  const float *kin = a.keys + ((long)b * N + q) * KNNF_CAP;
+  const unsigned short *jin = a.cjs + ((long)b * N + q) * KNNF_CAP;
+  unsigned int kf[8];
+  int cj[8];
+#pragma unroll
+  for (int bt = 0; bt < 8; ++bt) {
+    kf[bt] = 0xFFFFFFFFu;
+    cj[bt] = q;
+    if (bt * 64 < total) {                                   // wave-uniform
+      const int c = bt * 64 + lane;
+      if (c < total) { kf[bt] = key_f2u(kin[c]); cj[bt] = (int)jin[c]; }
+    }
+  }
+  TopB tb;
+  rank_candidates(kf, cj, total, a.k, lane, tb);
+  // a-posteriori check with the exact k-th key (header comment)
+  const float xxq = a.xx[(long)b * N + q];
+  const float dk = key_u2f((unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(tb.lst >> 32), a.k - 1));
+  const float nq = 2.f * a.hn[(long)b * N + q];
+  const float Rt2 = __uint_as_float(a.stat[b * 2]), X2 = __uint_as_float(a.stat[b * 2 + 1]);
+  const float eta = 0.00198f * (sqrtf(nq) + sqrtf(Rt2)) * 1.0001f;
+  const float big = fmaxf(sqrtf(nq), sqrtf(xxq)) + fmaxf(sqrtf(Rt2), sqrtf(X2));
+  const float Delta = 4.f * (float)(CC + 8) * 5.9604645e-8f * big * big * 1.0001f;
+  const float root = sqrtf(fmaxf(a.tau[(long)b * N + q] - Delta, 0.f)) * 0.99999f - eta;
+  const bool proven = root > 0.f && (root * root) * 0.99999f - Delta > dk;
+  if (lane == 0) {
+    a.flag[(long)b * N + q] = proven ? 0 : 1;
+    if (!proven) a.flist[atomicAdd(a.nflag, 1u)] = (unsigned int)(b * N + q);
+  }
+  if (proven && lane < a.k && (lane % a.step) == 0)
+    a.idx[((long)b * N + q) * a.kout + lane / a.step] = (int64_t)(unsigned int)tb.lst;
+}
+
 // ------------------------------------------------------------------ 5. exhaustive exact search of the listed queries
 // One workgroup per listed query; its four waves scan a quarter of the cloud each (rows are consecutive: a batch of 64
 // candidates is 64 contiguous rows), keep a buffered bitonic top-64, and wave 0 merges the four lists.
@@ -541,7 +733,7 @@ __global__ __launch_bounds__(256) void knnf_fallback_kernel(KnnfArgs a) {
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct KnnfWs {
-  size_t ut, hn, xx, msum, stat, nflag, theta, tau, bitmap, flag, flist, total;
+  size_t ut, hn, xx, msum, stat, nflag, theta, tau, bitmap, flag, flist, keys, cjs, ccnt, total;
 };
 
 static KnnfWs knnf_layout(int B, int N, int Cp) {
@@ -558,6 +750,9 @@ static KnnfWs knnf_layout(int B, int N, int Cp) {
   w.flag = o; o += align256((size_t)B * N);
   w.flist = o; o += align256(sizeof(unsigned int) * (size_t)B * N);
   w.bitmap = o; o += align256(sizeof(unsigned int) * (size_t)B * N * (N / 32));
+  w.keys = o; o += align256(sizeof(float) * (size_t)B * N * KNNF_CAP);
+  w.cjs = o; o += align256(sizeof(unsigned short) * (size_t)B * N * KNNF_CAP);
+  w.ccnt = o; o += align256(sizeof(int) * (size_t)B * N);
   w.total = o;
   return w;
 }
@@ -593,6 +788,7 @@ GCN_EXPORT int gcn_knn_feature(const float *x_pm, int B, int N, int C, int k1, i
   a.msum = (float *)(base + w.msum); a.stat = (unsigned int *)(base + w.stat); a.theta = (float *)(base + w.theta);
   a.bitmap = (unsigned int *)(base + w.bitmap); a.flag = (unsigned char *)(base + w.flag); a.idx = idx;
   a.tau = (float *)(base + w.tau); a.nflag = (unsigned int *)(base + w.nflag); a.flist = (unsigned int *)(base + w.flist);
+  a.keys = (float *)(base + w.keys); a.cjs = (unsigned short *)(base + w.cjs); a.ccnt = (int *)(base + w.ccnt);
   a.B = B; a.N = N; a.C = C; a.Cp = Cp; a.NW = N / 32; a.k = k2; a.step = k2 / k1;
   a.kout = (k2 + a.step - 1) / a.step;
   // rank of the sample order statistic: mean k/8 of the true neighbours fall into the 1-in-8 sample
@@ -619,9 +815,23 @@ GCN_EXPORT int gcn_knn_feature(const float *x_pm, int B, int N, int C, int k1, i
   int rc = check_launch("knnf_stream_kernel");
   if (rc) return rc;
   const dim3 rgrid(N / 4, B);
-  if (C == 32) knnf_rerank_kernel<32><<<rgrid, 256, 0, st>>>(a);
-  else if (C == 64) knnf_rerank_kernel<64><<<rgrid, 256, 0, st>>>(a);
-  else knnf_rerank_kernel<128><<<rgrid, 256, 0, st>>>(a);
+  const char *rr_env = getenv("GCANET_KNN_RERANK");
+  if (rr_env && atoi(rr_env) == 1) {                         // the single-kernel form (kept for comparison)
+    if (C == 32) knnf_rerank_kernel<32><<<rgrid, 256, 0, st>>>(a);
+    else if (C == 64) knnf_rerank_kernel<64><<<rgrid, 256, 0, st>>>(a);
+    else knnf_rerank_kernel<128><<<rgrid, 256, 0, st>>>(a);
+  } else {
+#define KNNF_RERANK2(CCV)                                                                                          \
+    {                                                                                                               \
+      constexpr int PBV = (CCV >= 64 ? 16 : 8) * 16;                                                                \
+      constexpr int LDSV = 4 * (64 * PBV + 2 * KNNF_CAP);                                                           \
+      GCN_HIP(hipFuncSetAttribute((const void *)knnf_keys_kernel<CCV>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSV)); \
+      knnf_keys_kernel<CCV><<<rgrid, 256, LDSV, st>>>(a);                                                           \
+      knnf_rank_kernel<CCV><<<rgrid, 256, 0, st>>>(a);                                                              \
+    }
+    if (C == 32) KNNF_RERANK2(32) else if (C == 64) KNNF_RERANK2(64) else KNNF_RERANK2(128)
+#undef KNNF_RERANK2
+  }
   rc = check_launch("knnf_rerank_kernel");
   if (rc) return rc;
   if (C == 32) knnf_fallback_kernel<32><<<256, 256, 0, st>>>(a);
