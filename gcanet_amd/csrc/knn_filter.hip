@@ -511,7 +511,7 @@ __device__ __forceinline__ void knnf_fetch_piece(knnf_v4 (&v)[NI], const float *
 
 template <int CC>
 __global__ __launch_bounds__(256) void knnf_keys_kernel(KnnfArgs a) {
-  constexpr int PCH = CC >= 64 ? 16 : 8;       // 16-byte chunks per row piece (256 or 128 bytes)
+  constexpr int PCH = 8;                       // 16-byte chunks per row piece: 128 bytes = one cache line
   constexpr int NP = CC / (4 * PCH);            // pieces per row
   constexpr int RPI = 64 / PCH;                 // rows per cooperative load instruction
   constexpr int NI = 64 / RPI;                  // load instructions per piece of a 64-row batch
@@ -588,8 +588,9 @@ __global__ __launch_bounds__(256) void knnf_keys_kernel(KnnfArgs a) {
   unsigned short *jout = a.cjs + ((long)b * N + q) * KNNF_CAP;
   const int npieces = nb * NP;
   float dot = 0.f;
-  auto consume = [&](int t, const knnf_v4 (&v)[NI]) __attribute__((always_inline)) {
-    const int bt = t / NP, p = t % NP;
+  auto consume = [&](int t, auto pc, const knnf_v4 (&v)[NI]) __attribute__((always_inline)) {
+    constexpr int p = decltype(pc)::value;                       // row piece (compile time: indexes the scalar query row)
+    const int bt = t / NP;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int r = i * RPI + lrow;
@@ -600,13 +601,13 @@ __global__ __launch_bounds__(256) void knnf_keys_kernel(KnnfArgs a) {
     if (p == 0) dot = 0.f;
 #pragma unroll
     for (int c = 0; c < PCH; ++c) {
-      if ((c & 3) == 0) __builtin_amdgcn_sched_barrier(0);     // four LDS reads in flight, not sixteen (register pressure)
+      if ((c & 3) == 0) __builtin_amdgcn_sched_barrier(0);     // four LDS reads in flight, not eight (register pressure)
       const knnf_v4 w4 = *reinterpret_cast<const knnf_v4 *>(stage + lane * PB + ((c ^ (lane & (PCH - 1))) << 4));
-      const float *qk = qrow + (NP == 1 ? 0 : p * (PCH * 4)) + c * 4;
-      dot = fmaf(qk[0], w4.x, dot);
-      dot = fmaf(qk[1], w4.y, dot);
-      dot = fmaf(qk[2], w4.z, dot);
-      dot = fmaf(qk[3], w4.w, dot);
+      const int kk = p * (PCH * 4) + c * 4;
+      dot = fmaf(qrow[kk], w4.x, dot);
+      dot = fmaf(qrow[kk + 1], w4.y, dot);
+      dot = fmaf(qrow[kk + 2], w4.z, dot);
+      dot = fmaf(qrow[kk + 3], w4.w, dot);
     }
     __builtin_amdgcn_wave_barrier();                           // the next piece overwrites the stage after these reads
     if (p == NP - 1) {
@@ -620,13 +621,27 @@ __global__ __launch_bounds__(256) void knnf_keys_kernel(KnnfArgs a) {
       }
     }
   };
+  // unrolled by U pieces so that the piece number inside a row is a compile-time constant; even pieces live in ra,
+  // odd ones in rb, and piece t + 1 is fetched before piece t is consumed
+  constexpr int U = NP < 2 ? 2 : NP;
   knnf_fetch_piece<CC, NI, RPI, PCH>(ra, xb, cand, 0, 0, lrow, lch, total);
-  for (int t = 0; t < npieces; t += 2) {
-    if (t + 1 < npieces) knnf_fetch_piece<CC, NI, RPI, PCH>(rb, xb, cand, (t + 1) / NP, (t + 1) % NP, lrow, lch, total);
-    consume(t, ra);
-    if (t + 1 < npieces) {
-      if (t + 2 < npieces) knnf_fetch_piece<CC, NI, RPI, PCH>(ra, xb, cand, (t + 2) / NP, (t + 2) % NP, lrow, lch, total);
-      consume(t + 1, rb);
+  auto step = [&](int t, auto uc) __attribute__((always_inline)) {
+    constexpr int u = decltype(uc)::value;
+    if (t + u >= npieces) return;
+    constexpr int pn = (u + 1) % NP;
+    if (t + u + 1 < npieces) {
+      if (u % 2 == 0) knnf_fetch_piece<CC, NI, RPI, PCH>(rb, xb, cand, (t + u + 1) / NP, pn, lrow, lch, total);
+      else knnf_fetch_piece<CC, NI, RPI, PCH>(ra, xb, cand, (t + u + 1) / NP, pn, lrow, lch, total);
+    }
+    if (u % 2 == 0) consume(t + u, std::integral_constant<int, u % NP>{}, ra);
+    else consume(t + u, std::integral_constant<int, u % NP>{}, rb);
+  };
+  for (int t = 0; t < npieces; t += U) {
+    step(t, std::integral_constant<int, 0>{});
+    step(t, std::integral_constant<int, 1>{});
+    if (U > 2) {
+      step(t, std::integral_constant<int, 2 % U>{});
+      step(t, std::integral_constant<int, 3 % U>{});
     }
   }
 }
@@ -823,7 +838,7 @@ GCN_EXPORT int gcn_knn_feature(const float *x_pm, int B, int N, int C, int k1, i
   } else {
 #define KNNF_RERANK2(CCV)                                                                                          \
     {                                                                                                               \
-      constexpr int PBV = (CCV >= 64 ? 16 : 8) * 16;                                                                \
+      constexpr int PBV = 8 * 16;                                                                                   \
       constexpr int LDSV = 4 * (64 * PBV + 2 * KNNF_CAP);                                                           \
       GCN_HIP(hipFuncSetAttribute((const void *)knnf_keys_kernel<CCV>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSV)); \
       knnf_keys_kernel<CCV><<<rgrid, 256, LDSV, st>>>(a);                                                           \
