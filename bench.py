@@ -444,12 +444,17 @@ def main():
 
     torch.manual_seed(0)
     model = dgcnn.PrimitivesEmbeddingDGCNGn(nn_nb=args.k, dtype="bf16").to(dev)
+    # One process per GPU.  With a single rank the whole step (forward, backward, gradient packing, Adam) is captured
+    # ONCE into a HIP graph after the warm-up and the timed steps are replays: ~390 launches cost the host ~7.5 ms per
+    # step otherwise, about as long as the GPU needs to execute them.  Multi-rank runs launch every kernel from the host
+    # (the heads' RCCL all-reduce is started from a backward hook and overlaps the encoder's backward).  A graph of
+    # forward + backward followed by an eager all-reduce was tried with two ranks sharing the one GPU available here:
+    # every step -- and every eager step after the first replay -- stalled for seconds (tools/debug/two_rank_graph.py),
+    # presumably a queue-oversubscription artefact of two processes on one device; it cannot be checked on a real
+    # multi-GPU node from here, so the proven path stays.
+    use_graph = world == 1 and not args.no_graph
     dp = parallel.FlatGradDP(model, world, late=model.encoder.parameters())   # heads' all-reduce overlaps the encoder's backward
     dp.sync_params()
-    # one process per GPU; with a single rank the whole step (forward, backward, gradient packing, Adam) is captured once
-    # into a HIP graph and the timed steps are replays: ~390 launches cost the host ~7.7 ms per step otherwise, about as
-    # long as the GPU needs to execute them (the RCCL all-reduce with its backward hook stays on eager launches)
-    use_graph = world == 1 and not args.no_graph
     # option_new.py:83-90 trains with Adam(lr=1e-3): the same rule as ONE elementwise kernel over the flat parameter /
     # gradient / moment buffers (gcanet_amd/optim.py; torch's multi-tensor launches take 0.2 ms for these 57 tensors)
     from gcanet_amd.optim import FlatAdam
@@ -462,7 +467,7 @@ def main():
     # bf16 weight copies (in the GEMM kernel's padded operand layout): one multi-tensor cast per step, not one per layer
     casts = CastCache(model, pad_k={model.conv3.weight: (model.conv3.weight.shape[1] + 15) // 16 * 16})
 
-    def step():
+    def fwd_bwd():
         dp.zero_grad()
         arena.begin_step()
         casts.refresh()
@@ -470,6 +475,10 @@ def main():
             out = model(pts, nrm)
         loss = loss_of(out)
         loss.backward()
+        return loss
+
+    def step():
+        loss = fwd_bwd()
         dp.all_reduce_grads()
         opt.step()
         return loss
