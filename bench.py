@@ -503,7 +503,6 @@ def main():
     else:
         for _ in range(args.warmup):
             step()
-        _lib.enable_timing(True)                          # per-kernel HIP events ride along with the timed steps
     torch.cuda.synchronize()
     barrier()
     t0 = time.perf_counter()
@@ -515,17 +514,16 @@ def main():
     dt = time.perf_counter() - t0
     if not use_graph:
         loss = out_loss
-        timed_steps = args.steps
-    else:
-        # per-kernel durations: the same step, launched eagerly with HIP events around every entry point, right after
-        # the timed region (a replayed graph has no host-side call to bracket)
-        timed_steps = 3
-        if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
-            torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)   # the capture ran on a side stream
-        _lib.enable_timing(True)
-        for _ in range(timed_steps):
-            step()
-        torch.cuda.synchronize()
+    # per-kernel durations: the same step, launched from the host with HIP events around every entry point, right after
+    # the timed region (a replayed graph has no host-side call to bracket; on the eager path the event records would
+    # ride inside the timed steps)
+    timed_steps = 3
+    if use_graph and hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
+        torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)   # the capture ran on a side stream
+    _lib.enable_timing(True)
+    for _ in range(timed_steps):
+        step()
+    torch.cuda.synchronize()
     timing = _lib.timing_results()
     _lib.enable_timing(False)
     if world > 1:
