@@ -149,7 +149,8 @@ def pmc_traffic(tag):
     ks = json.load(open(path))["kernels"]
     parts = {
         "knn_model[B=8,C=64": ["gcn::knnf_colsum_kernel", "gcn::knnf_prep_kernel", "gcn::knnf_stream_kernel<4, 0>",
-                               "gcn::knnf_stream_kernel<4, 1>", "gcn::knnf_rerank_kernel<64>", "gcn::knnf_fallback_kernel<64>"],
+                               "gcn::knnf_stream_kernel<4, 1>", "gcn::knnf_keys_kernel<64>", "gcn::knnf_rank_kernel<64>",
+                               "gcn::knnf_fallback_kernel<64>"],
         "knn_model[B=8,C=6,": ["gcn::knnn_prep_kernel", "gcn::knnn_sample_kernel", "gcn::knnn_filter_kernel",
                                "gcn::knnn_rerank_kernel"],
         "edgeconv_fwd[B=8,N=8192,k=64,C=64,Cout=128": ["gcn::edgeconv_center_kernel<4, 4>",
