@@ -11,7 +11,7 @@
 //                per-cloud maxima of |ut| and |x|.
 //   2. threshold (knnf_stream_kernel<MODE 0>) for every query a value tau that (almost surely) has at least k
 //                APPROXIMATE squared distances a(q,j) = |ut_q - ut_j|^2 under it, from a 1-in-8 strided sample of
-//                the candidates: the m-th smallest sample value with m ~ k/8 + 6 sqrt(k/8).
+//                the candidates: the m-th smallest sample value with m ~ k/8 + 5 sqrt(k/8).
 //   3. filter    (knnf_stream_kernel<MODE 1>) a(q,j) <= tau for ALL pairs, one bit per pair (B*N*N/8 bytes).
 //   4. re-rank   (knnf_rerank_kernel) one wave per query: expand the bits (~3k candidates), gather their f32 rows,
 //                evaluate the reference's arithmetic exactly (ascending-channel fmaf chain, fl(fl(2 dot - xx_j) -
@@ -808,7 +808,7 @@ GCN_EXPORT int gcn_knn_feature(const float *x_pm, int B, int N, int C, int k1, i
   a.kout = (k2 + a.step - 1) / a.step;
   // rank of the sample order statistic: mean k/8 of the true neighbours fall into the 1-in-8 sample
   const double mu = (double)k2 / KNNF_STRIDE;
-  double sig = 6.0;
+  double sig = 5.0;            // 5 sigma: a query misses its quota about once in 3 million (then the exhaustive kernel serves it)
   if (const char *e = getenv("GCANET_KNN_SIGMA")) sig = atof(e);          // experiment knob (tools/knn_bench.py)
   int m = (int)(mu + sig * __builtin_sqrt(mu) + 2.0);
   if (m > 96) m = 96;
