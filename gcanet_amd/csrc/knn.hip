@@ -339,10 +339,16 @@ static int launch_knn(const KnnArgs &a, int B, hipStream_t st) {
 //   16-candidate blocks XOR-permuted by (r&3) and the fetch undoes it (source-side swizzle).
 typedef __attribute__((ext_vector_type(4))) float knn_f32x4;
 
-template <int CC, int TC, int KPL>   // KPL list registers per query: k <= 64 * KPL
+// FLAGGED (the exhaustive stage of knn_filter.hip when its list is long): `only` (B,N) marks the queries to search and
+// write; a wave none of whose 16 queries is marked only keeps the tile stream going, a workgroup without marked queries
+// leaves at once, and the whole launch is a no-op unless *gate > gate_min.
+template <int CC, int TC, int KPL, bool FLAGGED = false>   // KPL list registers per query: k <= 64 * KPL
 __global__ __launch_bounds__(KPL == 1 ? 512 : 256, KPL == 1 ? 4 : 3) void knn_mfma16_kernel(const float *__restrict__ x, const float *__restrict__ xxg,
                                                             int N, int k, int step, int kout,
-                                                            int64_t *__restrict__ ind, float *__restrict__ val) {
+                                                            int64_t *__restrict__ ind, float *__restrict__ val,
+                                                            const unsigned char *__restrict__ only = nullptr,
+                                                            const unsigned int *__restrict__ gate = nullptr,
+                                                            unsigned int gate_min = 0) {
   constexpr int ROWS = CC + 1;           // + one row of squared norms
   constexpr int RPP = 256 / TC;          // rows per 1-KiB DMA piece
   constexpr int PIECES = (ROWS + RPP - 1) / RPP;
@@ -360,6 +366,14 @@ __global__ __launch_bounds__(KPL == 1 ? 512 : 256, KPL == 1 ? 4 : 3) void knn_mf
   const int q0 = ((lin / (int)gridDim.y) * NW + wave) * 16;
   const float *xb = x + (long)b * CC * N;
   const float *xxb = xxg + (long)b * N;
+
+  bool act = true;                                   // wave-uniform: this wave has queries to search
+  if (FLAGGED) {
+    if (*gate <= gate_min) return;
+    const bool mine = lane < 16 && q0 + lane < N && only[(long)b * N + q0 + lane] != 0;
+    act = __ballot(mine) != 0ull;
+    if (!__syncthreads_or(act ? 1 : 0)) return;
+  }
 
   const int qa = min(q0 + lc, N - 1);
   float afrag[CC / 4];
@@ -410,6 +424,7 @@ __global__ __launch_bounds__(KPL == 1 ? 512 : 256, KPL == 1 ? 4 : 3) void knn_mf
     // dependent chain (-2 %); at CC = 128 the 2 x 32 extra registers cost the fourth wave per SIMD (2.1 -> 3.6 ms)
     constexpr bool PREFETCH_B = CC <= 64;
     float bv[PREFETCH_B ? CC / 4 : 1];
+    if (!FLAGGED || act) {
     if (PREFETCH_B) {
       const float *bcol0 = tb + lg * TC + (TC == 64 ? (((0 ^ lg) << 4) + lc) : lc);
 #pragma unroll
@@ -468,9 +483,11 @@ __global__ __launch_bounds__(KPL == 1 ? 512 : 256, KPL == 1 ? 4 : 3) void knn_mf
         }
       }
     }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
+  if (FLAGGED && !act) return;
 
 #pragma unroll
   for (int r = 0; r < 4; ++r)
@@ -480,7 +497,7 @@ __global__ __launch_bounds__(KPL == 1 ? 512 : 256, KPL == 1 ? 4 : 3) void knn_mf
 #pragma unroll
       for (int sl = 0; sl < KPL; ++sl) {
         const int t = sl * 64 + lane;
-        if (q < N && t < k && (t % step) == 0) {
+        if (q < N && t < k && (t % step) == 0 && (!FLAGGED || only[(long)b * N + q] != 0)) {
           const long o = ((long)b * N + q) * kout + t / step;
           ind[o] = (int64_t)top[r][g].idx[sl];
           if (val) val[o] = -top[r][g].key[sl];
@@ -878,6 +895,24 @@ GCN_EXPORT int gcn_knn_cuda(const float *ref, const float *query, int B, int dim
 }
 
 namespace gcn {
+// Exhaustive exact search of the queries marked in `flag` on the f32 matrix cores (channel-major x_cm), a no-op unless
+// *gate > gate_min (knn_filter.hip, long fallback lists).
+int launch_knn_mfma16_flagged(const float *x_cm, const float *xx, const unsigned char *flag, const unsigned int *gate,
+                              unsigned int gate_min, int B, int N, int C, int k, int step, int kout, int64_t *idx, hipStream_t st) {
+#define GCN_KNN_FL(CCV, TCV)                                                                                       \
+  {                                                                                                                 \
+    constexpr int PIECES = (CCV + 1 + 256 / TCV - 1) / (256 / TCV);                                                 \
+    const int lds = 2 * PIECES * 1024;                                                                              \
+    GCN_HIP(hipFuncSetAttribute((const void *)knn_mfma16_kernel<CCV, TCV, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+    knn_mfma16_kernel<CCV, TCV, 1, true><<<dim3(cdiv(N, 128), B), 512, lds, st>>>(x_cm, xx, N, k, step, kout, idx, nullptr, flag, gate, gate_min); \
+  }
+  if (k > 64 || N < 64 || (N % 4) != 0) { set_error("launch_knn_mfma16_flagged: unsupported shape"); return GCN_EINVAL; }
+  if (C == 32) GCN_KNN_FL(32, 64) else if (C == 64) GCN_KNN_FL(64, 64) else if (C == 128) GCN_KNN_FL(128, 32)
+  else { set_error("launch_knn_mfma16_flagged: unsupported channel count"); return GCN_EINVAL; }
+#undef GCN_KNN_FL
+  return check_launch("knn_mfma16_kernel<flagged>");
+}
+
 int launch_knn_flagged(const float *x_pm, const float *xx, const unsigned char *flag, int B, int N, int C, int k, int step,
                        int kout, int64_t *idx, hipStream_t st) {
   KnnArgs a{};

@@ -19,7 +19,11 @@
 //                -> the lowest index wins ties, as in the oracle -- and VERIFY a posteriori, with the exact k-th key
 //                d_k in hand, that no pair the filter dropped can beat it (bound below).  Fewer than k or more than
 //                CAP candidates, or a failed verification -> the query goes on the fallback list and
-//   5. fallback  knnf_fallback_kernel searches the listed queries exhaustively in the same exact arithmetic.
+//   5. fallback  the listed queries are searched exhaustively in the same exact arithmetic: a short list one query per
+//                workgroup (knnf_fallback_kernel); a long one (> KNNF_LONG_LIST: clouds whose neighbours sit closer
+//                than bf16 resolves, e.g. near-identical features on flat regions) on the f32 matrix cores
+//                (knn.hip: knn_mfma16_kernel in its flagged mode, after a transpose to its channel-major layout) --
+//                1.4 ms for ALL 65536 queries at C = 64 where one workgroup per query took 20 ms.
 // The result is therefore ALWAYS the exact one; the sample statistics only decide how long the fallback list is.
 //
 // Verification bound.  Let D = |x_q - x_j| (reals), Dt = |ut_q - ut_j|.  ut = bf16(fl(x - mu)) = u (1 + d) with
@@ -51,6 +55,7 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 constexpr int KNNF_CAP = 512;        // candidates a query may keep (8 per lane)
 constexpr int KNNF_STRIDE = 8;       // sample every 8th candidate
 constexpr int KNNF_PHASE = 3;
+constexpr unsigned int KNNF_LONG_LIST = 4096;   // flagged queries beyond which the matrix-core kernel does the exhaustive search
 
 struct KnnfArgs {
   const float *x;            // (B,N,C) f32 point-major
@@ -69,6 +74,8 @@ struct KnnfArgs {
   float *keys;               // (B,N,KNNF_CAP) exact keys of a query's candidates (two-kernel re-rank)
   unsigned short *cjs;       // (B,N,KNNF_CAP) their indices
   int *ccnt;                 // (B,N) number of candidates (0: the query went to the fallback list)
+  float *xcm;                // (B,C,N) channel-major copy (long fallback lists only)
+  unsigned int long_list;    // list length beyond which the matrix-core kernel searches the flagged queries
   int B, N, C, Cp, NW, k, step, kout, m_rank;
 };
 
@@ -698,6 +705,7 @@ __global__ __launch_bounds__(256) void knnf_fallback_kernel(KnnfArgs a) {
   __shared__ __attribute__((aligned(16))) float qrow[CC];
   const int lane = lane_id(), wave = wave_id();
   const unsigned int nlist = *a.nflag;
+  if (nlist > a.long_list) return;                         // knn_mfma16_kernel<flagged> serves a long list
   const int N = a.N;
   const int klane = (a.k - 1) & 63;
   for (unsigned int e = blockIdx.x; e < nlist; e += gridDim.x) {
@@ -745,10 +753,26 @@ __global__ __launch_bounds__(256) void knnf_fallback_kernel(KnnfArgs a) {
   }
 }
 
+// Long lists: x (B,N,C) -> xcm (B,C,N), the layout knn_mfma16_kernel streams.  64 points per workgroup through LDS.
+__global__ __launch_bounds__(256) void knnf_transpose_kernel(KnnfArgs a) {
+  __shared__ float t[64][129];
+  if (*a.nflag <= a.long_list) return;
+  const int b = blockIdx.y, r0 = blockIdx.x * 64, C = a.C;
+  const float *xb = a.x + ((long)b * a.N + r0) * C;
+  for (int e = threadIdx.x; e < 64 * C / 4; e += 256) {
+    const float4 v = *reinterpret_cast<const float4 *>(xb + (long)e * 4);
+    const int r = (e * 4) / C, c = (e * 4) % C;
+    t[r][c] = v.x; t[r][c + 1] = v.y; t[r][c + 2] = v.z; t[r][c + 3] = v.w;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  for (int c = threadIdx.x >> 6; c < C; c += 4) a.xcm[((long)b * C + c) * a.N + r0 + lane] = t[lane][c];
+}
+
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct KnnfWs {
-  size_t ut, hn, xx, msum, stat, nflag, theta, tau, bitmap, flag, flist, keys, cjs, ccnt, total;
+  size_t ut, hn, xx, msum, stat, nflag, theta, tau, bitmap, flag, flist, keys, cjs, ccnt, xcm, total;
 };
 
 static KnnfWs knnf_layout(int B, int N, int Cp) {
@@ -768,6 +792,7 @@ static KnnfWs knnf_layout(int B, int N, int Cp) {
   w.keys = o; o += align256(sizeof(float) * (size_t)B * N * KNNF_CAP);
   w.cjs = o; o += align256(sizeof(unsigned short) * (size_t)B * N * KNNF_CAP);
   w.ccnt = o; o += align256(sizeof(int) * (size_t)B * N);
+  w.xcm = o; o += align256(sizeof(float) * (size_t)B * N * Cp);
   w.total = o;
   return w;
 }
@@ -804,6 +829,9 @@ GCN_EXPORT int gcn_knn_feature(const float *x_pm, int B, int N, int C, int k1, i
   a.bitmap = (unsigned int *)(base + w.bitmap); a.flag = (unsigned char *)(base + w.flag); a.idx = idx;
   a.tau = (float *)(base + w.tau); a.nflag = (unsigned int *)(base + w.nflag); a.flist = (unsigned int *)(base + w.flist);
   a.keys = (float *)(base + w.keys); a.cjs = (unsigned short *)(base + w.cjs); a.ccnt = (int *)(base + w.ccnt);
+  a.xcm = (float *)(base + w.xcm);
+  a.long_list = KNNF_LONG_LIST;
+  if (const char *e = getenv("GCANET_KNN_LONG_LIST")) a.long_list = (unsigned int)atol(e);   // test knob: 0 = always the matrix-core search
   a.B = B; a.N = N; a.C = C; a.Cp = Cp; a.NW = N / 32; a.k = k2; a.step = k2 / k1;
   a.kout = (k2 + a.step - 1) / a.step;
   // rank of the sample order statistic: mean k/8 of the true neighbours fall into the 1-in-8 sample
@@ -852,7 +880,12 @@ GCN_EXPORT int gcn_knn_feature(const float *x_pm, int B, int N, int C, int k1, i
   if (C == 32) knnf_fallback_kernel<32><<<256, 256, 0, st>>>(a);
   else if (C == 64) knnf_fallback_kernel<64><<<256, 256, 0, st>>>(a);
   else knnf_fallback_kernel<128><<<256, 256, 0, st>>>(a);
-  return check_launch("knnf_fallback_kernel");
+  rc = check_launch("knnf_fallback_kernel");
+  if (rc) return rc;
+  knnf_transpose_kernel<<<dim3(N / 64, B), 256, 0, st>>>(a);
+  rc = check_launch("knnf_transpose_kernel");
+  if (rc) return rc;
+  return launch_knn_mfma16_flagged(a.xcm, a.xx, a.flag, a.nflag, a.long_list, B, N, C, k2, a.step, a.kout, idx, st);
 }
 
 // diagnostics for tests / tools: number of flagged queries and total candidate bits of the last call (synchronises)

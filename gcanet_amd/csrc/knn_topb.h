@@ -143,6 +143,8 @@ __device__ __forceinline__ void rank_candidates(const unsigned int (&kf)[8], con
 
 // exact kNN in the model's expanded form for the queries whose flag byte is set (the safety net of knn_filter.hip);
 // x_pm (B,N,C) point-major, xx (B,N), flag (B,N), idx (B,N,kout).  Implemented in knn.hip on knn_select_kernel.
+int launch_knn_mfma16_flagged(const float *x_cm, const float *xx, const unsigned char *flag, const unsigned int *gate,
+                              unsigned int gate_min, int B, int N, int C, int k, int step, int kout, int64_t *idx, hipStream_t st);
 int launch_knn_flagged(const float *x_pm, const float *xx, const unsigned char *flag, int B, int N, int C, int k, int step,
                        int kout, int64_t *idx, hipStream_t st);
 

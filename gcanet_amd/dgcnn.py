@@ -30,8 +30,6 @@ def _knn_model(x, k1, k2, metric):
     # 3-D clouds: Morton-tiled kernel with box pruning (identical results).  Not used for the normal metric: its
     # factor (3 - 2 n_i.n_j) in [1,5] inflates the k-th key relative to the Euclidean bound, and with incoherent
     # normals (the synthetic benchmark clouds) more than half of the tiles survive -- slower than the full scan.
-    if k2 <= 64 and N >= 512 and metric == 0 and C == 3:
-        tile_ws = torch.empty(_lib.lib().gcn_knn_tiles_ws_bytes(B, C, N), dtype=torch.uint8, device=x.device)
     # 3-D clouds (xyz, or xyz + normal) at N % 1024 == 0: threshold + filter + re-rank in exact arithmetic
     # (csrc/knn_normal.hip)
     if ((metric == 1 and C == 6) or (metric == 0 and C == 3)) and _lib.lib().gcn_knn_normal_supported(B, N, k2):
@@ -39,6 +37,8 @@ def _knn_model(x, k1, k2, metric):
         if key not in _KNN_WS:        # one scratch buffer per shape and device (calls are stream-ordered)
             _KNN_WS[key] = torch.empty(_lib.lib().gcn_knn_tiles_ws_bytes(B, C, N), dtype=torch.uint8, device=x.device)
         tile_ws = _KNN_WS[key]
+    elif k2 <= 64 and N >= 512 and metric == 0 and C == 3:
+        tile_ws = torch.empty(_lib.lib().gcn_knn_tiles_ws_bytes(B, C, N), dtype=torch.uint8, device=x.device)
     with torch.cuda.device_of(x):
         _lib.call("gcn_knn_model", _lib.ptr(x), B, C, N, k1, k2, metric, _lib.ptr(idx), None, _lib.ptr(xx),
                   _lib.ptr(tile_ws), _lib.stream_of(x), tag="knn_model[B=%d,C=%d,N=%d,k=%d]" % (B, C, N, k2))

@@ -309,6 +309,47 @@ def test_knn_feature_prefilter_matches_exact_kernel_and_oracle(dev, kind, C, N, 
         assert fl.value > 0, "this cloud is meant to exercise the exhaustive path"
 
 
+@pytest.mark.parametrize("kind,C,N,k1,k2,long_list", [
+    ("offset", 64, 4096, 16, 16, None),      # every query flagged, 8192 > the default list limit -> matrix-core search
+    ("offset", 32, 2048, 20, 20, 0), ("offset", 128, 1024, 64, 64, 0), ("halfoffset", 64, 2048, 8, 64, 0),
+    ("normal", 64, 1024, 16, 16, 0),         # nothing flagged: the gated kernels are no-ops
+    ("flat", 64, 8192, 64, 64, None)])
+def test_knn_feature_long_fallback_list_runs_on_the_matrix_cores(dev, monkeypatch, kind, C, N, k1, k2, long_list):
+    """Clouds whose neighbours sit closer than the bf16 prefilter resolves put (nearly) every query on the fallback
+    list; beyond KNNF_LONG_LIST entries the list is searched by the exact f32 matrix-core kernel in its flagged mode
+    (waves without a flagged query idle, unflagged results are left alone).  GCANET_KNN_LONG_LIST=0 forces that kernel
+    for any non-empty list, so partly flagged clouds exercise the per-wave skip and the per-query write mask."""
+    import ctypes
+    from gcanet_amd import _lib, dgcnn
+    if long_list is not None:
+        monkeypatch.setenv("GCANET_KNN_LONG_LIST", str(long_list))
+    if kind == "halfoffset":                 # every other block of 24 points comes from the unresolvable cloud
+        x = _feature_cloud("normal", 2, C, N, 5 + C + N)
+        y = _feature_cloud("offset", 2, C, N, 6 + C + N)
+        sel = (torch.arange(N) // 24) % 2 == 0
+        x[:, :, sel] = y[:, :, sel] - 4.0 + 0.5
+    elif kind == "flat":                     # 64 patches of near-identical features (a CAD part's flat faces)
+        g = torch.Generator().manual_seed(77)
+        x = torch.randn(2, C, 64, generator=g)[:, :, torch.arange(N) % 64] + 1e-4 * torch.randn(2, C, N, generator=g)
+    else:
+        x = _feature_cloud(kind, 2, C, N, 11 + C + N)
+    xd = x.to(dev)
+    new = dgcnn.knn_feature_pm(xd.transpose(1, 2).contiguous(), k1, k2)
+    old = dgcnn._knn_model(xd, k1, k2, 0)                   # the exact kernel, unflagged (itself checked against the oracle)
+    assert torch.equal(new, old)
+    if N <= 4096:
+        np.testing.assert_array_equal(new.cpu().numpy(), oracle.knn_model(x.numpy(), k1, k2, 0))
+    fl, ca = ctypes.c_long(0), ctypes.c_long(0)
+    ws = dgcnn._KNN_WS[(2, N, C, xd.device)]
+    _lib.call("gcn_knn_feature_stats", _lib.ptr(ws), 2, N, C, ctypes.addressof(fl), ctypes.addressof(ca), _lib.stream_of(xd))
+    if kind in ("offset", "flat"):
+        assert fl.value > (4096 if long_list is None else N)
+    if kind == "halfoffset":
+        assert 0 < fl.value < 2 * N
+    if kind == "normal":
+        assert fl.value <= 2
+
+
 def test_knn_feature_unsupported_shapes_use_the_exact_kernel(dev):
     from gcanet_amd import _lib, dgcnn
     lib = _lib.lib()

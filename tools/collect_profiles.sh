@@ -1,0 +1,20 @@
+#!/bin/bash
+# Collect the bench line, the rocprofv3 kernel stats and the two PMC traffic passes of one bench command (GPU box).
+# usage: bash tools/collect_profiles.sh <tag>      -> gpurun_out/<tag>_{bench.json,kernel_stats.csv,pmc_traffic.json}
+set -e
+R=${GRAFT_REPO_ROOT:-/root/repo}
+T=${1:-r02_v5}
+O=$R/gpurun_out
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+python3 $R/bench.py > $O/${T}_bench.json 2> $O/${T}_bench.err
+echo "bench done"
+rm -rf /tmp/ps /tmp/pf /tmp/pw
+rocprofv3 --kernel-trace --stats -f csv -d /tmp/ps -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/${T}_stats.log 2>&1
+cp /tmp/ps/*/*_kernel_stats.csv $O/${T}_kernel_stats.csv
+echo "stats done"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d /tmp/pf -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/${T}_pf.log 2>&1
+echo "fetch done"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d /tmp/pw -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/${T}_pw.log 2>&1
+echo "write done"
+python3 $R/tools/pmc_traffic.py /tmp/pf/*/*counter_collection.csv /tmp/pw/*/*counter_collection.csv $O/${T}_pmc_traffic.json
