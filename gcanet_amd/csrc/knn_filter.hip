@@ -69,7 +69,7 @@ struct KnnfArgs {
   unsigned int *bitmap;      // (B,N,NW)
   unsigned char *flag;       // (B,N)
   unsigned int *nflag;       // [0] number of flagged queries
-  unsigned int *flist;       // (B*N) flagged queries (b*N + q), in arrival order
+  unsigned int *flist;       // (B*N) flagged queries (b*N + q), compacted from `flag` by knnf_list_kernel
   int64_t *idx;              // (B,N,kout)
   float *keys;               // (B,N,KNNF_CAP) exact keys of a query's candidates (two-kernel re-rank)
   unsigned short *cjs;       // (B,N,KNNF_CAP) their indices
@@ -367,7 +367,16 @@ __global__ __launch_bounds__(256, 2) void knnf_stream_kernel(KnnfArgs a) {
       if (lr == 0) {
         const int q = q0 + 4 * lh + (i & 3) + 8 * (i >> 2);
         const float nq = 2.f * hnb[q];                              // |ut_q|^2
-        const float tau = fmaf(2.f, G, nq);                         // approximate squared-distance threshold
+        float tau = fmaf(2.f, G, nq);                               // approximate squared-distance threshold
+        // A threshold inside the bf16 noise floor (sqrt(tau - Delta) <= eta, the re-rank's own expressions) can never
+        // be verified, whatever the k-th key turns out to be: such a query keeps no candidate (the filter passes
+        // nothing below -1e30) and goes straight to the exhaustive stage instead of through a re-rank that must fail.
+        const float xxq = a.xx[(long)b * N + q];
+        const float Rt2 = __uint_as_float(a.stat[b * 2]), X2 = __uint_as_float(a.stat[b * 2 + 1]);
+        const float eta = 0.00198f * (sqrtf(nq) + sqrtf(Rt2)) * 1.0001f;
+        const float big = fmaxf(sqrtf(nq), sqrtf(xxq)) + fmaxf(sqrtf(Rt2), sqrtf(X2));
+        const float Delta = 4.f * (float)(a.C + 8) * 5.9604645e-8f * big * big * 1.0001f;
+        if (sqrtf(fmaxf(tau - Delta, 0.f)) * 0.99999f - eta <= 0.f) tau = -1e30f;
         a.tau[(long)b * N + q] = tau;
         a.theta[(long)b * N + q] = 0.5f * (nq - tau);
       }
@@ -426,7 +435,6 @@ __global__ __launch_bounds__(256) void knnf_rerank_kernel(KnnfArgs a) {
   if (bad) {                                                 // the fallback handles this query exhaustively
     if (lane == 0) {
       a.flag[(long)b * N + q] = 1;
-      a.flist[atomicAdd(a.nflag, 1u)] = (unsigned int)(b * N + q);
     }
     return;
   }
@@ -486,7 +494,6 @@ __global__ __launch_bounds__(256) void knnf_rerank_kernel(KnnfArgs a) {
   const bool proven = !overflow && root > 0.f && (root * root) * 0.99999f - Delta > dk;
   if (lane == 0) {
     a.flag[(long)b * N + q] = proven ? 0 : 1;
-    if (!proven) a.flist[atomicAdd(a.nflag, 1u)] = (unsigned int)(b * N + q);
   }
   if (proven && lane < a.k && (lane % a.step) == 0)
     a.idx[((long)b * N + q) * a.kout + lane / a.step] = (int64_t)(unsigned int)tb.lst;
@@ -554,7 +561,6 @@ __global__ __launch_bounds__(256) void knnf_keys_kernel(KnnfArgs a) {
     if (lane == 0) {
       a.flag[(long)b * N + q] = 1;
       a.ccnt[(long)b * N + q] = 0;
-      a.flist[atomicAdd(a.nflag, 1u)] = (unsigned int)(b * N + q);
     }
     return;
   }
@@ -690,13 +696,29 @@ __global__ __launch_bounds__(256) void knnf_rank_kernel(KnnfArgs a) {
   const bool proven = root > 0.f && (root * root) * 0.99999f - Delta > dk;
   if (lane == 0) {
     a.flag[(long)b * N + q] = proven ? 0 : 1;
-    if (!proven) a.flist[atomicAdd(a.nflag, 1u)] = (unsigned int)(b * N + q);
   }
   if (proven && lane < a.k && (lane % a.step) == 0)
     a.idx[((long)b * N + q) * a.kout + lane / a.step] = (int64_t)(unsigned int)tb.lst;
 }
 
 // ------------------------------------------------------------------ 5. exhaustive exact search of the listed queries
+// The list is compacted from the flag bytes: one atomic per 64 queries that hold a flagged one (an append per flagged
+// query from the re-rank waves queued 65536 same-address atomics, 0.7 ms, when a whole batch was flagged).
+__global__ __launch_bounds__(256) void knnf_list_kernel(KnnfArgs a) {
+  const int lane = lane_id();
+  const long total = (long)a.B * a.N;
+  for (long i0 = ((long)blockIdx.x * 4 + wave_id()) * 64; i0 < total; i0 += (long)gridDim.x * 256) {
+    const long i = i0 + lane;
+    const bool f = i < total && a.flag[i] != 0;
+    const unsigned long long m = __ballot(f);
+    if (!m) continue;
+    unsigned int base = 0;
+    if (lane == 0) base = atomicAdd(a.nflag, (unsigned int)__popcll(m));
+    base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+    if (f) a.flist[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned int)i;
+  }
+}
+
 // One workgroup per listed query; its four waves scan a quarter of the cloud each (rows are consecutive: a batch of 64
 // candidates is 64 contiguous rows), keep a buffered bitonic top-64, and wave 0 merges the four lists.
 template <int CC>
@@ -877,6 +899,7 @@ GCN_EXPORT int gcn_knn_feature(const float *x_pm, int B, int N, int C, int k1, i
   }
   rc = check_launch("knnf_rerank_kernel");
   if (rc) return rc;
+  knnf_list_kernel<<<std::min(256, cdiv(B * N, 256)), 256, 0, st>>>(a);
   if (C == 32) knnf_fallback_kernel<32><<<256, 256, 0, st>>>(a);
   else if (C == 64) knnf_fallback_kernel<64><<<256, 256, 0, st>>>(a);
   else knnf_fallback_kernel<128><<<256, 256, 0, st>>>(a);
