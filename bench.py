@@ -150,7 +150,8 @@ def pmc_traffic(tag):
     parts = {
         "knn_model[B=8,C=64": ["gcn::knnf_colsum_kernel", "gcn::knnf_prep_kernel", "gcn::knnf_stream_kernel<4, 0>",
                                "gcn::knnf_stream_kernel<4, 1>", "gcn::knnf_keys_kernel<64>", "gcn::knnf_rank_kernel<64>",
-                               "gcn::knnf_fallback_kernel<64>"],
+                               "gcn::knnf_list_kernel", "gcn::knnf_fallback_kernel<64>", "gcn::knnf_transpose_kernel",
+                               "gcn::knn_mfma16_kernel<64, 64, 1, true>"],
         "knn_model[B=8,C=6,": ["gcn::knnn_prep_kernel", "gcn::knnn_sample_kernel", "gcn::knnn_filter_kernel",
                                "gcn::knnn_rerank_kernel"],
         "edgeconv_fwd[B=8,N=8192,k=64,C=64,Cout=128": ["gcn::edgeconv_center_kernel<4, 4>",

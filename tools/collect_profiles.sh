@@ -10,11 +10,15 @@ cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $O/${T}_bench.json 2> $O/${T}_bench.err
 echo "bench done"
 rm -rf /tmp/ps /tmp/pf /tmp/pw
-rocprofv3 --kernel-trace --stats -f csv -d /tmp/ps -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/${T}_stats.log 2>&1
+rocprofv3 --kernel-trace --stats -f csv -d /tmp/ps -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-full > $O/${T}_stats.log 2>&1
 cp /tmp/ps/*/*_kernel_stats.csv $O/${T}_kernel_stats.csv
 echo "stats done"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d /tmp/pf -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/${T}_pf.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d /tmp/pf -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-full > $O/${T}_pf.log 2>&1
 echo "fetch done"
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d /tmp/pw -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/${T}_pw.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d /tmp/pw -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-full > $O/${T}_pw.log 2>&1
 echo "write done"
 python3 $R/tools/pmc_traffic.py /tmp/pf/*/*counter_collection.csv /tmp/pw/*/*counter_collection.csv $O/${T}_pmc_traffic.json
+rm -rf /tmp/pfull
+rocprofv3 --kernel-trace --stats -f csv -d /tmp/pfull -- python3 $R/tools/full_profile.py 5 2 > $O/${T}_full.log 2>&1
+cp /tmp/pfull/*/*_kernel_stats.csv $O/${T}_full_workload_kernel_stats.csv
+echo "full workload stats done"

@@ -1,0 +1,15 @@
+"""The literal full workload of bench.py (forward_train + losses + backward + Adam on blob clouds) on its own, for
+rocprofv3 --kernel-trace --stats:  python3 tools/full_profile.py [steps warmup]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+
+steps, warmup = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (5, 2)
+args = bench.parse_args([])
+dev = torch.device("cuda:0")
+torch.cuda.set_device(dev)
+print(bench.full_workload(args, dev, steps=steps, warmup=warmup))

@@ -1,8 +1,8 @@
 """Build profiles/r02_pmc_traffic.json from two rocprofv3 PMC passes of the bench command:
 
   cd /tmp && export TMPDIR=/tmp
-  rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d /tmp/pf -- python3 $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline
-  rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d /tmp/pw -- python3 $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d /tmp/pf -- python3 $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-full
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d /tmp/pw -- python3 $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-full
   python tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> [out.json]
 
 Separate passes, no trace domains besides --kernel-trace (MI355X_MICROARCH.md, HBM section).  FETCH_SIZE / WRITE_SIZE are
@@ -35,7 +35,7 @@ def main():
         ks[name] = {"launches": len(f[name]), "FETCH_SIZE_KB": round(fe, 1), "WRITE_SIZE_KB": round(wr, 1),
                     "hbm_bytes_corrected": int((2 * fe + wr) * 1024)}
     doc = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-trace on `python3 bench.py --steps 2 "
-           "--warmup 1 --no-cpu-baseline`, MI355X. Units: KB per launch (mean over launches). hbm_bytes_corrected = "
+           "--warmup 1 --no-cpu-baseline --no-full`, MI355X. Units: KB per launch (mean over launches). hbm_bytes_corrected = "
            "(2*FETCH_SIZE + WRITE_SIZE)*1024 -- gfx950 FETCH_SIZE counts 16-B/lane streaming reads at half "
            "(MI355X_MICROARCH.md, HBM section); kernels that read with narrower accesses are over-corrected by up to 2x "
            "on the read side.")
