@@ -306,16 +306,19 @@ __global__ __launch_bounds__(256) void gemm_stats_reduce_kernel(const double *__
 }
 
 // ------------------------------------------------------------------ weight gradient: contraction over the rows
-// dW[n][k] = sum_m dY[m][n] X[m][k]   (dY (M,N) bf16, X (M,K) bf16, both row-major; dW (N,K) f32, accumulated with
-// atomics over the split of M).  Workgroup tile = 128 (n) x 128 (k); it walks its slice of M in steps of 64 rows:
+// dW[n][k] = sum_m dY[m][n] X[m][k]   (dY (M,N) bf16, X (M,K) bf16, both row-major; dW (N,K) f32).  M is cut into row
+// slices; every (tile, slice) workgroup stores its partial tile and gemm_wgrad_fold_kernel adds the slices in a fixed
+// order (float atomics onto dW instead: 128 workgroups queueing on the same 16 K addresses made a 45-us floor under
+// the narrow layers, and the sum order changed from run to run).  Workgroup tile = 128 (n) x 128 (k); it walks its slice of M in steps of 64 rows:
 // the two [64 m][128] images are fetched by LDS-DMA as they lie in memory and read COLUMN-wise with
 // ds_read_b64_tr_b16 (per 16 lanes: a 4-row x 16-column block delivered column-major, i.e. 4 consecutive m per lane).
 struct WgradArgs {
   const unsigned short *dY;  // (M,N)
   const unsigned short *X;   // (M,K)
-  float *dW;                 // (N,K) f32, zeroed by the caller
-  float *db;                 // (N) f32 column sums of dY (the bias gradient), zeroed by the caller; may be null
-  long M;
+  float *dW;                 // (N,K) f32
+  float *db;                 // (N) f32 column sums of dY (the bias gradient); may be null
+  float *part;               // (slices, N*K + N) f32 partial results of the row slices
+  long M, mper;              // rows, rows per slice (a multiple of 32)
   int N, K, msplit;
 };
 
@@ -326,12 +329,14 @@ __device__ __forceinline__ bf16x4 lds_tr_read(unsigned int addr) {
 }
 
 __global__ __launch_bounds__(256, 2) void gemm_wgrad_bf16_kernel(WgradArgs a) {
-  // images: [64 rows m][128 cols] bf16 = 256-B rows, 16 KB each, two buffers of (dY, X)
-  constexpr int IMG = 64 * 256;
+  // images: [32 rows m][128 cols] bf16 = 256-B rows, 8 KB each; a stage = (dY, X) = 16 KB; ring of four stages.
+  // Three stages are in flight while one is consumed: a 64-row double buffer left every step waiting for the whole
+  // fetch latency (512 MFMA cycles of work per wave against ~1 us), the matrix pipe was busy 16 % of the time.
+  constexpr int IMG = 32 * 256, STAGE = 2 * IMG, NSTG = 4;
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
   const int lane = lane_id(), wave = wave_id();
   // workgroup id -> (tile, row slice) with ALL tiles of a row slice on one XCD (ids are dealt round-robin to the 8
-  // XCDs): they run concurrently and walk the slice in step, so each [64 x 128] operand image comes from HBM once and
+  // XCDs): they run concurrently and walk the slice in step, so each [32 x 128] operand image comes from HBM once and
   // from that XCD's L2 for the other tiles.  (Tiles of one slice spread over the XCDs re-read dY K/128 times and X
   // N/128 times from memory: 1.3 GB instead of 0.24 GB at N=512, K=1280.)
   const int tiles_n = (a.N + 127) / 128, tiles = tiles_n * ((a.K + 127) / 128);
@@ -340,32 +345,31 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_bf16_kernel(WgradArgs a) {
   if (zslice >= a.msplit) return;
   const int tile_k = tile / tiles_n;
   const int n0 = (tile % tiles_n) * 128, k0 = tile_k * 128;
-  const long mper = ((a.M + a.msplit - 1) / a.msplit + 63) / 64 * 64;
+  const long mper = a.mper;
   const long mb = (long)zslice * mper;
   const long me = mb + mper < a.M ? mb + mper : a.M;
   if (mb >= me) return;
-  const int steps = (int)((me - mb + 63) / 64);
+  const int steps = (int)((me - mb + 31) / 32);
 
-  // DMA: 1 KiB = 4 rows x 256 B: 16 pieces per image; lane -> row p*4 + lane/16, chunk lane%16 (no swizzle: the
-  // transposed reads below take 4-row x 16-column blocks)
-  auto issue = [&](int st, int buf) {
-    const long mrow0 = mb + (long)st * 64;
+  // DMA: 1 KiB = 4 rows x 256 B: 8 pieces per image; wave w fetches pieces w and w + 4 of both images (4 requests per
+  // stage and wave: the s_waitcnt arithmetic below relies on it); lane -> row p*4 + lane/16, chunk lane%16 (no
+  // swizzle: the transposed reads take 4-row x 16-column blocks).  Stages past the end of the slice fetch its last row
+  // again (never read), so that every iteration issues the same number of requests.
+  const int ch = lane & 15;
+  // columns beyond N / K and rows beyond the slice: clamped reads whose products are masked out at the end
+  const int ncol = min(n0 + ch * 8, a.N - 8), kcol = min(k0 + ch * 8, a.K - 8);
+  auto issue = [&](int st) {
+    const long mrow0 = mb + (long)st * 32;
+    unsigned char *base = lds + (st & (NSTG - 1)) * STAGE;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 2; ++i) {
       const int p = wave + i * 4;
-      const int row = p * 4 + (lane >> 4);
-      const int ch = lane & 15;
-      long m = mrow0 + row;
-      const bool ok = m < me;
-      if (!ok) m = me - 1;
-      // columns beyond N / K and rows beyond the slice: clamped reads whose products are masked out at the end
-      const int ncol = min(n0 + ch * 8, a.N - 8), kcol = min(k0 + ch * 8, a.K - 8);
-      const unsigned short *sy = a.dY + m * a.N + ncol;
-      const unsigned short *sx = a.X + m * a.K + kcol;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)sy,
-                                       (__attribute__((address_space(3))) void *)(lds + buf * 2 * IMG + p * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)sx,
-                                       (__attribute__((address_space(3))) void *)(lds + buf * 2 * IMG + IMG + p * 1024), 16, 0, 0);
+      long m = mrow0 + p * 4 + (lane >> 4);
+      if (m > me - 1) m = me - 1;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a.dY + m * a.N + ncol),
+                                       (__attribute__((address_space(3))) void *)(base + p * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a.X + m * a.K + kcol),
+                                       (__attribute__((address_space(3))) void *)(base + IMG + p * 1024), 16, 0, 0);
     }
   };
   // wave tile: 64 (n) x 64 (k): waves 2 x 2; MFMA D[n][k]: A = dY^T fragment (row n, 8 consecutive m), B = X^T fragment
@@ -394,30 +398,48 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_bf16_kernel(WgradArgs a) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) accb[i][e] = 0.f;
 
-  issue(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  // The fragment reads are inline asm: hipcc orders every LDS read it can see behind ALL outstanding LDS-DMA requests
+  // (s_waitcnt vmcnt(0)), and __syncthreads() carries a fence that does the same -- either would empty the ring at
+  // every stage.  Here the waits are explicit: vmcnt(8) for the stage about to be read, lgkmcnt(0) for the fragments.
+  typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+  auto frag = [](u32x2 lo, u32x2 hi) -> bf16x8 {
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+    const u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
+    return __builtin_bit_cast(bf16x8, v);
+  };
+  const unsigned int ay0 = tr_base + (unsigned int)(wn * 2), ax0 = tr_base + (unsigned int)(IMG + wk * 2);
+  issue(0);
+  issue(1);
+  issue(2);
   for (int st = 0; st < steps; ++st) {
-    const int buf = st & 1;
-    if (st + 1 < steps) issue(st + 1, buf ^ 1);
-    const unsigned int by = (unsigned int)(buf * 2 * IMG), bx = by + IMG;
-    const long mrow0 = mb + (long)st * 64;
-    const int mvalid = (int)(me - mrow0 < 64 ? me - mrow0 : 64);
+    // this wave's requests of stage st have landed once at most the 8 of stages st+1, st+2 are outstanding; the barrier
+    // then says the same of every wave's -- and that every wave is done reading stage st-1, whose buffer stage st+3 takes
+    asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    issue(st + 3);
+    const unsigned int sb = (unsigned int)((st & (NSTG - 1)) * STAGE);
+    const long mrow0 = mb + (long)st * 32;
+    const int mvalid = (int)(me - mrow0 < 32 ? me - mrow0 : 32);
 #pragma unroll
-    for (int ms = 0; ms < 4; ++ms) {                          // 16 rows m per MFMA k-step
+    for (int ms = 0; ms < 2; ++ms) {                          // 16 rows m per MFMA k-step
       if (ms * 16 < mvalid) {
-        bf16x8 fy[2], fx[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const unsigned int ry = by + tr_base + (unsigned int)(ms * 16 * 256 + (wn + t * 32) * 2);
-          const unsigned int rx = bx + tr_base + (unsigned int)(ms * 16 * 256 + (wk + t * 32) * 2);
-          const bf16x4 y0 = lds_tr_read(ry), y1 = lds_tr_read(ry + 4 * 256);
-          const bf16x4 x0 = lds_tr_read(rx), x1 = lds_tr_read(rx + 4 * 256);
-          fy[t] = bf16x8{y0[0], y0[1], y0[2], y0[3], y1[0], y1[1], y1[2], y1[3]};
-          fx[t] = bf16x8{x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-        }
+        u32x2 y00, y01, y10, y11, x00, x01, x10, x11;
+        const unsigned int ay = sb + ay0 + (unsigned int)(ms * 16 * 256), ax = sb + ax0 + (unsigned int)(ms * 16 * 256);
+        asm volatile("ds_read_b64_tr_b16 %0, %8\n\t"
+                     "ds_read_b64_tr_b16 %1, %8 offset:1024\n\t"
+                     "ds_read_b64_tr_b16 %4, %9\n\t"
+                     "ds_read_b64_tr_b16 %5, %9 offset:1024\n\t"
+                     "ds_read_b64_tr_b16 %2, %8 offset:64\n\t"
+                     "ds_read_b64_tr_b16 %3, %8 offset:1088\n\t"
+                     "ds_read_b64_tr_b16 %6, %9 offset:64\n\t"
+                     "ds_read_b64_tr_b16 %7, %9 offset:1088\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(y00), "=&v"(y01), "=&v"(y10), "=&v"(y11), "=&v"(x00), "=&v"(x01), "=&v"(x10), "=&v"(x11)
+                     : "v"(ay), "v"(ax)
+                     : "memory");
+        bf16x8 fy[2] = {frag(y00, y01), frag(y10, y11)};
+        const bf16x8 fx[2] = {frag(x00, x01), frag(x10, x11)};
         // rows beyond the slice were clamped copies: zero their contribution (m index = ms*16 + 8*(lane/32) + e)
-        if (mvalid < 64) {
+        if (mvalid < 32) {
 #pragma unroll
           for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -434,11 +456,11 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_bf16_kernel(WgradArgs a) {
         }
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the look-ahead requests past the slice's end
   // D[n][k]: lane column = k (lane%32), register e -> row n = 8 (e>>2) + 4 (lane/32) + (e&3)
   const int lr = lane & 31, lh = lane >> 5;
+  float *pw = a.part + (size_t)zslice * ((size_t)a.N * a.K + a.N);
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -447,18 +469,51 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_bf16_kernel(WgradArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int n = n0 + wn + i * 32 + 8 * (e >> 2) + 4 * lh + (e & 3);
-        if (n < a.N && kk < a.K) atomicAdd(a.dW + (long)n * a.K + kk, acc[i][j][e]);
+        if (n < a.N && kk < a.K) pw[(long)n * a.K + kk] = acc[i][j][e];
       }
     }
   if (with_db && lr == 0) {
+    float *pb = pw + (size_t)a.N * a.K;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int n = n0 + wn + i * 32 + 8 * (e >> 2) + 4 * lh + (e & 3);
-        if (n < a.N) atomicAdd(a.db + n, accb[i][e]);
+        if (n < a.N) pb[n] = accb[i][e];
       }
   }
+}
+
+// (Tried: one WAVE per (128 x 64 tile, row slice) with a private four-stage ring, no barriers, fragment reads of stage
+// s+1 issued before the MFMAs of stage s -- 0.75 fragments per MFMA instead of 1.  Same 200 us at N=512, K=1280.
+// Ablation there: skeleton (prologue, partial tiles, fold) 68 us, + LDS-DMA 78, + fragment reads 15, + MFMAs 51 = the
+// measured total: with one wave per SIMD nothing overlaps -- the address arithmetic of the six requests, the vmcnt wait,
+// the reads and the MFMAs of a stage run back to back.  A 128 x 128 wave tile needs all 256 AGPRs as accumulators and
+// hipcc then moves ~200 registers between the two halves of the register file per stage, with builtins and with
+// "+a"-constrained asm alike.  The four-wave workgroups below at least overlap across waves.)
+// dW (and db) = the slices' partial results added in slice order; thread = 4 consecutive values, 8 slices in flight
+__global__ __launch_bounds__(256) void gemm_wgrad_fold_kernel(const float *__restrict__ part, int slices, long nw, long nb,
+                                                              float *__restrict__ dW, float *__restrict__ db) {
+  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  const long tot = nw + (db ? nb : 0);
+  if (i >= tot) return;
+  const long pitch = nw + nb;
+  const float4 *p = reinterpret_cast<const float4 *>(part + i);
+  float4 s = {0.f, 0.f, 0.f, 0.f};
+  int z = 0;
+  for (; z + 8 <= slices; z += 8) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = p[(long)(z + u) * (pitch / 4)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+  }
+  for (; z < slices; ++z) {
+    const float4 v = p[(long)z * (pitch / 4)];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  float *o = i < nw ? dW + i : db + (i - nw);
+  *reinterpret_cast<float4 *>(o) = s;
 }
 
 }  // namespace gcn
@@ -511,28 +566,49 @@ GCN_EXPORT int gcn_gemm_bf16(const void *A, const void *W, const float *bias, vo
   return check_launch("gemm_stats_reduce_kernel");
 }
 
-GCN_EXPORT int gcn_gemm_wgrad_bf16(const void *dY, const void *X, long M, int N, int K, float *dW, float *db, void *stream) {
-  GCN_REQUIRE(dY && X && dW, "gcn_gemm_wgrad_bf16: null pointer");
-  GCN_REQUIRE(M >= 1 && N >= 8 && K >= 8 && N % 8 == 0 && K % 8 == 0, "gcn_gemm_wgrad_bf16: need N %% 8 == 0 and K %% 8 == 0, got N=%d K=%d", N, K);
-  GCN_REQUIRE(((uintptr_t)dY & 15) == 0 && ((uintptr_t)X & 15) == 0, "gcn_gemm_wgrad_bf16: 16-byte aligned operands");
-  hipStream_t st = (hipStream_t)stream;
-  if (db == dW + (size_t)N * K) {                            // adjacent (the usual case): one fill
-    GCN_HIP(zero_dev(dW, sizeof(float) * ((size_t)N * K + N), st));
-  } else {
-    GCN_HIP(zero_dev(dW, sizeof(float) * (size_t)N * K, st));
-    if (db) GCN_HIP(zero_dev(db, sizeof(float) * (size_t)N, st));
-  }
-  WgradArgs a{};
-  a.dY = (const unsigned short *)dY; a.X = (const unsigned short *)X; a.dW = dW; a.db = db; a.M = M; a.N = N; a.K = K;
-  const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
-  int split = (256 + tiles - 1) / tiles;                     // ~256 workgroups (every split adds N*K float atomics)
+namespace gcn {
+struct WgradPlan { int tiles, split, slices; long mper; };
+static WgradPlan wgrad_plan(long M, int N, int K) {
+  WgradPlan p{};
+  p.tiles = ((N + 127) / 128) * ((K + 127) / 128);
+  int target = 512;                                          // two workgroups per CU
+  if (const char *e = getenv("GCANET_WGRAD_WGS")) target = atoi(e);
+  int split = (target + p.tiles - 1) / p.tiles;
   split = (split + 7) / 8 * 8;                               // one row slice per XCD and round
-  const long maxsplit = (M + 511) / 512;                     // at least 512 rows each
+  if ((long)split * p.tiles > target + target / 4 && split > 8) split -= 8;
+  const long maxsplit = (M + 255) / 256;                     // at least 256 rows each
   if (split > maxsplit) split = (int)maxsplit;
   if (split < 1) split = 1;
-  a.msplit = split;
-  const int LDSB = 2 * 2 * 64 * 256;
+  p.split = split;
+  p.mper = ((M + split - 1) / split + 31) / 32 * 32;
+  p.slices = (int)((M + p.mper - 1) / p.mper);               // non-empty slices (the rounding of mper may drop the last)
+  return p;
+}
+}  // namespace gcn
+
+GCN_EXPORT long gcn_gemm_wgrad_ws_bytes(long M, int N, int K) {
+  if (M < 1 || N < 8 || K < 8) return -1;
+  const WgradPlan p = wgrad_plan(M, N, K);
+  return (long)(sizeof(float) * (size_t)p.slices * ((size_t)N * K + N));
+}
+
+GCN_EXPORT int gcn_gemm_wgrad_bf16(const void *dY, const void *X, long M, int N, int K, float *dW, float *db, void *ws,
+                                   void *stream) {
+  GCN_REQUIRE(dY && X && dW && ws, "gcn_gemm_wgrad_bf16: null pointer");
+  GCN_REQUIRE(M >= 1 && N >= 8 && K >= 8 && N % 8 == 0 && K % 8 == 0, "gcn_gemm_wgrad_bf16: need N %% 8 == 0 and K %% 8 == 0, got N=%d K=%d", N, K);
+  GCN_REQUIRE(((uintptr_t)dY & 15) == 0 && ((uintptr_t)X & 15) == 0 && ((uintptr_t)ws & 15) == 0 && ((uintptr_t)dW & 15) == 0 &&
+              (!db || ((uintptr_t)db & 15) == 0), "gcn_gemm_wgrad_bf16: 16-byte aligned operands");
+  hipStream_t st = (hipStream_t)stream;
+  const WgradPlan p = wgrad_plan(M, N, K);
+  WgradArgs a{};
+  a.dY = (const unsigned short *)dY; a.X = (const unsigned short *)X; a.dW = dW; a.db = db; a.M = M; a.N = N; a.K = K;
+  a.part = (float *)ws; a.msplit = p.slices; a.mper = p.mper;
+  const int LDSB = 4 * 2 * 32 * 256;
   GCN_HIP(hipFuncSetAttribute((const void *)gemm_wgrad_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
-  gemm_wgrad_bf16_kernel<<<tiles * ((split + 7) / 8) * 8, 256, LDSB, st>>>(a);
-  return check_launch("gemm_wgrad_bf16_kernel");
+  gemm_wgrad_bf16_kernel<<<p.tiles * ((p.slices + 7) / 8) * 8, 256, LDSB, st>>>(a);
+  int rc = check_launch("gemm_wgrad_bf16_kernel");
+  if (rc) return rc;
+  const long nw = (long)N * K, nb = N, tot = nw + (db ? nb : 0);
+  gemm_wgrad_fold_kernel<<<(int)((tot / 4 + 255) / 256), 256, 0, st>>>(a.part, p.slices, nw, nb, dW, db);
+  return check_launch("gemm_wgrad_fold_kernel");
 }

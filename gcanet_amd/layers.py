@@ -258,16 +258,24 @@ def _own_wgrad(dy2, x2):
             and x2.shape[1] % 8 == 0 and dy2.shape[0] >= 512 and dy2.is_contiguous() and x2.is_contiguous())
 
 
+_WGRAD_WS = {}
+
+
 def _wgrad_own(dy2, x2, with_bias):
     """(dW (N,K) f32, db (N,) f32 | None) = (dy2^T @ x2, column sums of dy2) in ONE pass over the rows (csrc/gemm.hip):
-    no split-K partial products to add up, no separate reduction for the bias gradient."""
+    the row slices' partial tiles are folded in a fixed order by the same call, the bias gradient rides along."""
     M, N = dy2.shape
     K = x2.shape[1]
-    raw = zeroed_like((N * K + (N if with_bias else 0),), torch.float32, dy2.device)
+    raw = torch.empty(N * K + (N if with_bias else 0), dtype=torch.float32, device=dy2.device)
     dw = raw[:N * K].view(N, K)
     db = raw[N * K:] if with_bias else None
+    need = _lib.lib().gcn_gemm_wgrad_ws_bytes(M, N, K)
+    ws = _WGRAD_WS.get(dy2.device)
+    if ws is None or ws.numel() < need:           # one scratch buffer per device for the row slices' partial results
+        ws = _WGRAD_WS[dy2.device] = torch.empty(need, dtype=torch.uint8, device=dy2.device)   # (calls are stream-ordered)
     with torch.cuda.device_of(dy2):
-        _lib.call("gcn_gemm_wgrad_bf16", _lib.ptr(dy2), _lib.ptr(x2), M, N, K, _lib.ptr(dw), _lib.ptr(db), _lib.stream_of(dy2))
+        _lib.call("gcn_gemm_wgrad_bf16", _lib.ptr(dy2), _lib.ptr(x2), M, N, K, _lib.ptr(dw), _lib.ptr(db), _lib.ptr(ws),
+                  _lib.stream_of(dy2))
     return dw, db
 
 

@@ -524,12 +524,15 @@ int gcn_gn_apply(const void *x, int dtype, const double *gsum, const float *gamm
  * the f32 results for the GroupNorm that follows (needs (N/G) % 32 == 0, rows_per_cloud % 128 == 0, and stats_ws =
  * gcn_gemm_stats_ws_bytes(M, N) bytes of scratch for the per-wave partial sums); feed it to gcn_gn_apply.
  * gcn_gemm_wgrad_bf16: dW (N,K) f32 = dY (M,N)^T . X (M,K), the contraction running down the rows of both row-major
- * operands (fragments by ds_read_b64_tr_b16, M split over workgroups, f32 atomics into the zeroed dW); N % 8 == 0,
- * K % 8 == 0.  db (N) f32 or NULL: the bias gradient (column sums of dY) from the same pass. */
+ * operands (fragments by ds_read_b64_tr_b16; M is cut into row slices whose partial tiles go to ws,
+ * gcn_gemm_wgrad_ws_bytes(M, N, K) bytes, and are added in slice order: no atomics, the same bits every run);
+ * N % 8 == 0, K % 8 == 0, dW / db 16-byte aligned and fully overwritten.  db (N) f32 or NULL: the bias gradient
+ * (column sums of dY) from the same pass. */
 long gcn_gemm_stats_ws_bytes(long M, int N);
 int gcn_gemm_bf16(const void *A, const void *W, const float *bias, void *out, int out_f32, long M, int N, int Np,
                   int K, double *gsum, void *stats_ws, int rows_per_cloud, int G, void *stream);
-int gcn_gemm_wgrad_bf16(const void *dY, const void *X, long M, int N, int K, float *dW, float *db, void *stream);
+long gcn_gemm_wgrad_ws_bytes(long M, int N, int K);
+int gcn_gemm_wgrad_bf16(const void *dY, const void *X, long M, int N, int K, float *dW, float *db, void *ws, void *stream);
 
 /* ------------------------------------------------------------- attention stacks ------ */
 

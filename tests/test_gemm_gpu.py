@@ -70,22 +70,29 @@ def test_gemm_fused_groupnorm_statistics(dev, B, Npts, N, K, G):
 
 
 @pytest.mark.parametrize("M,N,K", [(2048, 256, 256), (4096, 512, 256), (1000, 64, 256), (3000, 16, 256), (2048, 256, 272),
-                                   (2048, 128, 832), (700, 32, 256), (5000, 256, 1024), (1024, 8, 64)])
+                                   (2048, 128, 832), (700, 32, 256), (5000, 256, 1024), (1024, 8, 64), (65536, 64, 256),
+                                   (40000, 512, 1280), (33, 16, 16)])
 def test_gemm_weight_gradient(dev, M, N, K):
     from gcanet_amd import _lib
     g = torch.Generator().manual_seed(M + N + K)
     dY = _bf(torch.randn(M, N, generator=g)).to(dev)
     X = _bf(torch.randn(M, K, generator=g)).to(dev)
     dW = torch.empty(N, K, device=dev)
-    _lib.call("gcn_gemm_wgrad_bf16", _lib.ptr(dY), _lib.ptr(X), M, N, K, _lib.ptr(dW), None, _lib.stream_of(X))
+    ws = torch.empty(_lib.lib().gcn_gemm_wgrad_ws_bytes(M, N, K), dtype=torch.uint8, device=dev)
+    _lib.call("gcn_gemm_wgrad_bf16", _lib.ptr(dY), _lib.ptr(X), M, N, K, _lib.ptr(dW), None, _lib.ptr(ws), _lib.stream_of(X))
     ref = dY.float().t() @ X.float()
     np.testing.assert_allclose(dW.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
     # with the bias gradient (column sums of dY) from the same pass, adjacent and separate accumulators
     raw = torch.empty(N * K + N, device=dev)
-    _lib.call("gcn_gemm_wgrad_bf16", _lib.ptr(dY), _lib.ptr(X), M, N, K, _lib.ptr(raw), _lib.ptr(raw[N * K:]), _lib.stream_of(X))
+    _lib.call("gcn_gemm_wgrad_bf16", _lib.ptr(dY), _lib.ptr(X), M, N, K, _lib.ptr(raw), _lib.ptr(raw[N * K:]), _lib.ptr(ws), _lib.stream_of(X))
     db2 = torch.full((N,), 7.0, device=dev)
-    _lib.call("gcn_gemm_wgrad_bf16", _lib.ptr(dY), _lib.ptr(X), M, N, K, _lib.ptr(dW), _lib.ptr(db2), _lib.stream_of(X))
+    _lib.call("gcn_gemm_wgrad_bf16", _lib.ptr(dY), _lib.ptr(X), M, N, K, _lib.ptr(dW), _lib.ptr(db2), _lib.ptr(ws), _lib.stream_of(X))
     dbr = dY.float().sum(0)
     for got in (raw[N * K:], db2):
         np.testing.assert_allclose(got.cpu().numpy(), dbr.cpu().numpy(), rtol=1e-4, atol=1e-4 * float(dbr.abs().max()) + 1e-5)
     np.testing.assert_allclose(raw[:N * K].view(N, K).cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
+    # slices are added in a fixed order: a second run gives the same bits
+    again = torch.empty_like(raw)
+    _lib.call("gcn_gemm_wgrad_bf16", _lib.ptr(dY), _lib.ptr(X), M, N, K, _lib.ptr(again), _lib.ptr(again[N * K:]), _lib.ptr(ws),
+              _lib.stream_of(X))
+    assert torch.equal(again, raw)

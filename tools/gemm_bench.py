@@ -41,7 +41,9 @@ for N, K in [(512, 1280), (512, 256), (256, 512), (256, 256), (256, 832), (64, 2
     t_lib = timed(lambda: torch.nn.functional.linear(A, W, bb))
     dY = torch.randn(M, N, device=dev).bfloat16()
     raw = torch.empty(N * K + N, device=dev)
-    t_wg = timed(lambda: _lib.call("gcn_gemm_wgrad_bf16", _lib.ptr(dY), _lib.ptr(A), M, N, K, _lib.ptr(raw), _lib.ptr(raw[N * K:]), st))
+    wws = torch.empty(_lib.lib().gcn_gemm_wgrad_ws_bytes(M, N, K), dtype=torch.uint8, device=dev)
+    t_wg = timed(lambda: _lib.call("gcn_gemm_wgrad_bf16", _lib.ptr(dY), _lib.ptr(A), M, N, K, _lib.ptr(raw), _lib.ptr(raw[N * K:]),
+                                   _lib.ptr(wws), st))
     t_wl = timed(lambda: (torch.bmm(dY.view(32, M // 32, N).transpose(1, 2), A.view(32, M // 32, K)).sum(0),
                           dY.sum(0, dtype=torch.float32)))
     fl = 2.0 * M * N * K
