@@ -759,35 +759,62 @@ __global__ __launch_bounds__(1024) void indeg_lds_kernel(const unsigned short *_
 // LeakyReLU+max.  The conv is linear, so y[n,j,:] = att[n,j] * (U[m_j,:] - V[n,:]) with
 // U = Wf.f_key + Wp.p_key (NK rows per cloud) and V = Wp.p_n: the whole key table sits in LDS and the
 // (B,N,k,128) tensor (1 GB at B=8,N=8192,k=30) is never formed.  Same outputs as edgeconv_fwd.
+// NCH = 64-channel blocks a lane carries per pass (2 when Cout % 128 == 0: the per-neighbour (weight, key id) reads
+// and the loop control are shared by two channels); the neighbour loop is unrolled by two so that four key-table reads
+// are in flight per lane (one dependent LDS round trip per neighbour made the loop latency-bound: 185 us at B=8,
+// N=8192, k=30, Cout=128 against ~65 us of VALU work).
+// ROUTED (gamma_route given): GroupNorm's scale has the sign of gamma and LeakyReLU is increasing, so the max over k
+// the block returns comes from max_j y where gamma >= 0 and from min_j y elsewhere -- known before the kernel runs.
+// The key table and V are loaded with the channel's sign folded in (exact), one extreme of s*y is tracked (7 instead of
+// 10 VALU per edge and channel) and s*max is stored to ymax / its position to amax; ymin / amin are not written.
+template <int NCH, bool ROUTED>
 __global__ __launch_bounds__(1024) void keyedge_fwd_kernel(const float *__restrict__ att, const int64_t *__restrict__ kidx,
                                                           const float *__restrict__ U, const float *__restrict__ V,
                                                           int N, int k, int NK, int Cout, int G, int pts_per_block,
                                                           float *__restrict__ ymax, float *__restrict__ ymin,
                                                           unsigned char *__restrict__ amax, unsigned char *__restrict__ amin,
-                                                          double *__restrict__ gsum) {
+                                                          double *__restrict__ gsum, const float *__restrict__ gamma_route) {
   extern __shared__ float u_lds[];  // NK * Cout, then 16 waves x 64 (weight, key id) slots
   const int lane = lane_id(), wave = wave_id();
   const int b = blockIdx.y;
   const float *Ub = U + (long)b * NK * Cout;
-  for (int i = threadIdx.x; i < NK * Cout; i += blockDim.x) u_lds[i] = Ub[i];
+  for (int i = threadIdx.x; i < NK * Cout; i += blockDim.x) {
+    float u = Ub[i];
+    if (ROUTED && gamma_route[i % Cout] < 0.f) u = -u;
+    u_lds[i] = u;
+  }
   __syncthreads();
-  float2 *slot = reinterpret_cast<float2 *>(u_lds + (long)NK * Cout) + wave * 64;
+  float2 *slot = reinterpret_cast<float2 *>(u_lds + (((long)NK * Cout + 3) & ~3L)) + wave * 64;    // 16-byte aligned
   const int n_lo = blockIdx.x * pts_per_block;
   const int n_hi = min(n_lo + pts_per_block, N);
   const int cpg = Cout / G;
-  for (int c0 = 0; c0 < Cout; c0 += 64) {
-    const int c = c0 + lane;
-    const bool cv = c < Cout;
-    float s1 = 0.f, s2 = 0.f;
+  for (int c0 = 0; c0 < Cout; c0 += 64 * NCH) {
+    int c[NCH];
+    bool cv[NCH], neg[NCH];
+    float s1[NCH], s2[NCH];
+#pragma unroll
+    for (int h = 0; h < NCH; ++h) {
+      c[h] = c0 + 64 * h + lane;
+      cv[h] = c[h] < Cout;
+      c[h] = min(c[h], Cout - 1);
+      s1[h] = 0.f; s2[h] = 0.f;
+      neg[h] = ROUTED && gamma_route[c[h]] < 0.f;
+    }
     // the point's k weights / key ids: one lane-parallel load each (lane = slot), read back in the loop -- loading
     // att[pn*k+j] inside it costs a dependent global round trip per iteration (347 -> ~100 us); the NEXT point's
     // operands are fetched while the current point is processed
     const int nstep = (int)(blockDim.x >> 6);
-    float v_n = 0.f, a_n[4] = {0.f, 0.f, 0.f, 0.f};
+    float v_n[NCH], a_n[4] = {0.f, 0.f, 0.f, 0.f};
     int m_n[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int h = 0; h < NCH; ++h) v_n[h] = 0.f;
     auto fetch = [&](int n) {
       const long pn = (long)b * N + min(n, n_hi - 1);
-      v_n = V[pn * Cout + min(c, Cout - 1)];
+#pragma unroll
+      for (int h = 0; h < NCH; ++h) {
+        v_n[h] = V[pn * Cout + c[h]];
+        if (neg[h]) v_n[h] = -v_n[h];
+      }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int jj = min(q * 64 + lane, k - 1);
@@ -799,54 +826,91 @@ __global__ __launch_bounds__(1024) void keyedge_fwd_kernel(const float *__restri
     if (n_lo + wave < n_hi) fetch(n_lo + wave);
     for (int n = n_lo + wave; n < n_hi; n += nstep) {
       const long pn = (long)b * N + n;
-      const float v = v_n;
+      float v[NCH];
+#pragma unroll
+      for (int h = 0; h < NCH; ++h) v[h] = v_n[h];
       float a_l[4];
       int m_l[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) { a_l[q] = a_n[q]; m_l[q] = m_n[q]; }
       if (n + nstep < n_hi) fetch(n + nstep);
-      float mx = -__builtin_inff(), mn = __builtin_inff();
-      int ax = 0, an = 0;
-      const bool via_lds = k <= 64;                    // one broadcast LDS read per neighbour instead of v_readlane pairs
-      if (via_lds) {
+      float mx[NCH], mn[NCH];
+      int ax[NCH], an[NCH];
+#pragma unroll
+      for (int h = 0; h < NCH; ++h) { mx[h] = -__builtin_inff(); mn[h] = __builtin_inff(); ax[h] = 0; an[h] = 0; }
+      auto edge = [&](float a, int m, int j, const float *uv) {
+#pragma unroll
+        for (int h = 0; h < NCH; ++h) {
+          const float y = a * (uv[h] - v[h]);
+          if (y > mx[h]) { mx[h] = y; ax[h] = j; }
+          if (!ROUTED && y < mn[h]) { mn[h] = y; an[h] = j; }
+          s1[h] += y;
+          s2[h] = fmaf(y, y, s2[h]);
+        }
+      };
+      if (k <= 64) {                                   // one broadcast LDS read per neighbour pair instead of v_readlane pairs
         __builtin_amdgcn_wave_barrier();
         if (lane < k) slot[lane] = float2{a_l[0], __int_as_float(m_l[0])};
         __builtin_amdgcn_wave_barrier();
-      }
-      for (int j = 0; j < k; ++j) {
-        float a = 0.f;
-        int m = 0;
-        if (via_lds) {
+        int j = 0;
+        for (; j + 1 < k; j += 2) {
+          const float4 am = *reinterpret_cast<const float4 *>(slot + j);
+          const int m0 = __float_as_int(am.y), m1 = __float_as_int(am.w);
+          float u0[NCH], u1[NCH];
+#pragma unroll
+          for (int h = 0; h < NCH; ++h) { u0[h] = u_lds[m0 * Cout + c[h]]; u1[h] = u_lds[m1 * Cout + c[h]]; }
+          edge(am.x, m0, j, u0);
+          edge(am.z, m1, j + 1, u1);
+        }
+        if (j < k) {
           const float2 am = slot[j];
-          a = am.x; m = __float_as_int(am.y);
-        } else {
+          const int m0 = __float_as_int(am.y);
+          float u0[NCH];
+#pragma unroll
+          for (int h = 0; h < NCH; ++h) u0[h] = u_lds[m0 * Cout + c[h]];
+          edge(am.x, m0, j, u0);
+        }
+      } else {
+        for (int j = 0; j < k; ++j) {
+          float a = 0.f;
+          int m = 0;
 #pragma unroll
           for (int q = 0; q < 4; ++q)
             if ((j >> 6) == q) { a = readlane_f(a_l[q], j & 63); m = readlane_i(m_l[q], j & 63); }
+          float u0[NCH];
+#pragma unroll
+          for (int h = 0; h < NCH; ++h) u0[h] = u_lds[m * Cout + c[h]];
+          edge(a, m, j, u0);
         }
-        const float y = a * (u_lds[m * Cout + min(c, Cout - 1)] - v);
-        if (y > mx) { mx = y; ax = j; }
-        if (y < mn) { mn = y; an = j; }
-        s1 += y;
-        s2 = fmaf(y, y, s2);
       }
-      if (cv) {
-        ymax[pn * Cout + c] = mx; ymin[pn * Cout + c] = mn;
-        if (amax) { amax[pn * Cout + c] = (unsigned char)ax; amin[pn * Cout + c] = (unsigned char)an; }
-      }
+#pragma unroll
+      for (int h = 0; h < NCH; ++h)
+        if (cv[h]) {
+          if (ROUTED) {
+            ymax[pn * Cout + c[h]] = neg[h] ? -mx[h] : mx[h];
+            if (amax) amax[pn * Cout + c[h]] = (unsigned char)ax[h];
+          } else {
+            ymax[pn * Cout + c[h]] = mx[h]; ymin[pn * Cout + c[h]] = mn[h];
+            if (amax) { amax[pn * Cout + c[h]] = (unsigned char)ax[h]; amin[pn * Cout + c[h]] = (unsigned char)an[h]; }
+          }
+        }
     }
     // one f64 atomic pair per GroupNorm group and wave (per-lane same-address f64 atomics serialise)
     const int seg = (cpg % 64) == 0 ? 64 : cpg;
-    if ((seg & (seg - 1)) == 0 && seg <= 64) {
-      double d1 = cv ? (double)s1 : 0.0, d2 = cv ? (double)s2 : 0.0;
-      for (int o = seg >> 1; o >= 1; o >>= 1) { d1 += __shfl_xor(d1, o); d2 += __shfl_xor(d2, o); }
-      if ((lane & (seg - 1)) == 0 && cv) {
-        atomicAdd(gsum + ((long)b * G + c / cpg) * 2, d1);
-        atomicAdd(gsum + ((long)b * G + c / cpg) * 2 + 1, d2);
+#pragma unroll
+    for (int h = 0; h < NCH; ++h) {
+      if (neg[h]) s1[h] = -s1[h];                      // the sums are those of y itself
+      if ((seg & (seg - 1)) == 0 && seg <= 64) {
+        double d1 = cv[h] ? (double)s1[h] : 0.0, d2 = cv[h] ? (double)s2[h] : 0.0;
+        for (int o = seg >> 1; o >= 1; o >>= 1) { d1 += __shfl_xor(d1, o); d2 += __shfl_xor(d2, o); }
+        if ((lane & (seg - 1)) == 0 && cv[h]) {
+          atomicAdd(gsum + ((long)b * G + c[h] / cpg) * 2, d1);
+          atomicAdd(gsum + ((long)b * G + c[h] / cpg) * 2 + 1, d2);
+        }
+      } else if (cv[h]) {
+        atomicAdd(gsum + ((long)b * G + c[h] / cpg) * 2, (double)s1[h]);
+        atomicAdd(gsum + ((long)b * G + c[h] / cpg) * 2 + 1, (double)s2[h]);
       }
-    } else if (cv) {
-      atomicAdd(gsum + ((long)b * G + c / cpg) * 2, (double)s1);
-      atomicAdd(gsum + ((long)b * G + c / cpg) * 2 + 1, (double)s2);
     }
   }
 }
@@ -1155,20 +1219,31 @@ GCN_EXPORT int gcn_reverse_sum(const float *x_pm, const int64_t *idx, int B, int
 
 GCN_EXPORT int gcn_keyedge_fwd(const float *att, const int64_t *kidx, const float *U, const float *V, int B, int N, int k,
                                int NK, int Cout, int G, float *ymax, float *ymin, uint8_t *amax, uint8_t *amin,
-                               double *gsum, void *stream) {
-  GCN_REQUIRE(att && kidx && U && V && ymax && ymin && gsum, "gcn_keyedge_fwd: null pointer");
-  GCN_REQUIRE((amax == nullptr) == (amin == nullptr), "gcn_keyedge_fwd: pass both amax and amin or neither");
+                               double *gsum, const float *gamma_route, void *stream) {
+  GCN_REQUIRE(att && kidx && U && V && ymax && gsum, "gcn_keyedge_fwd: null pointer");
+  GCN_REQUIRE(gamma_route || ymin, "gcn_keyedge_fwd: ymin may be NULL only in routed mode (gamma_route given)");
+  GCN_REQUIRE(gamma_route || (amax == nullptr) == (amin == nullptr), "gcn_keyedge_fwd: pass both amax and amin or neither");
   GCN_REQUIRE(B >= 0 && N >= 1 && k >= 1 && k <= 255 && NK >= 1 && Cout >= 1 && G >= 1 && Cout % G == 0, "gcn_keyedge_fwd: bad shape");
-  const size_t lds = sizeof(float) * (size_t)NK * Cout + 16 * 64 * sizeof(float2);    // key table + per-wave (weight, id) slots
+  const size_t lds = sizeof(float) * (((size_t)NK * Cout + 3) & ~(size_t)3) + 16 * 64 * sizeof(float2);    // key table + per-wave (weight, id) slots
   GCN_REQUIRE(lds <= 150 * 1024, "gcn_keyedge_fwd: key table %zu B exceeds LDS", lds);
   if (B == 0) return GCN_OK;
   hipStream_t st = (hipStream_t)stream;
   GCN_HIP(zero_dev(gsum, sizeof(double) * 2 * B * G, st));
-  GCN_HIP(hipFuncSetAttribute((const void *)keyedge_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int blocks_per_cloud = (256 + B - 1) / B;               // one 16-wave block per CU (the key table is 61 KB)
   if (blocks_per_cloud > (N + 15) / 16) blocks_per_cloud = (N + 15) / 16;
   const int ppb = (N + blocks_per_cloud - 1) / blocks_per_cloud;
-  keyedge_fwd_kernel<<<dim3(cdiv(N, ppb), B), 1024, lds, st>>>(att, kidx, U, V, N, k, NK, Cout, G, ppb, ymax, ymin, amax, amin, gsum);
+  const dim3 grid(cdiv(N, ppb), B);
+#define GCN_KE_FWD(NCHV, RV)                                                                                        \
+  {                                                                                                                 \
+    GCN_HIP(hipFuncSetAttribute((const void *)keyedge_fwd_kernel<NCHV, RV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    keyedge_fwd_kernel<NCHV, RV><<<grid, 1024, lds, st>>>(att, kidx, U, V, N, k, NK, Cout, G, ppb, ymax, ymin, amax, amin, gsum, gamma_route); \
+  }
+  if (Cout % 128 == 0) {
+    if (gamma_route) GCN_KE_FWD(2, true) else GCN_KE_FWD(2, false)
+  } else {
+    if (gamma_route) GCN_KE_FWD(1, true) else GCN_KE_FWD(1, false)
+  }
+#undef GCN_KE_FWD
   return check_launch("keyedge_fwd_kernel");
 }
 

@@ -501,15 +501,16 @@ class KeyEdgeBlockFunction(torch.autograd.Function):
         dev = att.device
         att, kidx, U, V = att.float().contiguous(), kidx.contiguous(), U.float().contiguous(), V.float().contiguous()
         f32 = dict(dtype=torch.float32, device=dev)
-        ymax, ymin = torch.empty(B, N, Cout, **f32), torch.empty(B, N, Cout, **f32)
+        # ROUTED forward: only the extreme GroupNorm+LeakyReLU will select is kept (ymin/amin not produced)
+        ymax = torch.empty(B, N, Cout, **f32)
         amax = torch.empty(B, N, Cout, dtype=torch.uint8, device=dev)
-        amin = torch.empty(B, N, Cout, dtype=torch.uint8, device=dev)
         gsum = _zeroed_like((B, groups, 2), torch.float64, dev)
-        _run("gcn_keyedge_fwd", att, _lib.ptr(att), _lib.ptr(kidx), _lib.ptr(U), _lib.ptr(V), B, N, k, NK, Cout, groups,
-             _lib.ptr(ymax), _lib.ptr(ymin), _lib.ptr(amax), _lib.ptr(amin), _lib.ptr(gsum),
-             tag="keyedge_fwd[B=%d,N=%d,k=%d,NK=%d,Cout=%d]" % (B, N, k, NK, Cout))
         ga, be = gamma.float().contiguous(), beta.float().contiguous()
-        out_cm, out_pm, mean_rstd = _finish(ymax, ymin, gsum, ga, be, B, N, k, Cout, groups, eps, slope, not pm_out, pm_out)
+        _run("gcn_keyedge_fwd", att, _lib.ptr(att), _lib.ptr(kidx), _lib.ptr(U), _lib.ptr(V), B, N, k, NK, Cout, groups,
+             _lib.ptr(ymax), None, _lib.ptr(amax), None, _lib.ptr(gsum), _lib.ptr(ga),
+             tag="keyedge_fwd[B=%d,N=%d,k=%d,NK=%d,Cout=%d]" % (B, N, k, NK, Cout))
+        out_cm, out_pm, mean_rstd = _finish(ymax, None, gsum, ga, be, B, N, k, Cout, groups, eps, slope, not pm_out, pm_out)
+        ymin = amin = torch.empty(0, device=dev)
         ctx.save_for_backward(att, kidx, U, V, ga, be, ymax, ymin, amax, amin, mean_rstd)
         ctx.cfg = (groups, slope, pm_out)
         return out_pm if pm_out else out_cm

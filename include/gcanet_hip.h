@@ -390,10 +390,12 @@ int gcn_reverse_sum(const float *x_pm, const int64_t *idx, int B, int N, int C, 
  * point has k edges to a fixed set of NK key points; the KPAM-scaled Conv2d(131->128) output is
  *   y[b,n,j,:] = att[b,n,j] * (U[b, kidx[b,n,j], :] - V[b,n,:])
  * (U = Wf.f_key + Wp.p_key, V = Wp.p_n; the conv is linear).  att (B,N,k) f32, kidx (B,N,k) int64 in
- * [0,NK), U (B,NK,Cout), V (B,N,Cout).  Outputs as gcn_edgeconv_fwd; feed them to gcn_edgeconv_finish. */
+ * [0,NK), U (B,NK,Cout), V (B,N,Cout).  Outputs as gcn_edgeconv_fwd; feed them to gcn_edgeconv_finish.
+ * gamma_route (Cout) f32 or NULL: as in gcn_edgeconv_fwd, the GroupNorm scale whose sign decides which extreme
+ * the block will use -- only that one is kept (in ymax / amax; ymin and amin may then be NULL and are not written). */
 int gcn_keyedge_fwd(const float *att, const int64_t *kidx, const float *U, const float *V, int B, int N,
                     int k, int NK, int Cout, int G, float *ymax, float *ymin, uint8_t *amax,
-                    uint8_t *amin, double *gsum, void *stream);
+                    uint8_t *amin, double *gsum, const float *gamma_route, void *stream);
 
 /* Backward of gcn_keyedge_fwd given the routed/affine decomposition of the conv-output gradient
  *   dy[b,n,j,c] = coef[b,n,c]*[j == jsel[b,n,c]] + Ac[b,c] + Bc[b,c]*y[b,n,j,c]
