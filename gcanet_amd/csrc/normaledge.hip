@@ -12,13 +12,21 @@ constexpr int NE_F = 7;
 
 // pts (B,N,6) point-major [xyz, normal]; idx (B,N,k) int64; W (Cout,7) f32.  Outputs as gcn_edgeconv_fwd:
 // ymax/ymin (B,N,Cout), amax/amin (B,N,Cout) u8 slots, gsum (B,G,2) f64 sums of y and y^2.  k <= 256.
+// The neighbour loop is VALU-bound: it runs on PAIRS of neighbours with packed f32 (v_pk_fma_f32: the four taps, the
+// sum and the sum of squares of two neighbours per instruction; the pairs lie in LDS as [x_j, x_j+1] so that a
+// broadcast read delivers them in adjacent registers), and in ROUTED mode (gamma_route given, see keyedge_fwd_kernel)
+// only the extreme the sign of gamma selects is tracked, with the sign folded into the weights (exact).
+typedef float ne_f2 __attribute__((ext_vector_type(2)));
+
+template <bool ROUTED>
 __global__ __launch_bounds__(256) void normal_edge_fwd_kernel(const float *__restrict__ pts, const int64_t *__restrict__ idx,
                                                               const float *__restrict__ W, int N, int k, int Cout, int G,
                                                               int pts_per_block, float *__restrict__ ymax,
                                                               float *__restrict__ ymin, unsigned char *__restrict__ amax,
-                                                              unsigned char *__restrict__ amin, double *__restrict__ gsum) {
+                                                              unsigned char *__restrict__ amin, double *__restrict__ gsum,
+                                                              const float *__restrict__ gamma_route) {
   __shared__ double red[128];                 // (group, stat) partial sums of this workgroup, G <= 64
-  __shared__ float4 efs[4][256];              // per wave: the k edge features [angle, dn] of the current point
+  __shared__ float4 efs[4][2][128];           // per wave, per neighbour pair: {ang_j, ang_j+1, d0_j, d0_j+1}, {d1.., d2..}
   const int lane = lane_id(), wave = wave_id();
   int tile, b;
   xcd_tile_cloud(tile, b);
@@ -27,13 +35,21 @@ __global__ __launch_bounds__(256) void normal_edge_fwd_kernel(const float *__res
   const float *pb = pts + (long)b * N * 6;
   if (threadIdx.x < 2 * G) red[threadIdx.x] = 0.0;
   __syncthreads();
+  float *efa = reinterpret_cast<float *>(&efs[wave][0][0]), *efb = reinterpret_cast<float *>(&efs[wave][1][0]);
   for (int c0 = 0; c0 < Cout; c0 += 64) {
     const int c = min(c0 + lane, Cout - 1);
     const bool cv = c0 + lane < Cout;
+    const bool neg = ROUTED && gamma_route[c] < 0.f;
     float w[NE_F];
 #pragma unroll
-    for (int f = 0; f < NE_F; ++f) w[f] = W[c * NE_F + f];
-    float s1 = 0.f, s2 = 0.f;
+    for (int f = 0; f < NE_F; ++f) {
+      w[f] = W[c * NE_F + f];
+      if (neg) w[f] = -w[f];
+    }
+    ne_f2 w2[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) w2[f] = ne_f2{w[f], w[f]};
+    ne_f2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
     for (int n = n_lo + wave; n < n_hi; n += 4) {
       const long pn = (long)b * N + n;
       const float ni0 = pb[(long)n * 6 + 3], ni1 = pb[(long)n * 6 + 4], ni2 = pb[(long)n * 6 + 5];
@@ -48,47 +64,74 @@ __global__ __launch_bounds__(256) void normal_edge_fwd_kernel(const float *__res
         d0[q] = a0 - ni0; d1[q] = a1 - ni1; d2[q] = a2 - ni2;
         if (q * 64 + 64 >= k) break;                                  // wave-uniform
       }
-      // The k edge features go through LDS and come back as ONE broadcast read per neighbour (four v_readlane per
-      // neighbour before: the loop is VALU-bound), and the centre-normal taps, constant over the neighbours, are
-      // summed once per (point, channel).
+      // The k edge features go through LDS and come back as broadcast reads (four v_readlane per neighbour before),
+      // and the centre-normal taps, constant over the neighbours, are summed once per (point, channel).
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        if (q * 64 + lane < k) efs[wave][q * 64 + lane] = float4{ang[q], d0[q], d1[q], d2[q]};
+        const int j = q * 64 + lane;
+        if (j < k) {
+          const int o = (j >> 1) * 4 + (j & 1);
+          efa[o] = ang[q]; efa[o + 2] = d0[q];
+          efb[o] = d1[q]; efb[o + 2] = d2[q];
+        }
         if (q * 64 + 64 >= k) break;
       }
       __builtin_amdgcn_wave_barrier();
       const float base = fmaf(w[6], ni2, fmaf(w[5], ni1, w[4] * ni0));
+      const ne_f2 base2 = {base, base};
       float mx = -__builtin_inff(), mn = __builtin_inff();
       int ax = 0, an = 0;
-      for (int j = 0; j < k; ++j) {
-        const float4 e = efs[wave][j];
-        float y = fmaf(w[0], e.x, base);
-        y = fmaf(w[1], e.y, y); y = fmaf(w[2], e.z, y); y = fmaf(w[3], e.w, y);
+      auto track = [&](float y, int j) {
         if (y > mx) { mx = y; ax = j; }
-        if (y < mn) { mn = y; an = j; }
+        if (!ROUTED && y < mn) { mn = y; an = j; }
+      };
+      int j = 0;
+      for (; j + 1 < k; j += 2) {
+        const float4 ea = efs[wave][0][j >> 1], eb = efs[wave][1][j >> 1];
+        ne_f2 y = __builtin_elementwise_fma(w2[0], ne_f2{ea.x, ea.y}, base2);
+        y = __builtin_elementwise_fma(w2[1], ne_f2{ea.z, ea.w}, y);
+        y = __builtin_elementwise_fma(w2[2], ne_f2{eb.x, eb.y}, y);
+        y = __builtin_elementwise_fma(w2[3], ne_f2{eb.z, eb.w}, y);
+        track(y.x, j);
+        track(y.y, j + 1);
         s1 += y;
-        s2 = fmaf(y, y, s2);
+        s2 = __builtin_elementwise_fma(y, y, s2);
+      }
+      if (j < k) {                                                    // odd k: the last neighbour alone
+        const float4 ea = efs[wave][0][j >> 1], eb = efs[wave][1][j >> 1];
+        float y = fmaf(w[0], ea.x, base);
+        y = fmaf(w[1], ea.z, y); y = fmaf(w[2], eb.x, y); y = fmaf(w[3], eb.z, y);
+        track(y, j);
+        s1.x += y;
+        s2.x = fmaf(y, y, s2.x);
       }
       if (cv) {
-        ymax[pn * Cout + c] = mx; ymin[pn * Cout + c] = mn;
-        amax[pn * Cout + c] = (unsigned char)ax; amin[pn * Cout + c] = (unsigned char)an;
+        if (ROUTED) {
+          ymax[pn * Cout + c] = neg ? -mx : mx;
+          amax[pn * Cout + c] = (unsigned char)ax;
+        } else {
+          ymax[pn * Cout + c] = mx; ymin[pn * Cout + c] = mn;
+          amax[pn * Cout + c] = (unsigned char)ax; amin[pn * Cout + c] = (unsigned char)an;
+        }
       }
     }
-    if (!cv) { s1 = 0.f; s2 = 0.f; }
+    float t1f = s1.x + s1.y, t2f = s2.x + s2.y;
+    if (neg) t1f = -t1f;                                              // the sums are those of y itself
+    if (!cv) { t1f = 0.f; t2f = 0.f; }
     // one f64 atomic pair per GroupNorm group and wave (same-address f64 atomics serialise at ~0.45 us each:
     // a per-lane version of this epilogue cost 7 ms)
     const int seg = (cpg % 64) == 0 ? 64 : cpg;          // lanes per group inside this 64-channel chunk
     if ((seg & (seg - 1)) == 0 && seg <= 64) {
-      double t1 = (double)s1, t2 = (double)s2;
+      double t1 = (double)t1f, t2 = (double)t2f;
       for (int o = seg >> 1; o >= 1; o >>= 1) { t1 += __shfl_xor(t1, o); t2 += __shfl_xor(t2, o); }
       if ((lane & (seg - 1)) == 0 && cv) {
         atomicAdd(&red[(c / cpg) * 2], t1);
         atomicAdd(&red[(c / cpg) * 2 + 1], t2);
       }
     } else if (cv) {
-      atomicAdd(&red[(c / cpg) * 2], (double)s1);
-      atomicAdd(&red[(c / cpg) * 2 + 1], (double)s2);
+      atomicAdd(&red[(c / cpg) * 2], (double)t1f);
+      atomicAdd(&red[(c / cpg) * 2 + 1], (double)t2f);
     }
   }
   __syncthreads();
@@ -202,8 +245,10 @@ __global__ __launch_bounds__(256) void normal_edge_bwd_kernel(const float *__res
 using namespace gcn;
 
 GCN_EXPORT int gcn_normal_edge_fwd(const float *pts, const int64_t *idx, const float *W, int B, int N, int k, int Cout, int G,
-                                   float *ymax, float *ymin, uint8_t *amax, uint8_t *amin, double *gsum, void *stream) {
-  GCN_REQUIRE(pts && idx && W && ymax && ymin && amax && amin && gsum, "gcn_normal_edge_fwd: null pointer");
+                                   float *ymax, float *ymin, uint8_t *amax, uint8_t *amin, double *gsum,
+                                   const float *gamma_route, void *stream) {
+  GCN_REQUIRE(pts && idx && W && ymax && amax && gsum, "gcn_normal_edge_fwd: null pointer");
+  GCN_REQUIRE(gamma_route || (ymin && amin), "gcn_normal_edge_fwd: ymin / amin may be NULL only in routed mode (gamma_route given)");
   GCN_REQUIRE(B >= 0 && N >= 1 && k >= 1 && k <= 256 && Cout >= 1 && G >= 1 && G <= 64 && Cout % G == 0, "gcn_normal_edge_fwd: bad shape");
   if (B == 0) return GCN_OK;
   hipStream_t st = (hipStream_t)stream;
@@ -211,7 +256,10 @@ GCN_EXPORT int gcn_normal_edge_fwd(const float *pts, const int64_t *idx, const f
   int blocks_per_cloud = (1024 + B - 1) / B;
   if (blocks_per_cloud > (N + 3) / 4) blocks_per_cloud = (N + 3) / 4;
   const int ppb = (N + blocks_per_cloud - 1) / blocks_per_cloud;
-  normal_edge_fwd_kernel<<<dim3(cdiv(N, ppb), B), 256, 0, st>>>(pts, idx, W, N, k, Cout, G, ppb, ymax, ymin, amax, amin, gsum);
+  if (gamma_route)
+    normal_edge_fwd_kernel<true><<<dim3(cdiv(N, ppb), B), 256, 0, st>>>(pts, idx, W, N, k, Cout, G, ppb, ymax, ymin, amax, amin, gsum, gamma_route);
+  else
+    normal_edge_fwd_kernel<false><<<dim3(cdiv(N, ppb), B), 256, 0, st>>>(pts, idx, W, N, k, Cout, G, ppb, ymax, ymin, amax, amin, gsum, gamma_route);
   return check_launch("normal_edge_fwd_kernel");
 }
 

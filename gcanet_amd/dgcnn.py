@@ -368,14 +368,15 @@ class NormalEdgeBlockFunction(torch.autograd.Function):
         pts, idx = pts.float().contiguous(), idx.contiguous()
         w = weight.float().reshape(Cout, 7).contiguous()
         f32 = dict(dtype=torch.float32, device=dev)
-        ymax, ymin = torch.empty(B, N, Cout, **f32), torch.empty(B, N, Cout, **f32)
+        # ROUTED forward: only the extreme GroupNorm+LeakyReLU will select is kept (ymin/amin not produced)
+        ymax = torch.empty(B, N, Cout, **f32)
         amax = torch.empty(B, N, Cout, dtype=torch.uint8, device=dev)
-        amin = torch.empty(B, N, Cout, dtype=torch.uint8, device=dev)
         gsum = _zeroed_like((B, groups, 2), torch.float64, dev)
-        _run("gcn_normal_edge_fwd", pts, _lib.ptr(pts), _lib.ptr(idx), _lib.ptr(w), B, N, k, Cout, groups, _lib.ptr(ymax),
-             _lib.ptr(ymin), _lib.ptr(amax), _lib.ptr(amin), _lib.ptr(gsum))
         ga, be = gamma.float().contiguous(), beta.float().contiguous()
-        out_cm, out_pm, mean_rstd = _finish(ymax, ymin, gsum, ga, be, B, N, k, Cout, groups, eps, slope, not pm_out, pm_out)
+        _run("gcn_normal_edge_fwd", pts, _lib.ptr(pts), _lib.ptr(idx), _lib.ptr(w), B, N, k, Cout, groups, _lib.ptr(ymax),
+             None, _lib.ptr(amax), None, _lib.ptr(gsum), _lib.ptr(ga))
+        out_cm, out_pm, mean_rstd = _finish(ymax, None, gsum, ga, be, B, N, k, Cout, groups, eps, slope, not pm_out, pm_out)
+        ymin = amin = torch.empty(0, device=dev)
         ctx.save_for_backward(pts, idx, w, ga, be, ymax, ymin, amax, amin, mean_rstd)
         ctx.cfg = (groups, slope, pm_out, weight.shape)
         return out_pm if pm_out else out_cm

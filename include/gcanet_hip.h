@@ -412,10 +412,11 @@ int gcn_keyedge_bwd(const float *att, const int64_t *kidx, const float *U, const
 /* Normal-feature EdgeConv of M4:164-205,575-577,691-693 without its (B,7,N,k) edge tensor: the feature
  * [clamp(n_i.n_j, +-0.99), n_j - n_i, n_i] is rebuilt in registers from pts (B,N,6) point-major [xyz, normal]
  * and idx (B,N,k) int64; W (Cout,7) f32 = the Conv2d(7->Cout,1x1) weight.  Outputs as gcn_edgeconv_fwd
- * (ymax/ymin (B,N,Cout), amax/amin u8, gsum (B,G,2) f64; feed them to gcn_edgeconv_finish).  k <= 256. */
+ * (ymax/ymin (B,N,Cout), amax/amin u8, gsum (B,G,2) f64; feed them to gcn_edgeconv_finish).  k <= 256.
+ * gamma_route (Cout) f32 or NULL: routed mode as in gcn_edgeconv_fwd / gcn_keyedge_fwd (ymin, amin may be NULL). */
 int gcn_normal_edge_fwd(const float *pts, const int64_t *idx, const float *W, int B, int N, int k, int Cout,
                         int G, float *ymax, float *ymin, uint8_t *amax, uint8_t *amin, double *gsum,
-                        void *stream);
+                        const float *gamma_route, void *stream);
 
 /* Weight-gradient pieces of that block for dy = coef*[j == jsel] + Ac + Bc*y (the block's inputs are the
  * cloud itself and carry no gradient): dWsp (Cout,7) = sum coef * ef[jsel], esum (B,7) = sum_{n,j} ef,

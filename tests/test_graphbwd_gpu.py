@@ -1,6 +1,7 @@
 """Direct C-ABI tests of the graph-aggregation / weight-gradient kernels behind the closed-form EdgeConv backward
 (edgeconv.hip: reverse_sum_lds_kernel, neighbor_sum_kernel; graphbwd.hip: edge_wgrad_kernel) against plain torch
 restatements.  The end-to-end gradient parity vs the reference's autograd lives in test_edgeconv_gpu.py."""
+import numpy as np
 import pytest
 import torch
 
@@ -110,7 +111,7 @@ def test_edge_wgrad_rejects_unsupported(dev):
                   _lib.ptr(t), 1, 1, 32, 64, _lib.ptr(t), _lib.ptr(t), _lib.stream_of(t))
 
 
-@pytest.mark.parametrize("B,N,k", [(2, 300, 16), (1, 257, 80), (2, 64, 64)])
+@pytest.mark.parametrize("B,N,k", [(2, 300, 16), (1, 257, 80), (2, 64, 64), (2, 200, 31), (1, 100, 1), (1, 300, 129)])
 def test_normal_edge_block_matches_materialised(dev, B, N, k):
     """Fused normal-feature EdgeConv (csrc/normaledge.hip) vs the same block on the materialised (B,N,k,7) edge
     feature of get_graph_feature_with_normals_g (M4:164-205) through torch autograd, f32."""
@@ -137,6 +138,31 @@ def test_normal_edge_block_matches_materialised(dev, B, N, k):
         assert (a - b).abs().max().item() <= 2e-4 * max(b.abs().max().item(), 1.0)
 
 
+@pytest.mark.parametrize("B,N,k,Cout", [(2, 300, 16, 64), (1, 200, 33, 96), (1, 260, 200, 128)])
+def test_normal_edge_forward_routed_equals_unrouted_extremes(dev, B, N, k, Cout):
+    """gcn_normal_edge_fwd with gamma_route keeps exactly the extreme (value, position) the two-sided call returns in
+    ymax/amax (gamma >= 0) or ymin/amin (gamma < 0), and the same GroupNorm sums."""
+    from gcanet_amd import _lib
+    g = torch.Generator().manual_seed(N + k)
+    pts = torch.cat([torch.rand(B, N, 3, generator=g), torch.nn.functional.normalize(torch.randn(B, N, 3, generator=g), dim=-1)], -1).to(dev)
+    idx = torch.randint(0, N, (B, N, k), generator=g).to(dev)
+    W = (0.3 * torch.randn(Cout, 7, generator=g)).to(dev)
+    gamma = torch.randn(Cout, generator=g).to(dev)
+    G = 2 if Cout != 96 else 3
+    f = lambda: torch.empty(B, N, Cout, device=dev)
+    u8 = lambda: torch.empty(B, N, Cout, dtype=torch.uint8, device=dev)
+    ymax, ymin, amax, amin, gs = f(), f(), u8(), u8(), torch.empty(B, G, 2, dtype=torch.float64, device=dev)
+    _lib.call("gcn_normal_edge_fwd", _lib.ptr(pts), _lib.ptr(idx), _lib.ptr(W), B, N, k, Cout, G, _lib.ptr(ymax), _lib.ptr(ymin),
+              _lib.ptr(amax), _lib.ptr(amin), _lib.ptr(gs), None, _lib.stream_of(pts))
+    yr, ar, gr = f(), u8(), torch.empty(B, G, 2, dtype=torch.float64, device=dev)
+    _lib.call("gcn_normal_edge_fwd", _lib.ptr(pts), _lib.ptr(idx), _lib.ptr(W), B, N, k, Cout, G, _lib.ptr(yr), None,
+              _lib.ptr(ar), None, _lib.ptr(gr), _lib.ptr(gamma), _lib.stream_of(pts))
+    pos = (gamma >= 0).view(1, 1, Cout)
+    assert torch.equal(yr, torch.where(pos, ymax, ymin))
+    assert torch.equal(ar, torch.where(pos, amax, amin))
+    np.testing.assert_allclose(gr.cpu().numpy(), gs.cpu().numpy(), rtol=1e-6, atol=1e-6)
+
+
 def test_new_entry_points_handle_empty_and_reject_bad_shapes(dev):
     """Empty batches are a no-op (GCN_OK), impossible shapes raise RuntimeError (status int -> exception, never exit)."""
     from gcanet_amd import _lib
@@ -148,7 +174,7 @@ def test_new_entry_points_handle_empty_and_reject_bad_shapes(dev):
     _lib.call("gcn_reverse_sum", _lib.ptr(t), _lib.ptr(i64), 0, 8, 4, 2, _lib.ptr(t), _lib.ptr(t), _lib.ptr(u8), st)
     _lib.call("gcn_topk_rows", _lib.ptr(t), 0, 0, 8, 4, _lib.ptr(t), _lib.ptr(i64), st)
     _lib.call("gcn_normal_edge_fwd", _lib.ptr(t), _lib.ptr(i64), _lib.ptr(t), 0, 8, 4, 8, 2, _lib.ptr(t), _lib.ptr(t),
-              _lib.ptr(u8), _lib.ptr(u8), _lib.ptr(d), st)
+              _lib.ptr(u8), _lib.ptr(u8), _lib.ptr(d), None, st)
     _lib.call("gcn_param_normalise_fwd", _lib.ptr(t), 0, _lib.ptr(t), st)
     _lib.call("gcn_attention_fwd_bf16", _lib.ptr(t), _lib.ptr(t), _lib.ptr(t), None, 0, 0, 4, 4, 32, 1.0, _lib.ptr(t),
               _lib.ptr(t), _lib.ptr(u8), st)
@@ -159,7 +185,7 @@ def test_new_entry_points_handle_empty_and_reject_bad_shapes(dev):
                   _lib.ptr(t), _lib.ptr(t), _lib.ptr(u8), st)                                               # head dim 48
     with pytest.raises(RuntimeError):
         _lib.call("gcn_normal_edge_fwd", _lib.ptr(t), _lib.ptr(i64), _lib.ptr(t), 1, 8, 300, 8, 2, _lib.ptr(t), _lib.ptr(t),
-                  _lib.ptr(u8), _lib.ptr(u8), _lib.ptr(d), st)                                              # k > 256
+                  _lib.ptr(u8), _lib.ptr(u8), _lib.ptr(d), None, st)                                        # k > 256
     torch.cuda.synchronize()
 
 
