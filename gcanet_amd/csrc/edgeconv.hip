@@ -775,8 +775,10 @@ __global__ __launch_bounds__(1024) void keyedge_fwd_kernel(const float *__restri
                                                           unsigned char *__restrict__ amax, unsigned char *__restrict__ amin,
                                                           double *__restrict__ gsum, const float *__restrict__ gamma_route) {
   extern __shared__ float u_lds[];  // NK * Cout, then 16 waves x 64 (weight, key id) slots
+  __shared__ double red[128];       // (group, statistic) sums of this workgroup, G <= 64
   const int lane = lane_id(), wave = wave_id();
   const int b = blockIdx.y;
+  if (threadIdx.x < 128) red[threadIdx.x] = 0.0;
   const float *Ub = U + (long)b * NK * Cout;
   for (int i = threadIdx.x; i < NK * Cout; i += blockDim.x) {
     float u = Ub[i];
@@ -895,7 +897,8 @@ __global__ __launch_bounds__(1024) void keyedge_fwd_kernel(const float *__restri
           }
         }
     }
-    // one f64 atomic pair per GroupNorm group and wave (per-lane same-address f64 atomics serialise)
+    // one LDS f64 atomic pair per GroupNorm group and wave, one global pair per group and WORKGROUP at the end: device
+    // atomics on one address retire ~0.4 us apart, and every wave of the grid gets here at about the same time
     const int seg = (cpg % 64) == 0 ? 64 : cpg;
 #pragma unroll
     for (int h = 0; h < NCH; ++h) {
@@ -904,15 +907,17 @@ __global__ __launch_bounds__(1024) void keyedge_fwd_kernel(const float *__restri
         double d1 = cv[h] ? (double)s1[h] : 0.0, d2 = cv[h] ? (double)s2[h] : 0.0;
         for (int o = seg >> 1; o >= 1; o >>= 1) { d1 += __shfl_xor(d1, o); d2 += __shfl_xor(d2, o); }
         if ((lane & (seg - 1)) == 0 && cv[h]) {
-          atomicAdd(gsum + ((long)b * G + c[h] / cpg) * 2, d1);
-          atomicAdd(gsum + ((long)b * G + c[h] / cpg) * 2 + 1, d2);
+          atomicAdd(&red[(c[h] / cpg) * 2], d1);
+          atomicAdd(&red[(c[h] / cpg) * 2 + 1], d2);
         }
       } else if (cv[h]) {
-        atomicAdd(gsum + ((long)b * G + c[h] / cpg) * 2, (double)s1[h]);
-        atomicAdd(gsum + ((long)b * G + c[h] / cpg) * 2 + 1, (double)s2[h]);
+        atomicAdd(&red[(c[h] / cpg) * 2], (double)s1[h]);
+        atomicAdd(&red[(c[h] / cpg) * 2 + 1], (double)s2[h]);
       }
     }
   }
+  __syncthreads();
+  if (threadIdx.x < 2 * G) atomicAdd(gsum + (long)b * G * 2 + threadIdx.x, red[threadIdx.x]);
 }
 
 
@@ -1223,9 +1228,9 @@ GCN_EXPORT int gcn_keyedge_fwd(const float *att, const int64_t *kidx, const floa
   GCN_REQUIRE(att && kidx && U && V && ymax && gsum, "gcn_keyedge_fwd: null pointer");
   GCN_REQUIRE(gamma_route || ymin, "gcn_keyedge_fwd: ymin may be NULL only in routed mode (gamma_route given)");
   GCN_REQUIRE(gamma_route || (amax == nullptr) == (amin == nullptr), "gcn_keyedge_fwd: pass both amax and amin or neither");
-  GCN_REQUIRE(B >= 0 && N >= 1 && k >= 1 && k <= 255 && NK >= 1 && Cout >= 1 && G >= 1 && Cout % G == 0, "gcn_keyedge_fwd: bad shape");
+  GCN_REQUIRE(B >= 0 && N >= 1 && k >= 1 && k <= 255 && NK >= 1 && Cout >= 1 && G >= 1 && G <= 64 && Cout % G == 0, "gcn_keyedge_fwd: bad shape");
   const size_t lds = sizeof(float) * (((size_t)NK * Cout + 3) & ~(size_t)3) + 16 * 64 * sizeof(float2);    // key table + per-wave (weight, id) slots
-  GCN_REQUIRE(lds <= 150 * 1024, "gcn_keyedge_fwd: key table %zu B exceeds LDS", lds);
+  GCN_REQUIRE(lds <= 148 * 1024, "gcn_keyedge_fwd: key table %zu B exceeds LDS", lds);
   if (B == 0) return GCN_OK;
   hipStream_t st = (hipStream_t)stream;
   GCN_HIP(zero_dev(gsum, sizeof(double) * 2 * B * G, st));

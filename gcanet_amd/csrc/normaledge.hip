@@ -18,15 +18,17 @@ constexpr int NE_F = 7;
 // only the extreme the sign of gamma selects is tracked, with the sign folded into the weights (exact).
 typedef float ne_f2 __attribute__((ext_vector_type(2)));
 
+// Workgroups of 16 waves: the GroupNorm sums leave a workgroup as ONE device atomic per (group, statistic), and all
+// workgroups reach that point together -- with 4-wave workgroups 128 of them queued on each address (~0.4 us apiece).
 template <bool ROUTED>
-__global__ __launch_bounds__(256) void normal_edge_fwd_kernel(const float *__restrict__ pts, const int64_t *__restrict__ idx,
+__global__ __launch_bounds__(1024) void normal_edge_fwd_kernel(const float *__restrict__ pts, const int64_t *__restrict__ idx,
                                                               const float *__restrict__ W, int N, int k, int Cout, int G,
                                                               int pts_per_block, float *__restrict__ ymax,
                                                               float *__restrict__ ymin, unsigned char *__restrict__ amax,
                                                               unsigned char *__restrict__ amin, double *__restrict__ gsum,
                                                               const float *__restrict__ gamma_route) {
   __shared__ double red[128];                 // (group, stat) partial sums of this workgroup, G <= 64
-  __shared__ float4 efs[4][2][128];           // per wave, per neighbour pair: {ang_j, ang_j+1, d0_j, d0_j+1}, {d1.., d2..}
+  extern __shared__ float4 efs[];             // [wave][2][P]: per neighbour pair {ang_j, ang_j+1, d0_j, d0_j+1}, {d1.., d2..}
   const int lane = lane_id(), wave = wave_id();
   int tile, b;
   xcd_tile_cloud(tile, b);
@@ -35,7 +37,9 @@ __global__ __launch_bounds__(256) void normal_edge_fwd_kernel(const float *__res
   const float *pb = pts + (long)b * N * 6;
   if (threadIdx.x < 2 * G) red[threadIdx.x] = 0.0;
   __syncthreads();
-  float *efa = reinterpret_cast<float *>(&efs[wave][0][0]), *efb = reinterpret_cast<float *>(&efs[wave][1][0]);
+  const int P = (k + 1) >> 1;                 // neighbour pairs
+  const float4 *pa = efs + (long)wave * 2 * P, *pbq = pa + P;
+  float *efa = reinterpret_cast<float *>(efs + (long)wave * 2 * P), *efb = efa + 4 * P;
   for (int c0 = 0; c0 < Cout; c0 += 64) {
     const int c = min(c0 + lane, Cout - 1);
     const bool cv = c0 + lane < Cout;
@@ -50,7 +54,7 @@ __global__ __launch_bounds__(256) void normal_edge_fwd_kernel(const float *__res
 #pragma unroll
     for (int f = 0; f < 4; ++f) w2[f] = ne_f2{w[f], w[f]};
     ne_f2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
-    for (int n = n_lo + wave; n < n_hi; n += 4) {
+    for (int n = n_lo + wave; n < n_hi; n += 16) {
       const long pn = (long)b * N + n;
       const float ni0 = pb[(long)n * 6 + 3], ni1 = pb[(long)n * 6 + 4], ni2 = pb[(long)n * 6 + 5];
       float ang[4], d0[4], d1[4], d2[4];
@@ -88,7 +92,7 @@ __global__ __launch_bounds__(256) void normal_edge_fwd_kernel(const float *__res
       };
       int j = 0;
       for (; j + 1 < k; j += 2) {
-        const float4 ea = efs[wave][0][j >> 1], eb = efs[wave][1][j >> 1];
+        const float4 ea = pa[j >> 1], eb = pbq[j >> 1];
         ne_f2 y = __builtin_elementwise_fma(w2[0], ne_f2{ea.x, ea.y}, base2);
         y = __builtin_elementwise_fma(w2[1], ne_f2{ea.z, ea.w}, y);
         y = __builtin_elementwise_fma(w2[2], ne_f2{eb.x, eb.y}, y);
@@ -99,7 +103,7 @@ __global__ __launch_bounds__(256) void normal_edge_fwd_kernel(const float *__res
         s2 = __builtin_elementwise_fma(y, y, s2);
       }
       if (j < k) {                                                    // odd k: the last neighbour alone
-        const float4 ea = efs[wave][0][j >> 1], eb = efs[wave][1][j >> 1];
+        const float4 ea = pa[j >> 1], eb = pbq[j >> 1];
         float y = fmaf(w[0], ea.x, base);
         y = fmaf(w[1], ea.z, y); y = fmaf(w[2], eb.x, y); y = fmaf(w[3], eb.z, y);
         track(y, j);
@@ -253,13 +257,16 @@ GCN_EXPORT int gcn_normal_edge_fwd(const float *pts, const int64_t *idx, const f
   if (B == 0) return GCN_OK;
   hipStream_t st = (hipStream_t)stream;
   GCN_HIP(zero_dev(gsum, sizeof(double) * 2 * B * G, st));
-  int blocks_per_cloud = (1024 + B - 1) / B;
-  if (blocks_per_cloud > (N + 3) / 4) blocks_per_cloud = (N + 3) / 4;
+  int blocks_per_cloud = (256 + B - 1) / B;                // one 16-wave workgroup per CU
+  if (blocks_per_cloud > (N + 15) / 16) blocks_per_cloud = (N + 15) / 16;
   const int ppb = (N + blocks_per_cloud - 1) / blocks_per_cloud;
+  const size_t lds = sizeof(float4) * 16 * 2 * (size_t)((k + 1) / 2);
+  GCN_HIP(hipFuncSetAttribute((const void *)normal_edge_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  GCN_HIP(hipFuncSetAttribute((const void *)normal_edge_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   if (gamma_route)
-    normal_edge_fwd_kernel<true><<<dim3(cdiv(N, ppb), B), 256, 0, st>>>(pts, idx, W, N, k, Cout, G, ppb, ymax, ymin, amax, amin, gsum, gamma_route);
+    normal_edge_fwd_kernel<true><<<dim3(cdiv(N, ppb), B), 1024, lds, st>>>(pts, idx, W, N, k, Cout, G, ppb, ymax, ymin, amax, amin, gsum, gamma_route);
   else
-    normal_edge_fwd_kernel<false><<<dim3(cdiv(N, ppb), B), 256, 0, st>>>(pts, idx, W, N, k, Cout, G, ppb, ymax, ymin, amax, amin, gsum, gamma_route);
+    normal_edge_fwd_kernel<false><<<dim3(cdiv(N, ppb), B), 1024, lds, st>>>(pts, idx, W, N, k, Cout, G, ppb, ymax, ymin, amax, amin, gsum, gamma_route);
   return check_launch("normal_edge_fwd_kernel");
 }
 
