@@ -774,7 +774,7 @@ __global__ __launch_bounds__(1024) void keyedge_fwd_kernel(const float *__restri
                                                           float *__restrict__ ymax, float *__restrict__ ymin,
                                                           unsigned char *__restrict__ amax, unsigned char *__restrict__ amin,
                                                           double *__restrict__ gsum, const float *__restrict__ gamma_route) {
-  extern __shared__ float u_lds[];  // NK * Cout, then 16 waves x 64 (weight, key id) slots
+  extern __shared__ __attribute__((aligned(16))) float u_lds[];  // NK * Cout, then 16 waves x 64 (weight, key id) slots
   __shared__ double red[128];       // (group, statistic) sums of this workgroup, G <= 64
   const int lane = lane_id(), wave = wave_id();
   const int b = blockIdx.y;
@@ -931,6 +931,7 @@ __global__ __launch_bounds__(1024) void keyedge_fwd_kernel(const float *__restri
 //               written here as a dense (N x NK) matrix for one tall-skinny GEMM; dUsp, T1, T2 accumulate in LDS
 //               (B*N*(Cout+2k) float atomics instead of B*N*k*Cout: ds_add_f32 retires 0.33 lane-ops/clk/CU).
 // One wave per point; U, the sparse dU accumulator and the per-key tables live in LDS.
+template <int NCH>
 __global__ __launch_bounds__(1024) void keyedge_bwd_kernel(const float *__restrict__ att, const int64_t *__restrict__ kidx,
                                                           const float *__restrict__ U, const float *__restrict__ V,
                                                           const float *__restrict__ coef, const int64_t *__restrict__ jsel,
@@ -939,21 +940,42 @@ __global__ __launch_bounds__(1024) void keyedge_bwd_kernel(const float *__restri
                                                           int pts_per_block, float *__restrict__ datt, float *__restrict__ dV,
                                                           float *__restrict__ A2, float *__restrict__ dUsp,
                                                           float *__restrict__ T12) {
-  extern __shared__ float lds_f[];  // U | dUsp | UA | UB2 | T1 | T2 | per-wave: att[64], kidx[64], datt_sp[64], row[NKp]
+  // U | dUsp | UA | UB2 | T1, T2 (64-bit fixed point) | per-wave: (att, kidx)[64], datt_sp[64] (64-bit fixed point), row[NKp]
+  // The per-key sums T1, T2 and the per-neighbour sums of datt are scatter-adds with same-address collisions inside a
+  // wave: ds_add_f32 retires 0.33 lane-ops/clk/CU, ds_add_u64 ~3 (tools/micro/lds_atomic_bench.hip) -- as f32 they were
+  // ~60 of this kernel's 187 us.  Scales: 2^S with S from the largest magnitude that can arrive (the workgroup's max
+  // |att| for T1/T2; the wave's max |value| of the current point and pass for datt), so that a sum of 256 terms stays
+  // below 2^58 and the rounding is 2^-50 of that magnitude -- finer than the f32 sums it replaces, and order-free.
+  extern __shared__ __attribute__((aligned(16))) float lds_f[];     // (behind the 4-byte static below: keep it 16-byte aligned)
+  __shared__ unsigned int attmax_s;
   const int NKp = (NK + 63) & ~63;
-  float *u_lds = lds_f, *du_lds = u_lds + NK * Cout;
-  float *ua = du_lds + NK * Cout, *ub2 = ua + NKp, *t1 = ub2 + NKp, *t2 = t1 + NKp;
+  const int UC = (NK * Cout + 3) & ~3;      // table pitch: keeps everything behind it 16-byte aligned
+  float *u_lds = lds_f, *du_lds = u_lds + UC;
+  float *ua = du_lds + UC, *ub2 = ua + NKp;
+  unsigned long long *t1q = reinterpret_cast<unsigned long long *>(ub2 + NKp), *t2q = t1q + NKp;
   const int lane = lane_id(), wave = wave_id();
-  float *wa = t2 + NKp + wave * (192 + NKp);
-  int *wm = reinterpret_cast<int *>(wa + 64);
-  float *wd = wa + 128, *wrow = wa + 192;
+  float2 *wam = reinterpret_cast<float2 *>(reinterpret_cast<float *>(t2q + NKp) + wave * (256 + NKp));     // slot j: (att_j, key id as bits)
+  unsigned long long *wdq = reinterpret_cast<unsigned long long *>(wam + 64);
+  float *wrow = reinterpret_cast<float *>(wdq + 64);
   const int b = blockIdx.y;
+  const int n_lo = blockIdx.x * pts_per_block;
+  const int n_hi = min(n_lo + pts_per_block, N);
   for (int i = threadIdx.x; i < NK * Cout; i += blockDim.x) {
     u_lds[i] = U[(long)b * NK * Cout + i];
     du_lds[i] = 0.f;
   }
-  for (int i = threadIdx.x; i < NKp; i += blockDim.x) { t1[i] = 0.f; t2[i] = 0.f; }
+  for (int i = threadIdx.x; i < NKp; i += blockDim.x) { t1q[i] = 0ull; t2q[i] = 0ull; }
+  wdq[lane] = 0ull;
+  if (threadIdx.x == 0) attmax_s = 0u;
   __syncthreads();
+  {
+    float am = 0.f;
+    const float *ab = att + ((long)b * N + n_lo) * k;
+    for (int i = threadIdx.x; i < (n_hi - n_lo) * k; i += blockDim.x) am = fmaxf(am, fabsf(ab[i]));
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) am = fmaxf(am, __shfl_xor(am, o));
+    if (lane == 0) atomicMax(&attmax_s, __float_as_uint(am));     // non-negative floats order as their bit patterns
+  }
   for (int m = threadIdx.x; m < NK; m += blockDim.x) {
     float sa = 0.f, sb = 0.f;
     for (int c = 0; c < Cout; ++c) {
@@ -965,16 +987,47 @@ __global__ __launch_bounds__(1024) void keyedge_bwd_kernel(const float *__restri
     ub2[m] = sb;
   }
   __syncthreads();
-  const int n_lo = blockIdx.x * pts_per_block;
-  const int n_hi = min(n_lo + pts_per_block, N);
-  for (int n = n_lo + wave; n < n_hi; n += (int)(blockDim.x >> 6)) {
+  auto pow2 = [](int e) -> double { return __longlong_as_double((long long)(1023 + e) << 52); };
+  auto fxq = [](float x, double scale) -> unsigned long long {       // round(x * scale), |x * scale| < 2^51
+    return (unsigned long long)(__double_as_longlong(fma((double)x, scale, 6755399441055744.0)) - 0x4338000000000000LL);
+  };
+  auto fexp = [](float bound) -> int { return (int)((__float_as_uint(bound) >> 23) & 0xffu) - 127; };   // bound < 2^(e+1)
+  const int e_att = fexp(__uint_as_float(attmax_s));
+  const double sc1 = pow2(49 - e_att), sc2 = pow2(48 - 2 * e_att);      // att < 2^(e+1), att^2 < 2^(2e+2)
+  // The NEXT point's operands are requested while the current point is processed (each point otherwise waits out two
+  // dependent global round trips); with one channel pass (Cout <= 64 NCH) that includes its V / coef / jsel rows.
+  const int nstep = (int)(blockDim.x >> 6);
+  const bool jv = lane < k;
+  const bool single = Cout <= 64 * NCH;
+  float a_nx = 0.f, v_nx[NCH], cf_nx[NCH];
+  int m_nx = 0, js_nx[NCH];
+#pragma unroll
+  for (int h = 0; h < NCH; ++h) { v_nx[h] = 0.f; cf_nx[h] = 0.f; js_nx[h] = 0; }
+  auto fetch = [&](int n) {
+    const long pq = (long)b * N + n;
+    a_nx = jv ? att[pq * k + lane] : 0.f;
+    m_nx = jv ? (int)kidx[pq * k + lane] : 0;
+    if (single) {
+#pragma unroll
+      for (int h = 0; h < NCH; ++h) {
+        const int cc = min(64 * h + lane, Cout - 1);
+        v_nx[h] = V[pq * Cout + cc];
+        cf_nx[h] = coef[pq * Cout + cc];
+        js_nx[h] = (int)jsel[pq * Cout + cc];
+      }
+    }
+  };
+  if (n_lo + wave < n_hi) fetch(n_lo + wave);
+  for (int n = n_lo + wave; n < n_hi; n += nstep) {
     const long pn = (long)b * N + n;
-    const bool jv = lane < k;
-    const float a = jv ? att[pn * k + lane] : 0.f;
-    const int m = jv ? (int)kidx[pn * k + lane] : 0;
-    wa[lane] = a;
-    wm[lane] = m;
-    wd[lane] = 0.f;
+    const float a = a_nx;
+    const int m = m_nx;
+    float v_cur[NCH], cf_cur[NCH];
+    int js_cur[NCH];
+#pragma unroll
+    for (int h = 0; h < NCH; ++h) { v_cur[h] = v_nx[h]; cf_cur[h] = cf_nx[h]; js_cur[h] = js_nx[h]; }
+    if (n + nstep < n_hi) fetch(n + nstep);
+    wam[lane] = float2{a, __int_as_float(m)};
     for (int i = lane; i < NKp; i += 64) wrow[i] = 0.f;
     __builtin_amdgcn_wave_barrier();
     float a1 = a, a2 = a * a;
@@ -982,47 +1035,90 @@ __global__ __launch_bounds__(1024) void keyedge_bwd_kernel(const float *__restri
     for (int o = 32; o >= 1; o >>= 1) { a1 += __shfl_xor(a1, o); a2 += __shfl_xor(a2, o); }
     if (jv) {
       wrow[m] = a * a;                       // top-k key ids of one point are distinct
-      atomicAdd(&t1[m], a);
-      atomicAdd(&t2[m], a * a);
+      atomicAdd(&t1q[m], fxq(a, sc1));
+      atomicAdd(&t2q[m], fxq(a * a, sc2));
     }
     __builtin_amdgcn_wave_barrier();
     for (int i = lane; i < NK; i += 64) A2[pn * NK + i] = wrow[i];
-    float va = 0.f, vb2 = 0.f;
-    for (int c0 = 0; c0 < Cout; c0 += 64) {
-      const int c = min(c0 + lane, Cout - 1);
-      const bool cv = c0 + lane < Cout;
-      const float v = V[pn * Cout + c];
-      const float a_c = Ac[(long)b * Cout + c], b_c = Bc[(long)b * Cout + c];
-      const float cf = coef[pn * Cout + c];
-      const int js = (int)jsel[pn * Cout + c];
-      float wu2 = 0.f;
-      for (int j = 0; j < k; ++j) {
-        const float aj = readlane_f(a, j);
-        const int mj = readlane_i(m, j);
-        wu2 = fmaf(aj * aj, u_lds[mj * Cout + c], wu2);
+    float va = 0.f, vb2 = 0.f, dsp = 0.f;
+    // NCH 64-channel blocks per lane and pass (2 when Cout % 128 == 0): the per-neighbour (att, key id) broadcast read and
+    // the loop control serve two channels, and two neighbours are in flight per iteration (same fma order as one by one)
+    for (int c0 = 0; c0 < Cout; c0 += 64 * NCH) {
+      int c[NCH], js[NCH];
+      bool cv[NCH];
+      float v[NCH], a_c[NCH], b_c[NCH], cf[NCH], wu2[NCH];
+#pragma unroll
+      for (int h = 0; h < NCH; ++h) {
+        cv[h] = c0 + 64 * h + lane < Cout;
+        c[h] = min(c0 + 64 * h + lane, Cout - 1);
+        a_c[h] = Ac[(long)b * Cout + c[h]]; b_c[h] = Bc[(long)b * Cout + c[h]];
+        if (single) {
+          v[h] = v_cur[h]; cf[h] = cf_cur[h]; js[h] = js_cur[h];
+        } else {
+          v[h] = V[pn * Cout + c[h]];
+          cf[h] = coef[pn * Cout + c[h]];
+          js[h] = (int)jsel[pn * Cout + c[h]];
+        }
+        wu2[h] = 0.f;
       }
-      const float att_sel = wa[js];
-      const int m_sel = wm[js];
-      const float d_sel = u_lds[m_sel * Cout + c] - v;
-      if (cv) {
-        dV[pn * Cout + c] = -(cf * att_sel + a_c * a1 + b_c * (wu2 - a2 * v));
-        atomicAdd(&wd[js], cf * d_sel);
-        atomicAdd(&du_lds[m_sel * Cout + c], cf * att_sel);
-        va = fmaf(a_c, v, va);
-        vb2 = fmaf(b_c * v, v, vb2);
+      int j = 0;
+      for (; j + 1 < k; j += 2) {
+        const float4 am = *reinterpret_cast<const float4 *>(wam + j);
+        const int m0 = __float_as_int(am.y), m1 = __float_as_int(am.w);
+        const float q0 = am.x * am.x, q1 = am.z * am.z;
+        float u0[NCH], u1[NCH];
+#pragma unroll
+        for (int h = 0; h < NCH; ++h) { u0[h] = u_lds[m0 * Cout + c[h]]; u1[h] = u_lds[m1 * Cout + c[h]]; }
+#pragma unroll
+        for (int h = 0; h < NCH; ++h) { wu2[h] = fmaf(q0, u0[h], wu2[h]); wu2[h] = fmaf(q1, u1[h], wu2[h]); }
       }
+      if (j < k) {
+        const float2 am = wam[j];
+        const int m0 = __float_as_int(am.y);
+        const float q0 = am.x * am.x;
+#pragma unroll
+        for (int h = 0; h < NCH; ++h) wu2[h] = fmaf(q0, u_lds[m0 * Cout + c[h]], wu2[h]);
+      }
+      float val[NCH], vmax = 0.f;
+#pragma unroll
+      for (int h = 0; h < NCH; ++h) {
+        const float2 sel = wam[js[h]];
+        const float att_sel = sel.x;
+        const int m_sel = __float_as_int(sel.y);
+        const float d_sel = u_lds[m_sel * Cout + c[h]] - v[h];
+        val[h] = cv[h] ? cf[h] * d_sel : 0.f;
+        vmax = fmaxf(vmax, fabsf(val[h]));
+        if (cv[h]) {
+          dV[pn * Cout + c[h]] = -(cf[h] * att_sel + a_c[h] * a1 + b_c[h] * (wu2[h] - a2 * v[h]));
+          atomicAdd(&du_lds[m_sel * Cout + c[h]], cf[h] * att_sel);
+          va = fmaf(a_c[h], v[h], va);
+          vb2 = fmaf(b_c[h] * v[h], v[h], vb2);
+        }
+      }
+      // datt's routed part of this pass: sum_{c: js = j} cf * d_js, scattered by js in fixed point
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+      const int e_w = fexp(vmax);
+      const double scw = pow2(49 - e_w);
+#pragma unroll
+      for (int h = 0; h < NCH; ++h)
+        if (cv[h]) atomicAdd(&wdq[js[h]], fxq(val[h], scw));
+      __builtin_amdgcn_wave_barrier();
+      dsp += (float)((double)(long long)wdq[lane] * pow2(e_w - 49));
+      __builtin_amdgcn_wave_barrier();
+      wdq[lane] = 0ull;
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) { va += __shfl_xor(va, o); vb2 += __shfl_xor(vb2, o); }
     __builtin_amdgcn_wave_barrier();
-    if (jv) datt[pn * k + lane] = wd[lane] + (ua[m] - va) + a * (ub2[m] - 2.f * X[pn * NK + m] + vb2);
+    if (jv) datt[pn * k + lane] = dsp + (ua[m] - va) + a * (ub2[m] - 2.f * X[pn * NK + m] + vb2);
     __builtin_amdgcn_wave_barrier();
   }
   __syncthreads();
   for (int i = threadIdx.x; i < NK * Cout; i += blockDim.x) atomicAdd(dUsp + (long)b * NK * Cout + i, du_lds[i]);
   for (int i = threadIdx.x; i < NK; i += blockDim.x) {
-    atomicAdd(T12 + ((long)b * 2) * NK + i, t1[i]);
-    atomicAdd(T12 + ((long)b * 2 + 1) * NK + i, t2[i]);
+    atomicAdd(T12 + ((long)b * 2) * NK + i, (float)((double)(long long)t1q[i] * pow2(e_att - 49)));
+    atomicAdd(T12 + ((long)b * 2 + 1) * NK + i, (float)((double)(long long)t2q[i] * pow2(2 * e_att - 48)));
   }
 }
 
@@ -1268,16 +1364,21 @@ GCN_EXPORT int gcn_keyedge_bwd(const float *att, const int64_t *kidx, const floa
               "gcn_keyedge_bwd: null pointer");
   GCN_REQUIRE(B >= 0 && N >= 1 && k >= 1 && k <= 64 && NK >= 1 && Cout >= 1, "gcn_keyedge_bwd: bad shape (need k <= 64)");
   const int NKp = (NK + 63) & ~63;
-  const size_t lds = sizeof(float) * (2 * (size_t)NK * Cout + 4 * NKp + 16 * (192 + NKp));
+  const size_t lds = sizeof(float) * (2 * (((size_t)NK * Cout + 3) & ~(size_t)3) + 6 * NKp + 16 * (256 + NKp));
   GCN_REQUIRE(lds <= 158 * 1024, "gcn_keyedge_bwd: key tables %zu B exceed LDS", lds);
   if (B == 0) return GCN_OK;
   hipStream_t st = (hipStream_t)stream;
   GCN_HIP(zero_spans(st, {dUsp, sizeof(float) * (size_t)B * NK * Cout}, {T12, sizeof(float) * (size_t)B * 2 * NK}));
-  GCN_HIP(hipFuncSetAttribute((const void *)keyedge_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  GCN_HIP(hipFuncSetAttribute((const void *)keyedge_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  GCN_HIP(hipFuncSetAttribute((const void *)keyedge_bwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int blocks_per_cloud = (256 + B - 1) / B;
   if (blocks_per_cloud > (N + 3) / 4) blocks_per_cloud = (N + 3) / 4;
   const int ppb = (N + blocks_per_cloud - 1) / blocks_per_cloud;
-  keyedge_bwd_kernel<<<dim3(cdiv(N, ppb), B), 1024, lds, st>>>(att, kidx, U, V, coef, jsel, Ac, Bc, X, N, k, NK, Cout, ppb,
-                                                                datt, dV, A2, dUsp, T12);
+  if (Cout % 128 == 0)
+    keyedge_bwd_kernel<2><<<dim3(cdiv(N, ppb), B), 1024, lds, st>>>(att, kidx, U, V, coef, jsel, Ac, Bc, X, N, k, NK, Cout, ppb,
+                                                                     datt, dV, A2, dUsp, T12);
+  else
+    keyedge_bwd_kernel<1><<<dim3(cdiv(N, ppb), B), 1024, lds, st>>>(att, kidx, U, V, coef, jsel, Ac, Bc, X, N, k, NK, Cout, ppb,
+                                                                     datt, dV, A2, dUsp, T12);
   return check_launch("keyedge_bwd_kernel");
 }

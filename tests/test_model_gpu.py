@@ -81,8 +81,8 @@ def test_zero_arena_steps_match_plain_steps(dev):
     """layers.ZeroArena (pre-zeroed accumulators, the library skips their fills): three training steps with the arena give
     the gradients of three steps without it.  f32 model: only the order of atomics differs between the runs -- 1e-4 of
     the largest gradient after the first step; by the third step that noise has gone through two parameter updates
-    (arg-max and near-tie selections may flip), hence the looser 5e-3 there.  A stale (non-zero) accumulator would be
-    off by O(1)."""
+    (arg-max and near-tie selections may flip: 0.2-0.7 % of the largest gradient seen over repeated runs), hence 2e-2
+    there.  A stale (non-zero) accumulator would be off by O(1) in the FIRST step already, which is held to 1e-4."""
     from gcanet_amd import dgcnn
     from gcanet_amd.layers import ZeroArena
     g = torch.Generator().manual_seed(2)
@@ -117,7 +117,7 @@ def test_zero_arena_steps_match_plain_steps(dev):
     l0, f0, g0 = run(False)
     assert ZeroArena.live is None
     assert abs(l1 - l0) <= 1e-4 * abs(l0)
-    for ga, gb, tol in ((f1, f0, 1e-4), (g1, g0, 5e-3)):
+    for ga, gb, tol in ((f1, f0, 1e-4), (g1, g0, 2e-2)):
         for n_ in gb:
             d = (ga[n_] - gb[n_]).abs().max().item()
             assert d <= tol * max(gb[n_].abs().max().item(), 1e-6) + 1e-7, (n_, tol)
