@@ -143,9 +143,11 @@ __global__ __launch_bounds__(1024) void normal_edge_fwd_kernel(const float *__re
 }
 
 // Weight-gradient pieces of the block for dy = coef*[j == jsel] + Ac + Bc*y (the inputs carry no gradient):
-//   dWsp[c,f] += coef[n,c] * ef[n, jsel[n,c], f];   esum[b,f] = sum_{n,j} ef;   gram[b,f,g] = sum_{n,j} ef_f ef_g
-// (dW = dWsp + Ac^T esum + sum_b Bc_b o (W gram_b) is finished by the caller: 64x7 numbers).  k <= 64 per pass.
-__global__ __launch_bounds__(256) void normal_edge_bwd_kernel(const float *__restrict__ pts, const int64_t *__restrict__ idx,
+//   dWsp[b,c,f] = sum_n coef[n,c] * ef[n, jsel[n,c], f];   esum[b,f] = sum_{n,j} ef;   gram[b,f,g] = sum_{n,j} ef_f ef_g
+// (dW = sum_b dWsp_b + Ac^T esum + sum_b Bc_b o (W gram_b) is finished by the caller: 64x7 numbers).  k <= 64 per pass.
+// 16-wave workgroups and per-CLOUD accumulators: every workgroup closes with one device atomic per output, and they all
+// get there together -- 512 four-wave workgroups on the same 448 addresses spent most of the kernel's 72 us queueing.
+__global__ __launch_bounds__(1024) void normal_edge_bwd_kernel(const float *__restrict__ pts, const int64_t *__restrict__ idx,
                                                               const float *__restrict__ coef, const int64_t *__restrict__ jsel,
                                                               int N, int k, int Cout, int pts_per_block,
                                                               float *__restrict__ dWsp, float *__restrict__ esum,
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(256) void normal_edge_bwd_kernel(const float *__res
 #pragma unroll
     for (int f = 0; f < NE_F; ++f) dw[h][f] = 0.f;
 
-  for (int n = n_lo + wave; n < n_hi; n += 4) {
+  for (int n = n_lo + wave; n < n_hi; n += 16) {
     const long pn = (long)b * N + n;
     const float ni0 = pb[(long)n * 6 + 3], ni1 = pb[(long)n * 6 + 4], ni2 = pb[(long)n * 6 + 5];
     for (int j0 = 0; j0 < k; j0 += 64) {
@@ -205,10 +207,10 @@ __global__ __launch_bounds__(256) void normal_edge_bwd_kernel(const float *__res
       }
     }
   }
-  // workgroup-level sums in LDS first: 1024 blocks x 4 waves of same-address global float atomics were 0.5 ms
+  // workgroup-level sums in LDS first
   __shared__ float red[128 * NE_F + NE_F + NE_F * NE_F];
   float *rdw = red, *res = red + 128 * NE_F, *rgr = res + NE_F;
-  for (int i = threadIdx.x; i < 128 * NE_F + NE_F + NE_F * NE_F; i += 256) red[i] = 0.f;
+  for (int i = threadIdx.x; i < 128 * NE_F + NE_F + NE_F * NE_F; i += 1024) red[i] = 0.f;
   __syncthreads();
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
@@ -239,7 +241,7 @@ __global__ __launch_bounds__(256) void normal_edge_bwd_kernel(const float *__res
       }
     }
   __syncthreads();
-  for (int i = threadIdx.x; i < Cout * NE_F; i += 256) atomicAdd(dWsp + i, rdw[i]);
+  for (int i = threadIdx.x; i < Cout * NE_F; i += 1024) atomicAdd(dWsp + (long)b * Cout * NE_F + i, rdw[i]);
   if (threadIdx.x < NE_F) atomicAdd(esum + (long)b * NE_F + threadIdx.x, res[threadIdx.x]);
   if (threadIdx.x < NE_F * NE_F) atomicAdd(gram + (long)b * NE_F * NE_F + threadIdx.x, rgr[threadIdx.x]);
 }
@@ -275,11 +277,11 @@ GCN_EXPORT int gcn_normal_edge_bwd(const float *pts, const int64_t *idx, const f
   GCN_REQUIRE(pts && idx && coef && jsel && dWsp && esum && gram, "gcn_normal_edge_bwd: null pointer");
   GCN_REQUIRE(B >= 0 && N >= 1 && k >= 1 && Cout >= 1 && Cout <= 128, "gcn_normal_edge_bwd: bad shape (Cout <= 128)");
   hipStream_t st = (hipStream_t)stream;
-  if (B == 0) { GCN_HIP(zero_spans(st, {dWsp, sizeof(float) * Cout * NE_F})); return GCN_OK; }
-  GCN_HIP(zero_spans(st, {dWsp, sizeof(float) * Cout * NE_F}, {esum, sizeof(float) * B * NE_F}, {gram, sizeof(float) * B * NE_F * NE_F}));
-  int blocks_per_cloud = (512 + B - 1) / B;
-  if (blocks_per_cloud > (N + 3) / 4) blocks_per_cloud = (N + 3) / 4;
+  if (B == 0) return GCN_OK;
+  GCN_HIP(zero_spans(st, {dWsp, sizeof(float) * (size_t)B * Cout * NE_F}, {esum, sizeof(float) * B * NE_F}, {gram, sizeof(float) * B * NE_F * NE_F}));
+  int blocks_per_cloud = (256 + B - 1) / B;
+  if (blocks_per_cloud > (N + 15) / 16) blocks_per_cloud = (N + 15) / 16;
   const int ppb = (N + blocks_per_cloud - 1) / blocks_per_cloud;
-  normal_edge_bwd_kernel<<<dim3(cdiv(N, ppb), B), 256, 0, st>>>(pts, idx, coef, jsel, N, k, Cout, ppb, dWsp, esum, gram);
+  normal_edge_bwd_kernel<<<dim3(cdiv(N, ppb), B), 1024, 0, st>>>(pts, idx, coef, jsel, N, k, Cout, ppb, dWsp, esum, gram);
   return check_launch("normal_edge_bwd_kernel");
 }

@@ -391,11 +391,12 @@ class NormalEdgeBlockFunction(torch.autograd.Function):
         jsel, coef, Ac, Bc, dgamma, dbeta, _ = _route_backward_fused(dpm, gamma, beta, ymax, ymin, amax, amin, mean_rstd, G,
                                                                      slope, float((Cout // G) * N * k), want_jsel=True)
         f32 = dict(dtype=torch.float32, device=pts.device)
-        raw = _zeroed_like((Cout * 7 + B * 7 + B * 49,), torch.float32, pts.device)        # adjacent accumulators: one zero fill in the library
-        dWsp, esum, gram = raw[:Cout * 7].view(Cout, 7), raw[Cout * 7:Cout * 7 + B * 7].view(B, 7), raw[Cout * 7 + B * 7:].view(B, 7, 7)
+        raw = _zeroed_like((B * Cout * 7 + B * 7 + B * 49,), torch.float32, pts.device)    # adjacent accumulators: one zero fill in the library
+        n1, n2 = B * Cout * 7, B * Cout * 7 + B * 7
+        dWsp, esum, gram = raw[:n1].view(B, Cout, 7), raw[n1:n2].view(B, 7), raw[n2:].view(B, 7, 7)
         _run("gcn_normal_edge_bwd", pts, _lib.ptr(pts), _lib.ptr(idx), _lib.ptr(coef), _lib.ptr(jsel), B, N, k, Cout,
              _lib.ptr(dWsp), _lib.ptr(esum), _lib.ptr(gram))
-        dW = dWsp + Ac.t() @ esum + torch.einsum("bo,og,bgf->of", Bc, W, gram)
+        dW = dWsp.sum(0) + Ac.t() @ esum + torch.einsum("bo,og,bgf->of", Bc, W, gram)
         return None, None, dW.reshape(wshape), dgamma, dbeta, None, None, None, None
 
 

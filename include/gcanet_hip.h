@@ -419,9 +419,9 @@ int gcn_normal_edge_fwd(const float *pts, const int64_t *idx, const float *W, in
                         const float *gamma_route, void *stream);
 
 /* Weight-gradient pieces of that block for dy = coef*[j == jsel] + Ac + Bc*y (the block's inputs are the
- * cloud itself and carry no gradient): dWsp (Cout,7) = sum coef * ef[jsel], esum (B,7) = sum_{n,j} ef,
+ * cloud itself and carry no gradient): dWsp (B,Cout,7) = per-cloud sum coef * ef[jsel], esum (B,7) = sum_{n,j} ef,
  * gram (B,7,7) = sum_{n,j} ef ef^T (all zeroed by the call); the caller finishes
- *   dW = dWsp + Ac^T esum + sum_b Bc_b o (W gram_b).   Cout <= 128. */
+ *   dW = sum_b dWsp_b + Ac^T esum + sum_b Bc_b o (W gram_b).   Cout <= 128. */
 int gcn_normal_edge_bwd(const float *pts, const int64_t *idx, const float *coef, const int64_t *jsel, int B,
                         int N, int k, int Cout, float *dWsp, float *esum, float *gram, void *stream);
 
