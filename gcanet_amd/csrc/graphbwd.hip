@@ -210,16 +210,14 @@ __global__ __launch_bounds__(256) void edge_combine_kernel(const float *__restri
 //   M1 += Dsp^T x, M2 += D2^T x  (Cout x C, summed over clouds);  G11[b] = x^T diag(indeg) x,  G21[b] = x^T s
 //   (C x C per cloud);  ssum[b] = sum_n s[n,:].
 // Workgroup = 4 waves on one row chunk of one cloud; wave w owns output-row tiles {w*OW..} of M1/M2 and
-// c-tile w of G11/G21; partial tiles are added with f32 atomics (256 workgroups -> ~8k adds per element set).
+// c-tile w of G11/G21; every workgroup stores its partial tiles, edge_wgrad_fold_kernel adds them.
 typedef __attribute__((ext_vector_type(4))) float wg_f32x4;
 
 template <int CT, int OT>
 __global__ __launch_bounds__(256) void edge_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ sx,
                                                          const float *__restrict__ dsp, const float *__restrict__ d2,
                                                          const float *__restrict__ indeg, int N, int C, int Cout,
-                                                         int rows_per_block, float *__restrict__ M1, float *__restrict__ M2,
-                                                         float *__restrict__ G11, float *__restrict__ G21,
-                                                         float *__restrict__ ssum) {
+                                                         int rows_per_block, float *__restrict__ part) {
   constexpr int OW = OT / 4;                   // o-tiles per wave
   constexpr bool HAS_G = true;
   const int lane = lane_id(), wave = wave_id();
@@ -305,6 +303,11 @@ __global__ __launch_bounds__(256) void edge_wgrad_kernel(const float *__restrict
       for (int t = 0; t < CT; ++t) ss[t] += sv[t];
     }
   }
+  // This workgroup's partial [M1 | M2 | G11 | G21 | ssum], every element written once; edge_wgrad_fold_kernel adds the
+  // partials in a fixed order.  (As float atomics these were 12.6 M device atomics per launch at C = 64, Cout = 128 --
+  // 49 MB of write traffic, 512 workgroups queueing on the same addresses at the end of the kernel.)
+  float *M1 = part + ((long)b * gridDim.x + tile) * (2L * Cout * C + 2L * C * C + C);
+  float *M2 = M1 + (long)Cout * C, *G11 = M2 + (long)Cout * C, *G21 = G11 + (long)C * C, *ssum = G21 + (long)C * C;
   // C/D layout of 16x16: col = lane&15, row = 4*(lane>>4) + r
 #pragma unroll
   for (int t = 0; t < CT; ++t) {
@@ -315,16 +318,16 @@ __global__ __launch_bounds__(256) void edge_wgrad_kernel(const float *__restrict
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int oc = 16 * (wave * OW + o) + 4 * lk + r;
-          atomicAdd(M1 + (long)oc * C + c, m1[o][t][r]);
-          atomicAdd(M2 + (long)oc * C + c, m2[o][t][r]);
+          M1[(long)oc * C + c] = m1[o][t][r];
+          M2[(long)oc * C + c] = m2[o][t][r];
         }
       if (gwave) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int cr = 16 * wave + 4 * lk + r;
           if (cr < C) {
-            atomicAdd(G11 + ((long)b * C + cr) * C + c, g11[t][r]);
-            atomicAdd(G21 + ((long)b * C + cr) * C + c, g21[t][r]);
+            G11[(long)cr * C + c] = g11[t][r];
+            G21[(long)cr * C + c] = g21[t][r];
           }
         }
       }
@@ -337,9 +340,46 @@ __global__ __launch_bounds__(256) void edge_wgrad_kernel(const float *__restrict
       v += __shfl_xor(v, 16);
       v += __shfl_xor(v, 32);
       const int c = 16 * t + li;
-      if (lk == 0 && c < C) atomicAdd(ssum + (long)b * C + c, v);
+      if (lk == 0 && c < C) ssum[c] = v;
     }
   }
+}
+
+// fin = [M1 | M2 (Cout,C) | G11 | G21 (B,C,C) | ssum (B,C)] from the workgroups' partials: M1, M2 over all B * nblk of
+// them, the rest over the nblk of their cloud.  64 outputs per workgroup, each wave a quarter of the partials, 16 loads
+// in flight; fixed order.
+__global__ __launch_bounds__(256) void edge_wgrad_fold_kernel(const float *__restrict__ part, int B, int nblk, int C, int Cout,
+                                                              float *__restrict__ fin) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long CC = (long)C * C, n_m = 2L * Cout * C, n_g = 2 * CC + C, PSZ = n_m + n_g;
+  const long NO = n_m + (long)B * n_g;
+  const long i = (long)blockIdx.x * 64 + lane;
+  long off = 0, dst = 0;
+  int p0 = 0, np = 0;
+  if (i < n_m) {
+    off = i; np = B * nblk; dst = i;
+  } else if (i < NO) {
+    const long j = i - n_m;
+    const int b = (int)(j / n_g);
+    const long e = j % n_g;
+    off = n_m + e; p0 = b * nblk; np = nblk;
+    dst = e < CC ? n_m + b * CC + e : (e < 2 * CC ? n_m + B * CC + b * CC + (e - CC) : n_m + 2 * B * CC + (long)b * C + (e - 2 * CC));
+  }
+  const int k0 = p0 + (int)((long)np * wave / 4), k1 = p0 + (int)((long)np * (wave + 1) / 4);
+  float acc = 0.f;
+  int k = k0;
+  for (; k + 16 <= k1; k += 16) {
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = part[(long)(k + u) * PSZ + off];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc += v[u];
+  }
+  for (; k < k1; ++k) acc += part[(long)k * PSZ + off];
+  red[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && i < NO) fin[dst] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
 }
 
 // dW (Cout, 2C) = [dW1 - dWd | dWd],  dWd = M2,
@@ -504,7 +544,9 @@ GCN_EXPORT int gcn_edge_combine(const float *coef, const float *dsp, const float
 
 GCN_EXPORT long gcn_edge_wgrad_ws_floats(int B, int C, int Cout) {
   if (B < 0 || C < 1 || Cout < 1) return -1;
-  return 2L * Cout * C + 2L * B * C * C + (long)B * C;
+  // the five result arrays + one partial set per workgroup (at most ceil(512 / B) workgroups per cloud)
+  const long psz = 2L * Cout * C + 2L * C * C + C;
+  return 2L * Cout * C + 2L * B * C * C + (long)B * C + (long)B * ((512 + B - 1) / B) * psz;
 }
 
 GCN_EXPORT int gcn_edge_wgrad(const float *x_pm, const float *s_pm, const float *dsp, const float *d2, const float *indeg,
@@ -515,15 +557,13 @@ GCN_EXPORT int gcn_edge_wgrad(const float *x_pm, const float *s_pm, const float 
   GCN_REQUIRE((C <= 16 || C == 64) && (Cout == 64 || Cout == 128),
               "gcn_edge_wgrad: supported C <= 16 or C == 64, Cout in {64,128}; got C=%d Cout=%d", C, Cout);
   hipStream_t st = (hipStream_t)stream;
-  const long nws = gcn_edge_wgrad_ws_floats(B, C, Cout);
-  GCN_HIP(zero_dev(ws, sizeof(float) * nws, st));
   float *M1 = ws, *M2 = M1 + (long)Cout * C, *G11 = M2 + (long)Cout * C, *G21 = G11 + (long)B * C * C,
-        *ssum = G21 + (long)B * C * C;
+        *ssum = G21 + (long)B * C * C, *part = ssum + (long)B * C;
   int blocks = (512 + B - 1) / B;
   int rows = (N + blocks - 1) / blocks;
   rows = (rows + 3) & ~3;
-  const dim3 grid(cdiv(N, rows), B);
-#define GCN_WG(CT, OT) edge_wgrad_kernel<CT, OT><<<grid, 256, 0, st>>>(x_pm, s_pm, dsp, d2, indeg, N, C, Cout, rows, M1, M2, G11, G21, ssum)
+  const dim3 grid(cdiv(N, rows), B);           // grid.x <= blocks: the partial sets fit gcn_edge_wgrad_ws_floats
+#define GCN_WG(CT, OT) edge_wgrad_kernel<CT, OT><<<grid, 256, 0, st>>>(x_pm, s_pm, dsp, d2, indeg, N, C, Cout, rows, part)
   if (C <= 16 && Cout == 64) GCN_WG(1, 4);
   else if (C <= 16) GCN_WG(1, 8);
   else if (Cout == 64) GCN_WG(4, 4);
@@ -531,6 +571,12 @@ GCN_EXPORT int gcn_edge_wgrad(const float *x_pm, const float *s_pm, const float 
 #undef GCN_WG
   int rc = check_launch("edge_wgrad_kernel");
   if (rc) return rc;
+  {
+    const long NO = 2L * Cout * C + (long)B * (2L * C * C + C);
+    edge_wgrad_fold_kernel<<<(int)((NO + 63) / 64), 256, 0, st>>>(part, B, (int)grid.x, C, Cout, ws);
+    rc = check_launch("edge_wgrad_fold_kernel");
+    if (rc) return rc;
+  }
   edge_wgrad_finish_kernel<<<Cout, 256, 0, st>>>(W, Ac, Bc, M1, M2, G11, G21, ssum, B, C, Cout, dW);
   return check_launch("edge_wgrad_finish_kernel");
 }

@@ -229,7 +229,7 @@ def _edgeconv_backward(saved, cfg, dout, pm, need_dx=True):
         # weight gradients
         if (C <= 16 or C == 64) and Cout in (64, 128):                 # all row reductions in one MFMA pass
             dW = torch.empty(Cout, 2 * C, dtype=torch.float32, device=x.device)
-            wsf = _zeroed_like((_lib.lib().gcn_edge_wgrad_ws_floats(B, C, Cout),), torch.float32, x.device)
+            wsf = torch.empty(_lib.lib().gcn_edge_wgrad_ws_floats(B, C, Cout), dtype=torch.float32, device=x.device)   # fully overwritten
             _run("gcn_edge_wgrad", x, _lib.ptr(x), _lib.ptr(s), _lib.ptr(Dsp), _lib.ptr(D2), _lib.ptr(indeg),
                  _lib.ptr(W.contiguous()), _lib.ptr(Ac), _lib.ptr(Bc), B, N, C, Cout, _lib.ptr(dW), _lib.ptr(wsf))
             return dx_pm, dW, dgamma, dbeta
