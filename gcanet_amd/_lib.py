@@ -108,7 +108,35 @@ def ptr(t):
 def stream_of(t):
     """Raw hipStream_t of torch's current stream on the tensor's device."""
     import torch
-    return torch.cuda.current_stream(t.device).cuda_stream
+    idx = t.device.index
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice() if idx is None else idx)
+
+
+class on_device:
+    """`with on_device(t):` -- make t's GPU the current one for the call, like torch.cuda.device_of(t) but without its
+    per-use Python cost when the device already is current (one process per GPU: always; an eager step makes ~200 such
+    calls, and the host, not the GPU, bounds that mode)."""
+    __slots__ = ("idx", "prev")
+
+    def __init__(self, t):
+        self.idx = t.device.index if t.is_cuda else None
+        self.prev = -1
+
+    def __enter__(self):
+        if self.idx is not None:
+            import torch
+            cur = torch._C._cuda_getDevice()
+            if cur != self.idx:
+                self.prev = cur
+                torch._C._cuda_setDevice(self.idx)
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev >= 0:
+            import torch
+            torch._C._cuda_setDevice(self.prev)
+            self.prev = -1
+        return False
 
 
 def require_cuda(*tensors):

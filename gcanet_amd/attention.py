@@ -29,7 +29,7 @@ class SDPAFunction(torch.autograd.Function):
         if mask is not None:
             m8 = mask.to(torch.uint8).contiguous()
             per_bh = 1 if m8.dim() == 3 else 0
-        with torch.cuda.device_of(q):
+        with _lib.on_device(q):
             if precision in ("bf16", "fp16"):
                 ws = _workspace(BH, Lq, Lk, D, q.device)
                 _lib.call("gcn_attention_fwd_" + ("bf16" if precision == "bf16" else "f16"), _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(m8), per_bh, BH, Lq,
@@ -53,7 +53,7 @@ class SDPAFunction(torch.autograd.Function):
             dout = dout.float().contiguous()
             dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
             mm = m8 if m8.numel() else None
-            with torch.cuda.device_of(q):
+            with _lib.on_device(q):
                 ws = _workspace(BH, Lq, Lk, D, q.device)
                 _lib.call("gcn_attention_bwd_" + ("bf16" if ctx.precision == "bf16" else "f16"), _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(out), _lib.ptr(dout),
                           _lib.ptr(lse), _lib.ptr(mm), 1 if (mm is not None and mm.dim() == 3) else 0, BH, Lq, Lk, D,

@@ -39,7 +39,7 @@ def _knn_model(x, k1, k2, metric):
         tile_ws = _KNN_WS[key]
     elif k2 <= 64 and N >= 512 and metric == 0 and C == 3:
         tile_ws = torch.empty(_lib.lib().gcn_knn_tiles_ws_bytes(B, C, N), dtype=torch.uint8, device=x.device)
-    with torch.cuda.device_of(x):
+    with _lib.on_device(x):
         _lib.call("gcn_knn_model", _lib.ptr(x), B, C, N, k1, k2, metric, _lib.ptr(idx), None, _lib.ptr(xx),
                   _lib.ptr(tile_ws), _lib.stream_of(x), tag="knn_model[B=%d,C=%d,N=%d,k=%d]" % (B, C, N, k2))
     return idx
@@ -59,7 +59,7 @@ def knn_feature_pm(x_pm, k1, k2):
     if key not in _KNN_WS:            # one scratch buffer per shape and device (calls are stream-ordered)
         _KNN_WS[key] = torch.empty(lib.gcn_knn_feature_ws_bytes(B, N, C), dtype=torch.uint8, device=x_pm.device)
     idx = torch.empty(B, N, kout, dtype=torch.int64, device=x_pm.device)
-    with torch.cuda.device_of(x_pm):
+    with _lib.on_device(x_pm):
         _lib.call("gcn_knn_feature", _lib.ptr(x_pm), B, N, C, k1, k2, _lib.ptr(idx), _lib.ptr(_KNN_WS[key]),
                   _lib.stream_of(x_pm), tag="knn_model[B=%d,C=%d,N=%d,k=%d]" % (B, C, N, k2))
     return idx
@@ -88,7 +88,7 @@ def knn_points_normals(x, k1, k2):
 # Fused EdgeConv block: get_graph_feature -> Conv2d 1x1 -> GroupNorm -> LeakyReLU -> max_k
 # ------------------------------------------------------------------------------------------
 def _run(name, like, *args, tag=None):
-    with torch.cuda.device_of(like):
+    with _lib.on_device(like):
         _lib.call(name, *args, _lib.stream_of(like), tag=tag)
 
 

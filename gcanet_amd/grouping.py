@@ -135,7 +135,7 @@ def forward_grouping_device(semantic_scores, pt_offsets, batch_idxs, coords_floa
     xx = torch.empty(n, dtype=torch.float32, device=dev)
     tiles = torch.empty(S + 1, dtype=torch.int32, device=dev)
     dm = torch.empty(2, S, dtype=torch.float32, device=dev)
-    with torch.cuda.device_of(shifted):
+    with _lib.on_device(shifted):
         for f, d in ((fi, dm[0]), (fp, dm[1])):
             _lib.call("gcn_segment_diameter2", n, f.shape[1], _lib.ptr(f), _lib.ptr(seg_offsets), _lib.ptr(seg_cls), S,
                       _lib.ptr(xx), _lib.ptr(tiles), _lib.ptr(d), st)

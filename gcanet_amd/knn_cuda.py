@@ -39,7 +39,7 @@ def _knn_batched(ref, query, k, point_major):
     if dim == 3 and k <= 64 and nr >= 512 and nr == nq and ref.data_ptr() == query.data_ptr():
         # a 3-D cloud against itself: Morton-tiled kernel with box pruning (identical results)
         tile_ws = torch.empty(_lib.lib().gcn_knn_tiles_ws_bytes(B, 3, nr), dtype=torch.uint8, device=ref.device)
-    with torch.cuda.device_of(ref):
+    with _lib.on_device(ref):
         _lib.call("gcn_knn_cuda", _lib.ptr(ref), _lib.ptr(query), B, dim, nr, nq, k, int(point_major),
                   _lib.ptr(D), _lib.ptr(I), _lib.ptr(tile_ws), _lib.stream_of(ref))
     return D, I

@@ -13,7 +13,7 @@ from . import _lib
 
 
 def _run(name, like, *args):
-    with torch.cuda.device_of(like):
+    with _lib.on_device(like):
         _lib.call(name, *args, _lib.stream_of(like))
 
 
@@ -191,7 +191,7 @@ class CastCache:
                 self._segs = self._segment_table() or False
             if self._segs and self._segs[1] == [p.data_ptr() for p in self.params]:
                 tab = self._segs[0]
-                with torch.cuda.device_of(tab):
+                with _lib.on_device(tab):
                     _lib.call("gcn_multi_cast_bf16", _lib.ptr(tab), tab.shape[0], _lib.stream_of(tab))
             else:                                   # CPU tensors, another dtype, or storage that moved
                 torch._foreach_copy_(self.copies, self.params)
@@ -244,7 +244,7 @@ def gemm_own(x2, wq, bias, N, out_f32=False, gn=None, rows_per_cloud=0):
     if gn:
         gsum = torch.empty(M // rows_per_cloud, gn, 2, dtype=torch.float64, device=x2.device)
         ws = torch.empty(_lib.lib().gcn_gemm_stats_ws_bytes(M, N), dtype=torch.uint8, device=x2.device)
-    with torch.cuda.device_of(x2):
+    with _lib.on_device(x2):
         _lib.call("gcn_gemm_bf16", _lib.ptr(x2), _lib.ptr(wq), _lib.ptr(bias), _lib.ptr(out), int(out_f32), M, N, wq.shape[0], K,
                   _lib.ptr(gsum), _lib.ptr(ws), rows_per_cloud if gn else 0, gn or 0, _lib.stream_of(x2))
     return out, gsum
@@ -273,7 +273,7 @@ def _wgrad_own(dy2, x2, with_bias):
     ws = _WGRAD_WS.get(dy2.device)
     if ws is None or ws.numel() < need:           # one scratch buffer per device for the row slices' partial results
         ws = _WGRAD_WS[dy2.device] = torch.empty(need, dtype=torch.uint8, device=dy2.device)   # (calls are stream-ordered)
-    with torch.cuda.device_of(dy2):
+    with _lib.on_device(dy2):
         _lib.call("gcn_gemm_wgrad_bf16", _lib.ptr(dy2), _lib.ptr(x2), M, N, K, _lib.ptr(dw), _lib.ptr(db), _lib.ptr(ws),
                   _lib.stream_of(dy2))
     return dw, db

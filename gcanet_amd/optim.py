@@ -41,7 +41,7 @@ class FlatAdam:
             denom = self.v.sqrt() / (1 - b2 ** t) ** 0.5 + self.eps
             self.flat_p.addcdiv_(self.m, denom, value=-self.lr / (1 - b1 ** t))
             return
-        with torch.cuda.device_of(f):
+        with _lib.on_device(f):
             _lib.call("gcn_adam_flat", _lib.ptr(self.flat_p), _lib.ptr(f), _lib.ptr(self.m), _lib.ptr(self.v), f.numel(),
                       self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, _lib.ptr(self.state),
                       _lib.stream_of(f))

@@ -22,7 +22,7 @@ def _check(t, name, dtype):
 
 
 def _run(name, like, *args):
-    with torch.cuda.device_of(like):
+    with _lib.on_device(like):
         _lib.call(name, *args, _lib.stream_of(like))
 
 

@@ -20,7 +20,7 @@ __all__ = ["hierarchical_aggregation", "ball_query", "ball_query_easy", "octree_
 
 
 def _run(name, like, *args):
-    with torch.cuda.device_of(like):
+    with _lib.on_device(like):
         _lib.call(name, *args, _lib.stream_of(like))
 
 

@@ -21,7 +21,7 @@ from . import _lib
 
 
 def _call(name, like, *args):
-    with torch.cuda.device_of(like):
+    with _lib.on_device(like):
         _lib.call(name, *args, _lib.stream_of(like))
 
 
