@@ -606,7 +606,7 @@ class DGCNNEncoderGn(nn.Module):
 
     def forward_pm(self, x_cm, x_pm=None, idxs=None):
         """Point-major core: x_cm (B,Cin,N) feeds the kNN, x_pm (B,N,Cin) the row gathers.
-        Returns (x_features (B,N,256) f32, x4 (B,1024)).  idxs: optional (idx1, idx2, idx3) neighbour lists to use
+        Returns (x_features (B,N,256) -- f32, or the autocast type under torch.autocast --, x4 (B,1024)).  idxs: optional (idx1, idx2, idx3) neighbour lists to use
         instead of searching (parity tests isolate the feature math from near-tie flips this way)."""
         from .layers import conv1x1, group_norm_relu_max
         k = self.k
@@ -629,6 +629,10 @@ class DGCNNEncoderGn(nn.Module):
         x3, _ = edge_conv_pm(x2, idx3, self.conv3._modules["0"].weight, self.bn3, self.dtype, want_cm=False)
         self.last_idx = (idx1, idx2, idx3)
         x_features = torch.cat((x1, x2, x3), dim=2)                            # (B,N,256)
+        if x_features.is_cuda and torch.is_autocast_enabled():
+            # both consumers (mlp1 here, conv1's feature half in the caller) run in the autocast type: convert once, so
+            # that their two input gradients also meet in that type and come back through ONE conversion
+            x_features = x_features.to(torch.get_autocast_dtype("cuda"))
         x4 = group_norm_relu_max(conv1x1(x_features, self.mlp1), self.bnmlp1)  # (B,1024); (B,N,1024) never written
         return x_features, x4
 
@@ -636,7 +640,7 @@ class DGCNNEncoderGn(nn.Module):
         """Reference signature: x (B,Cin,N) -> (B,1280,N)  (M4:492-534)."""
         B, _, N = x.shape
         xf, x4 = self.forward_pm(x)
-        return torch.cat([x4.float().view(B, 1024, 1).expand(-1, -1, N), xf.transpose(1, 2)], 1)
+        return torch.cat([x4.float().view(B, 1024, 1).expand(-1, -1, N), xf.float().transpose(1, 2)], 1)
 
 
 def cos_dist(instance_feature, global_instance_feature):
