@@ -762,7 +762,10 @@ class OFFSET_PRED_MODULE(nn.Module):
             from .layers import conv1x1
             y = KeyEdgeBlockFunction.apply(att, topk_idx, U, V, self.bn1.weight, self.bn1.bias, self.bn1.num_groups,
                                            self.bn1.eps, 0.2, True)            # (B,N,128)
-            return conv1x1(torch.cat([y, feature.to(y.dtype)], dim=2), self.mlp_offset)
+            # under autocast the 1x1 conv runs in the autocast type anyway: concatenate in that type (the f32
+            # concatenation + its conversion moved 2.5x the bytes)
+            dt = torch.get_autocast_dtype("cuda") if (y.is_cuda and torch.is_autocast_enabled()) else y.dtype
+            return conv1x1(torch.cat([y.to(dt), feature.to(dt)], dim=2), self.mlp_offset)
         y = KeyEdgeBlockFunction.apply(att, topk_idx, U, V, self.bn1.weight, self.bn1.bias, self.bn1.num_groups,
                                        self.bn1.eps, 0.2)                      # (B,128,N)
         y = torch.cat([y, feature.permute(0, 2, 1).to(y.dtype)], dim=1)
@@ -848,8 +851,8 @@ class PrimitivesEmbeddingDGCNGn(nn.Module):
             parts.append(torch.zeros(B, N, (kin + 15) // 16 * 16 - kin, dtype=x_all.dtype, device=pts.device))
         feat_plus = conv1x1_gn_relu(torch.cat(parts, dim=2), self.conv3, self.bn3)             # (B,N,128)
         semantic_scores = type_forgroup.reshape(-1, type_forgroup.shape[-1])
-        pt_offsets = self.offset_pred_block(pts[:, :, 0:3], feat_plus.float(), output_feats, pm_out=True,
-                                            topk_idx=topk_idx)
+        feat_in = feat_plus if (feat_plus.is_cuda and torch.is_autocast_enabled()) else feat_plus.float()
+        pt_offsets = self.offset_pred_block(pts[:, :, 0:3], feat_in, output_feats, pm_out=True, topk_idx=topk_idx)
         pt_offsets = pt_offsets.reshape(-1, 3)
         return dict(type_per_point=type_per_point, param_per_point=param_per_point,
                     semantic_scores=semantic_scores, pt_offsets=pt_offsets, output_feats=output_feats)
