@@ -197,9 +197,9 @@ __global__ __launch_bounds__(256) void edge_combine_kernel(const float *__restri
     const long n = e / Cout;
     const long o = (long)b * per + e;
     const float a = Ac[(long)b * Cout + c], bb = Bc[(long)b * Cout + c];
-    const float dg = indeg[(long)b * N + n];
+    const float dg = D1 ? indeg[(long)b * N + n] : 0.f;
     D2[o] = coef[o] + kf * a + bb * (SW[o] + kf * XW[o]);
-    D1[o] = dsp[o] + dg * (a + bb * P1[o]) + bb * RW[o];
+    if (D1) D1[o] = dsp[o] + dg * (a + bb * P1[o]) + bb * RW[o];
   }
 }
 
@@ -533,7 +533,8 @@ GCN_EXPORT int gcn_route_bwd(const float *dout_pm, const float *ymax, const floa
 GCN_EXPORT int gcn_edge_combine(const float *coef, const float *dsp, const float *indeg, const float *Ac, const float *Bc,
                                 const float *P1, const float *SW, const float *XW, const float *RW, int B, int N, int k,
                                 int Cout, float *D1, float *D2, void *stream) {
-  GCN_REQUIRE(coef && dsp && indeg && Ac && Bc && P1 && SW && XW && RW && D1 && D2, "gcn_edge_combine: null pointer");
+  GCN_REQUIRE(coef && Ac && Bc && SW && XW && D2, "gcn_edge_combine: null pointer");
+  GCN_REQUIRE(!D1 || (dsp && indeg && P1 && RW), "gcn_edge_combine: D1 needs dsp, indeg, P1 and RW");
   GCN_REQUIRE(B >= 0 && N >= 1 && Cout >= 1, "gcn_edge_combine: bad shape");
   if (B == 0) return GCN_OK;
   const long per = (long)N * Cout;

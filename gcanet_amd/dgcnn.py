@@ -222,9 +222,11 @@ def _edgeconv_backward(saved, cfg, dout, pm, need_dx=True):
             D1, D2 = torch.empty_like(coef), torch.empty_like(coef)
             _run("gcn_edge_combine", x, _lib.ptr(coef), _lib.ptr(Dsp), _lib.ptr(indeg), _lib.ptr(Ac), _lib.ptr(Bc),
                  _lib.ptr(P1), _lib.ptr(SW), _lib.ptr(XW), _lib.ptr(RW), B, N, k, Cout, _lib.ptr(D1), _lib.ptr(D2))
-            dx_pm = D1 @ W1 + D2 @ Wd                                  # (B,N,C)
+            dx_pm = torch.baddbmm(D1 @ W1, D2, Wd.unsqueeze(0).expand(B, -1, -1))   # D1.W1 + D2.Wd  (B,N,C), no separate add
         else:
-            D2 = coef + Ac.unsqueeze(1) * float(k) + Bc.unsqueeze(1) * (SW + float(k) * XW)
+            D2 = torch.empty_like(coef)                               # one kernel instead of six elementwise launches
+            _run("gcn_edge_combine", x, _lib.ptr(coef), None, None, _lib.ptr(Ac), _lib.ptr(Bc), None, _lib.ptr(SW), _lib.ptr(XW),
+                 None, B, N, k, Cout, None, _lib.ptr(D2))
             dx_pm = None
         # weight gradients
         if (C <= 16 or C == 64) and Cout in (64, 128):                 # all row reductions in one MFMA pass

@@ -465,7 +465,8 @@ int gcn_edge_wgrad(const float *x_pm, const float *s_pm, const float *dsp, const
                    float *ws, void *stream);
 
 /* D2 = coef + k*A + B*(SW + k*XW);  D1 = dsp + indeg*(A + B*P1) + B*RW   (all (B,N,Cout) f32;
- * A, B (B,Cout); indeg (B,N)): per-point sums of dy over outgoing / incoming edges. */
+ * A, B (B,Cout); indeg (B,N)): per-point sums of dy over outgoing / incoming edges.  D1 may be NULL (a first layer
+ * whose input carries no gradient needs D2 only; dsp, indeg, P1, RW are then not read). */
 int gcn_edge_combine(const float *coef, const float *dsp, const float *indeg, const float *Ac,
                      const float *Bc, const float *P1, const float *SW, const float *XW, const float *RW,
                      int B, int N, int k, int Cout, float *D1, float *D2, void *stream);
