@@ -745,7 +745,8 @@ class OFFSET_PRED_MODULE(nn.Module):
         """points (B,N,3), feature (B,N,128), instance_feature (B,N,64) -> offsets (B,3,N) [(B,N,3) if pm_out]."""
         B, N, _ = points.shape
         sub = key_point_indices(N, self.sampling_ratio, points.device)
-        key_pts, key_feat, key_emb = points[:, sub], feature[:, sub], instance_feature[:, sub]
+        # index_select: its backward is one index_add (advanced indexing goes through a seven-kernel index_put chain)
+        key_pts, key_feat, key_emb = (t.index_select(1, sub) for t in (points, feature, instance_feature))
         dist = cos_dist(instance_feature, key_emb)                             # (B,N,120)
         if topk_idx is None:
             topk_dist, topk_idx = topk_rows(dist, self.k)                      # once, not twice (M4:421-422)
