@@ -50,9 +50,57 @@ __global__ __launch_bounds__(256) void param_normalise_bwd_kernel(const float *_
   for (int c = 0; c < 22; ++c) gi[r * 22 + c] = g[c];
 }
 
+// row_normalise: y = x / |x| over the last dimension (the feature normalisation in front of the offset module's cosine
+// similarity, M4:326-342: `f / f.norm(dim=-1, keepdim=True)`, no epsilon -- a zero row gives NaN there and here).
+// One wave per row, lane = channel (+ 64 per step); backward dx = (g - y (y.g)) / |x|.  torch: norm + div forward, about
+// ten small kernels backward.
+__global__ __launch_bounds__(256) void row_normalise_fwd_kernel(const float *__restrict__ x, long R, int C, float *__restrict__ y) {
+  const long r = (long)blockIdx.x * 4 + wave_id();
+  if (r >= R) return;
+  const int lane = lane_id();
+  const float *xr = x + r * C;
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s = fmaf(xr[c], xr[c], s);
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+  const float n = sqrtf(s);
+  for (int c = lane; c < C; c += 64) y[r * C + c] = xr[c] / n;
+}
+
+__global__ __launch_bounds__(256) void row_normalise_bwd_kernel(const float *__restrict__ x, const float *__restrict__ go,
+                                                                long R, int C, float *__restrict__ gi) {
+  const long r = (long)blockIdx.x * 4 + wave_id();
+  if (r >= R) return;
+  const int lane = lane_id();
+  const float *xr = x + r * C, *gr = go + r * C;
+  float s = 0.f, d = 0.f;
+  for (int c = lane; c < C; c += 64) { s = fmaf(xr[c], xr[c], s); d = fmaf(xr[c], gr[c], d); }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) { s += __shfl_xor(s, o); d += __shfl_xor(d, o); }
+  const float n = sqrtf(s);
+  const float k = d / (n * n * n);                         // x (x.g) / |x|^3
+  for (int c = lane; c < C; c += 64) gi[r * C + c] = gr[c] / n - xr[c] * k;
+}
+
 }  // namespace gcn
 
 using namespace gcn;
+
+GCN_EXPORT int gcn_row_normalise_fwd(const float *x, long R, int C, float *y, void *stream) {
+  GCN_REQUIRE(x && y, "gcn_row_normalise_fwd: null pointer");
+  GCN_REQUIRE(R >= 0 && C >= 1, "gcn_row_normalise_fwd: bad shape");
+  if (R == 0) return GCN_OK;
+  row_normalise_fwd_kernel<<<(int)((R + 3) / 4), 256, 0, (hipStream_t)stream>>>(x, R, C, y);
+  return check_launch("row_normalise_fwd_kernel");
+}
+
+GCN_EXPORT int gcn_row_normalise_bwd(const float *x, const float *grad_out, long R, int C, float *grad_in, void *stream) {
+  GCN_REQUIRE(x && grad_out && grad_in, "gcn_row_normalise_bwd: null pointer");
+  GCN_REQUIRE(R >= 0 && C >= 1, "gcn_row_normalise_bwd: bad shape");
+  if (R == 0) return GCN_OK;
+  row_normalise_bwd_kernel<<<(int)((R + 3) / 4), 256, 0, (hipStream_t)stream>>>(x, grad_out, R, C, grad_in);
+  return check_launch("row_normalise_bwd_kernel");
+}
 
 GCN_EXPORT int gcn_param_normalise_fwd(const float *p, long R, float *out, void *stream) {
   GCN_REQUIRE(p && out, "gcn_param_normalise_fwd: null pointer");

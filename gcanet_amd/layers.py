@@ -463,3 +463,29 @@ class ParamNormaliseFunction(torch.autograd.Function):
 
 def param_normalise(p):
     return ParamNormaliseFunction.apply(p)
+
+
+class RowNormaliseFunction(torch.autograd.Function):
+    """x / x.norm(dim=-1, keepdim=True) on (..., C) rows, one kernel each way (csrc/heads.hip)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _lib.require_cuda(x)
+        xc = x.float().contiguous()
+        y = torch.empty_like(xc)
+        _run("gcn_row_normalise_fwd", xc, _lib.ptr(xc), xc.numel() // xc.shape[-1], xc.shape[-1], _lib.ptr(y))
+        ctx.save_for_backward(xc)
+        ctx.in_dtype = x.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, go):
+        (xc,) = ctx.saved_tensors
+        go = go.float().contiguous()
+        gi = torch.empty_like(xc)
+        _run("gcn_row_normalise_bwd", xc, _lib.ptr(xc), _lib.ptr(go), xc.numel() // xc.shape[-1], xc.shape[-1], _lib.ptr(gi))
+        return gi.to(ctx.in_dtype)
+
+
+def row_normalise(x):
+    return RowNormaliseFunction.apply(x)

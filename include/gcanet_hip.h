@@ -513,6 +513,12 @@ int gcn_gn_max_bwd(const void *x, int dtype, const float *gamma, const float *be
 int gcn_param_normalise_fwd(const float *p, long R, float *out, void *stream);
 int gcn_param_normalise_bwd(const float *p, const float *grad_out, long R, float *grad_in, void *stream);
 
+/* y = x / |x| over the last dimension of x (R,C) f32 -- the feature normalisation of cos_dist
+ * (models/dgcnn-hais-concat-direct-4.py:326-342: f / f.norm(dim=-1, keepdim=True), no epsilon) -- and its gradient
+ * dx = (g - y (y.g)) / |x|. */
+int gcn_row_normalise_fwd(const float *x, long R, int C, float *y, void *stream);
+int gcn_row_normalise_bwd(const float *x, const float *grad_out, long R, int C, float *grad_in, void *stream);
+
 /* gcn_gn_fwd's second half alone: the (B,G,2) f64 sums and sums of squares are already in `gsum` -- written by the
  * epilogue of the GEMM that produced x (gcn_gemm_bf16), so the statistics pass over x is skipped. */
 int gcn_gn_apply(const void *x, int dtype, const double *gsum, const float *gamma, const float *beta, int B,

@@ -77,3 +77,21 @@ def test_param_normalise_matches_torch_chain(dev):
     mask[0, 0, 4:7] = False                                         # torch's norm backward is NaN at exactly zero
     np.testing.assert_allclose(ga[mask].cpu().numpy(), gb[mask].cpu().numpy(), rtol=1e-4, atol=1e-5)
     assert torch.isfinite(ga).all()
+
+
+@pytest.mark.parametrize("shape", [(2, 300, 64), (1, 5, 3), (3, 70, 200), (4096, 64)])
+def test_row_normalise_matches_torch(dev, shape):
+    """x / x.norm(dim=-1, keepdim=True) (the feature normalisation of cos_dist, M4:326-342) as one kernel each way
+    (csrc/heads.hip) vs the torch expression in f64, forward and gradient."""
+    from gcanet_amd.layers import row_normalise
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(*shape, generator=g, dtype=torch.float64)
+    w = torch.randn(*shape, generator=g, dtype=torch.float64)
+    xr = x.clone().requires_grad_(True)
+    ref = xr / xr.norm(dim=-1, keepdim=True)
+    (ref * w).sum().backward()
+    xg = x.float().to(dev).requires_grad_(True)
+    out = row_normalise(xg)
+    (out * w.float().to(dev)).sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-4, atol=1e-5 * float(xr.grad.abs().max()))

@@ -24,7 +24,7 @@ def test_oracle_restatement_matches_m2_golden():
     t = lambda k: torch.from_numpy(g[k]).requires_grad_()
     pts, feat, sem, ins = t("points"), t("feat"), t("sem"), t("ins")
     o = R.offset_pred_module_m2(pts, feat, sem, ins, sd)
-    np.testing.assert_allclose(o.detach().numpy(), g["out"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(o.detach().numpy(), g["out"], rtol=1e-4, atol=5e-5)   # f32 CPU kernels differ by host (summation order)
     (o * torch.from_numpy(g["gout"])).sum().backward()
     for got, key in ((pts.grad, "dpoints"), (feat.grad, "dfeat"), (ins.grad, "dins")):
         np.testing.assert_allclose(got.numpy(), g[key], rtol=1e-4, atol=1e-4 * np.abs(g[key]).max(), err_msg=key)
