@@ -530,7 +530,7 @@ class KeyEdgeBlockFunction(torch.autograd.Function):
         jsel, coef, Ac, Bc, dgamma, dbeta, _ = _route_backward_fused(dpm, gamma, beta, ymax, ymin, amax, amin, mean_rstd,
                                                                      G, slope, Mg, want_jsel=True)
         if k <= 64:
-            X = (V * Bc.unsqueeze(1)) @ U.transpose(1, 2)                   # (B,N,NK)
+            X = V @ (U * Bc.unsqueeze(1)).transpose(1, 2)                   # (B,N,NK) = (V o Bc).U^T, scaling the NK rows
             datt, dV = torch.empty_like(att), torch.empty_like(V)
             A2 = torch.empty(B, N, NK, dtype=torch.float32, device=att.device)
             raw = _zeroed_like((U.numel() + B * 2 * NK,), torch.float32, att.device)   # adjacent: one zero fill
