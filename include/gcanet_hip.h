@@ -519,6 +519,20 @@ int gcn_param_normalise_bwd(const float *p, const float *grad_out, long R, float
 int gcn_row_normalise_fwd(const float *x, long R, int C, float *y, void *stream);
 int gcn_row_normalise_bwd(const float *x, const float *grad_out, long R, int C, float *grad_in, void *stream);
 
+/* L = sum over tensors t of mean(v_t^2), and grad_t = v_t * (2 / numel_t) * grad_loss[0], one launch each way for up to
+ * 8 f32 / bf16 tensors (torch: one reduction per tensor forward, two scaling passes backward).  No reference
+ * counterpart: it is the synthetic objective bench.py puts on the hot path's five outputs (M4:634-747 returns them to
+ * loss code that is out of scope), kept in the library so that the timed step has no torch reductions in it.
+ *   v, grad: HOST arrays of nt device pointers; numel, is_bf16: HOST arrays (element counts >= 1; 0 = f32, 1 = bf16).
+ *   part: gcn_multi_mean_square_ws_chunks(numel, nt) doubles of device scratch; done: one device uint32, zero before
+ *   the first call (every call leaves it zero); loss: one device float, written; grad_loss: one device float.
+ *   Partial sums are folded in a fixed order (bit-reproducible). */
+int gcn_multi_mean_square_ws_chunks(const long *numel, int nt);
+int gcn_multi_mean_square_fwd(const void *const *v, const long *numel, const int *is_bf16, int nt, double *part,
+                              unsigned int *done, float *loss, void *stream);
+int gcn_multi_mean_square_bwd(const void *const *v, void *const *grad, const long *numel, const int *is_bf16, int nt,
+                              const float *grad_loss, void *stream);
+
 /* gcn_gn_fwd's second half alone: the (B,G,2) f64 sums and sums of squares are already in `gsum` -- written by the
  * epilogue of the GEMM that produced x (gcn_gemm_bf16), so the statistics pass over x is skipped. */
 int gcn_gn_apply(const void *x, int dtype, const double *gsum, const float *gamma, const float *beta, int B,

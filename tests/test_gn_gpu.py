@@ -95,3 +95,30 @@ def test_row_normalise_matches_torch(dev, shape):
     (out * w.float().to(dev)).sum().backward()
     np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(xg.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-4, atol=1e-5 * float(xr.grad.abs().max()))
+
+
+@pytest.mark.parametrize("shapes", [[(8, 8192, 10), (8, 8192, 22), (65536, 10), (65536, 3), (8, 8192, 64)],
+                                    [(5,)], [(3, 7), (16385,), (2, 16384)]])
+def test_sum_mean_squares_matches_torch(dev, shapes):
+    """sum_t mean(v_t^2) over mixed f32 / bf16 tensors in one launch each way (csrc/heads.hip: the benchmark's synthetic
+    objective) vs the per-tensor torch expression in f64: value, gradients, repeatability (fixed fold order), and a
+    scaled incoming gradient."""
+    from gcanet_amd.losses import sum_mean_squares
+    g = torch.Generator().manual_seed(len(shapes))
+    vs, refs = [], []
+    for i, sh in enumerate(shapes):
+        x = torch.randn(*sh, generator=g)
+        if i % 2 == 1:
+            x = x.bfloat16()
+        vs.append(x.to(dev).requires_grad_(True))
+        refs.append(x.double().requires_grad_(True))
+    loss = sum_mean_squares(*vs)
+    (loss * 3.0).backward()
+    ref = sum(r.pow(2).mean() for r in refs)
+    (ref * 3.0).backward()
+    assert abs(float(loss.detach()) - float(ref.detach())) <= 2e-6 * float(ref.detach())
+    assert float(sum_mean_squares(*[v.detach() for v in vs])) == float(loss.detach())
+    for v, r in zip(vs, refs):
+        assert v.grad.dtype == v.dtype
+        tol = 1e-2 if v.dtype == torch.bfloat16 else 1e-6
+        np.testing.assert_allclose(v.grad.float().cpu().numpy(), r.grad.float().numpy(), rtol=tol, atol=1e-12)
