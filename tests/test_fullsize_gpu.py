@@ -304,3 +304,43 @@ def test_bf16_model_error_budget_vs_fp32_oracle(dev):
     print("bf16 relative L2 error vs fp32 oracle:", got)
     for k_, bound in budget.items():
         assert got[k_] < bound, got
+
+
+# ------------------------------------------------------------------------------------------ other cloud sizes
+# BASELINE configs[4] runs the same hot path on clouds of N=16384 (k=64); the reference's own defaults are B=3, N=7000,
+# k=80 (option_new.py:58, ABCDataset_new.py:120, M4:544-550) -- N not a multiple of any tile, k beyond 64.
+@pytest.mark.parametrize("n,k,C,metric", [(16384, 64, 64, 0), (16384, 64, 6, 1), (7000, 80, 64, 0), (7000, 80, 128, 0),
+                                          (7000, 80, 6, 1), (7000, 80, 3, 0)])
+def test_knn_other_sizes_bit_exact(dev, n, k, C, metric):
+    """dgcnn.knn / knn_points_normals at the config-5 cloud size and at the reference's default shape: indices identical
+    to the oracle's, and cloud 1 of a batch of two equals that cloud alone."""
+    from gcanet_amd import dgcnn
+    if metric == 1 or C == 3:
+        cl = [_cloud(c, n) for c in (3, 4)]
+        x = torch.stack([torch.cat([p, q], 1).t() if metric == 1 else p.t() for p, q in cl]).contiguous()
+    else:
+        x = _features(C, B=2, seed=n + C, n=n)
+    fn = dgcnn.knn_points_normals if metric == 1 else dgcnn.knn
+    xb = x.to(dev)
+    idx = fn(xb, k, k)
+    assert torch.equal(idx[1:2], fn(xb[1:2].contiguous(), k, k))
+    np.testing.assert_array_equal(idx[1:2].cpu().numpy(), oracle.knn_model(x[1:2].contiguous().numpy(), k, k, metric))
+
+
+@pytest.mark.parametrize("n,k", [(16384, 64), (7000, 80)])
+def test_hot_path_other_sizes_match_oracle(dev, n, k):
+    """Whole hot path (f32 exact path) on one cloud of the config-5 size / the reference's default shape vs
+    oracle/ref_model.hot_path, exactly as test_hot_path_full_size_matches_oracle does at N=8192."""
+    m, sd = _model("f32", k=k)
+    m = m.to(dev)
+    pts, nrm = _cloud(6, n)
+    pts, nrm = pts.unsqueeze(0), nrm.unsqueeze(0)
+    with torch.no_grad():
+        out = m(pts.to(dev), nrm.to(dev))
+        idxs = [i.cpu() for i in m.encoder.last_idx]
+        sel = m.offset_pred_block.last_topk_idx.cpu()
+        info = {}
+        ref, _ = R.hot_path(sd, pts, nrm, k, idxs=idxs, topk_idx=sel, info=info)
+    check_topk_selection(info["cos_dist"], sel)
+    for k_ in ref:
+        _close(out[k_].cpu().numpy(), ref[k_].numpy(), what="%s N=%d" % (k_, n))
