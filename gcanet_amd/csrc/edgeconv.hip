@@ -499,7 +499,8 @@ __global__ __launch_bounds__(256) void edgeconv_finish_kernel(const float *__res
                                                               const double *__restrict__ gsum, const float *__restrict__ gamma,
                                                               const float *__restrict__ beta, int N, int k, int Cout, int G,
                                                               float eps, float slope, float *__restrict__ out_cm,
-                                                              float *__restrict__ out_pm, float *__restrict__ mean_rstd) {
+                                                              float *__restrict__ out_pm, float *__restrict__ mean_rstd,
+                                                              unsigned short *__restrict__ out_bf, int bf_pitch) {
   __shared__ float tile[32][33];
   const int b = blockIdx.z;
   const int n0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
@@ -521,6 +522,7 @@ __global__ __launch_bounds__(256) void edgeconv_finish_kernel(const float *__res
       const float z = (y - mean) * rstd * ga + beta[c];
       v = z > 0.f ? z : z * slope;
       if (out_pm) out_pm[o] = v;
+      if (out_bf) out_bf[((long)b * N + n) * bf_pitch + c] = f32_to_bf16(v);
       if (mean_rstd && n == 0 && (c % cpg) == 0) {
         mean_rstd[((long)b * G + g) * 2] = mean;
         mean_rstd[((long)b * G + g) * 2 + 1] = rstd;
@@ -1239,12 +1241,15 @@ GCN_EXPORT int gcn_edgeconv_fwd(const void *x_pm, const void *w, const int64_t *
 
 GCN_EXPORT int gcn_edgeconv_finish(const float *ymax, const float *ymin, const double *gsum, const float *gamma,
                                    const float *beta, int B, int N, int k, int Cout, int G, float eps, float slope,
-                                   float *out_cm, float *out_pm, float *mean_rstd, void *stream) {
-  GCN_REQUIRE(ymax && gsum && gamma && beta && (out_cm || out_pm), "gcn_edgeconv_finish: null pointer");
+                                   float *out_cm, float *out_pm, float *mean_rstd, void *out_pm_bf16, int bf16_pitch,
+                                   void *stream) {
+  GCN_REQUIRE(ymax && gsum && gamma && beta && (out_cm || out_pm || out_pm_bf16), "gcn_edgeconv_finish: null pointer");
   GCN_REQUIRE(B >= 0 && N >= 1 && k >= 1 && G >= 1 && Cout % G == 0, "gcn_edgeconv_finish: bad shape");
+  GCN_REQUIRE(!out_pm_bf16 || bf16_pitch >= Cout, "gcn_edgeconv_finish: bf16 row pitch %d < Cout %d", bf16_pitch, Cout);
   if (B == 0) return GCN_OK;
   edgeconv_finish_kernel<<<dim3(cdiv(N, 32), cdiv(Cout, 32), B), 256, 0, (hipStream_t)stream>>>(
-      ymax, ymin, gsum, gamma, beta, N, k, Cout, G, eps, slope, out_cm, out_pm, mean_rstd);
+      ymax, ymin, gsum, gamma, beta, N, k, Cout, G, eps, slope, out_cm, out_pm, mean_rstd, (unsigned short *)out_pm_bf16,
+      bf16_pitch);
   return check_launch("edgeconv_finish_kernel");
 }
 

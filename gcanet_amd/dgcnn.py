@@ -154,7 +154,7 @@ def edgeconv_forward_raw(x, idx, weight, gamma, beta, groups, dtype="bf16", eps=
     mean_rstd = torch.empty(B, groups, 2, **f32)
     ga, be = gamma.float().contiguous(), beta.float().contiguous()
     _run("gcn_edgeconv_finish", x, _lib.ptr(ymax), _lib.ptr(ymin), _lib.ptr(gsum), _lib.ptr(ga), _lib.ptr(be),
-         B, N, k, Cout, groups, float(eps), float(slope), _lib.ptr(out), None, _lib.ptr(mean_rstd))
+         B, N, k, Cout, groups, float(eps), float(slope), _lib.ptr(out), None, _lib.ptr(mean_rstd), None, 0)
     return dict(out=out, ymax=ymax, ymin=ymin, amax=amax, amin=amin, gsum=gsum, mean_rstd=mean_rstd, x_pm=x_pm)
 
 
@@ -622,19 +622,29 @@ class DGCNNEncoderGn(nn.Module):
         # otherwise the EdgeConv finish kernel also writes the channel-major copy the generic kNN kernels read
         B_, N_ = x_pm.shape[0], x_pm.shape[1]
         fast = bool(x_pm.is_cuda and _lib.lib().gcn_knn_feature_supported(B_, N_, 64, k))
-        x1, x1_cm = edge_conv_pm(x_pm, idx1, self.conv1._modules["0"].weight, self.bn1, self.dtype, want_cm=not fast)
+        # under bf16 autocast both consumers of cat(x1,x2,x3) (mlp1 here, conv1's feature half in the caller) read it in
+        # bf16: the three finish kernels write their bf16 column slice of that tensor directly (no cat, no conversion
+        # pass), and the two input gradients meet in bf16 and come back as three slice conversions
+        direct = bool(x_pm.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16)
+        xf16 = torch.empty(B_, N_, 256, dtype=torch.bfloat16, device=x_pm.device) if direct else None
+        sl = (lambda a, b: xf16[:, :, a:b]) if direct else (lambda a, b: None)
+        x1, x1_cm = edge_conv_pm(x_pm, idx1, self.conv1._modules["0"].weight, self.bn1, self.dtype, want_cm=not fast,
+                                 bf_out=sl(0, 64))
         if idxs is None:
             idx2 = knn_feature_pm(x1.detach(), k, k) if fast else knn(x1_cm, k, k)
-        x2, x2_cm = edge_conv_pm(x1, idx2, self.conv2._modules["0"].weight, self.bn2, self.dtype, want_cm=not fast)
+        x2, x2_cm = edge_conv_pm(x1, idx2, self.conv2._modules["0"].weight, self.bn2, self.dtype, want_cm=not fast,
+                                 bf_out=sl(64, 128))
         if idxs is None:
             idx3 = knn_feature_pm(x2.detach(), k, k) if fast else knn(x2_cm, k, k)
-        x3, _ = edge_conv_pm(x2, idx3, self.conv3._modules["0"].weight, self.bn3, self.dtype, want_cm=False)
+        x3, _ = edge_conv_pm(x2, idx3, self.conv3._modules["0"].weight, self.bn3, self.dtype, want_cm=False,
+                             bf_out=sl(128, 256))
         self.last_idx = (idx1, idx2, idx3)
-        x_features = torch.cat((x1, x2, x3), dim=2)                            # (B,N,256)
-        if x_features.is_cuda and torch.is_autocast_enabled():
-            # both consumers (mlp1 here, conv1's feature half in the caller) run in the autocast type: convert once, so
-            # that their two input gradients also meet in that type and come back through ONE conversion
-            x_features = x_features.to(torch.get_autocast_dtype("cuda"))
+        if direct:
+            x_features = ConcatSlicesFunction.apply(xf16, x1, x2, x3)           # (B,N,256) bf16
+        else:
+            x_features = torch.cat((x1, x2, x3), dim=2)                        # (B,N,256)
+            if x_features.is_cuda and torch.is_autocast_enabled():
+                x_features = x_features.to(torch.get_autocast_dtype("cuda"))
         x4 = group_norm_relu_max(conv1x1(x_features, self.mlp1), self.bnmlp1)  # (B,1024); (B,N,1024) never written
         return x_features, x4
 
@@ -868,13 +878,15 @@ class PrimitivesEmbeddingDGCNGn(nn.Module):
 # ------------------------------------------------------------------------------------------
 # Point-major (B,N,C) fast path: same math, no layout round trips.  Used by PrimitivesEmbeddingDGCNGn.
 # ------------------------------------------------------------------------------------------
-def _finish(ymax, ymin, gsum, gamma, beta, B, N, k, Cout, groups, eps, slope, want_cm, want_pm):
+def _finish(ymax, ymin, gsum, gamma, beta, B, N, k, Cout, groups, eps, slope, want_cm, want_pm, bf_out=None):
+    """bf_out: optional bf16 (B,N,Cout) column slice of a wider (B,N,W) buffer that also receives the result."""
     f32 = dict(dtype=torch.float32, device=ymax.device)
     out_cm = torch.empty(B, Cout, N, **f32) if want_cm else None
     out_pm = torch.empty(B, N, Cout, **f32) if want_pm else None
     mean_rstd = torch.empty(B, groups, 2, **f32)
     _run("gcn_edgeconv_finish", ymax, _lib.ptr(ymax), _lib.ptr(ymin), _lib.ptr(gsum), _lib.ptr(gamma), _lib.ptr(beta),
-         B, N, k, Cout, groups, float(eps), float(slope), _lib.ptr(out_cm), _lib.ptr(out_pm), _lib.ptr(mean_rstd))
+         B, N, k, Cout, groups, float(eps), float(slope), _lib.ptr(out_cm), _lib.ptr(out_pm), _lib.ptr(mean_rstd),
+         _lib.ptr(bf_out), 0 if bf_out is None else bf_out.stride(1))
     return out_cm, out_pm, mean_rstd
 
 
@@ -883,7 +895,7 @@ class EdgeConvPMFunction(torch.autograd.Function):
     out_cm is a non-differentiable copy in the channel-major layout the kNN kernels read."""
 
     @staticmethod
-    def forward(ctx, x, idx, weight, gamma, beta, groups, dtype, eps, slope, want_cm):
+    def forward(ctx, x, idx, weight, gamma, beta, groups, dtype, eps, slope, want_cm, bf_out=None):
         _lib.require_cuda(x, idx)
         B, N, C = x.shape
         k = idx.shape[2]
@@ -913,7 +925,10 @@ class EdgeConvPMFunction(torch.autograd.Function):
         else:
             _run("gcn_edgeconv_fwd", x, _lib.ptr(x), _lib.ptr(w), _lib.ptr(idx), 0, B, N, N, C, k, Cout, groups,
                  None, _lib.ptr(ymax), None, _lib.ptr(amax), None, _lib.ptr(gsum), _lib.ptr(ga))
-        out_cm, out_pm, mean_rstd = _finish(ymax, ymin, gsum, ga, be, B, N, k, Cout, groups, eps, slope, want_cm, True)
+        if bf_out is not None:
+            assert bf_out.dtype == torch.bfloat16 and bf_out.shape == (B, N, Cout) and bf_out.stride(2) == 1 \
+                and bf_out.stride(0) == N * bf_out.stride(1)
+        out_cm, out_pm, mean_rstd = _finish(ymax, ymin, gsum, ga, be, B, N, k, Cout, groups, eps, slope, want_cm, True, bf_out)
         empty = torch.empty(0, device=dev)
         ctx.save_for_backward(x, idx, w, ga, be, ymax, empty, amax, empty, mean_rstd)
         ctx.cfg = (groups, slope)
@@ -926,9 +941,32 @@ class EdgeConvPMFunction(torch.autograd.Function):
     def backward(ctx, dout_pm, _unused):
         dx_pm, dW, dgamma, dbeta = _edgeconv_backward(ctx.saved_tensors, ctx.cfg, dout_pm.contiguous(), pm=True,
                                                       need_dx=ctx.needs_input_grad[0])
-        return dx_pm, None, dW, dgamma, dbeta, None, None, None, None, None
+        return dx_pm, None, dW, dgamma, dbeta, None, None, None, None, None, None
 
 
-def edge_conv_pm(x_pm, idx, conv_weight, gn, dtype="bf16", want_cm=True):
+def edge_conv_pm(x_pm, idx, conv_weight, gn, dtype="bf16", want_cm=True, bf_out=None):
+    """bf_out: a bf16 (B,N,Cout) column slice of the consumer's concatenated input; the finish kernel writes the result
+    there as well (see ConcatSlicesFunction)."""
     w = conv_weight.flatten(1) if conv_weight.dim() == 4 else conv_weight
-    return EdgeConvPMFunction.apply(x_pm, idx, w, gn.weight, gn.bias, gn.num_groups, dtype, gn.eps, 0.2, want_cm)
+    return EdgeConvPMFunction.apply(x_pm, idx, w, gn.weight, gn.bias, gn.num_groups, dtype, gn.eps, 0.2, want_cm, bf_out)
+
+
+class ConcatSlicesFunction(torch.autograd.Function):
+    """torch.cat(parts, dim=2).to(buf.dtype) for f32 parts whose low-precision images ALREADY sit in the column slices of
+    `buf` (written by the kernels that produced the parts): forward hands out `buf`, backward returns the gradient's
+    column slices in the parts' type -- no concatenation pass, no conversion pass over the wide tensor either way."""
+
+    @staticmethod
+    def forward(ctx, buf, *parts):
+        ctx.widths = [p.shape[2] for p in parts]
+        ctx.dtypes = [p.dtype for p in parts]
+        assert sum(ctx.widths) == buf.shape[2]
+        return buf.view_as(buf)
+
+    @staticmethod
+    def backward(ctx, g):
+        outs, c = [], 0
+        for w, dt in zip(ctx.widths, ctx.dtypes):
+            outs.append(g[:, :, c:c + w].to(dt).contiguous())
+            c += w
+        return (None, *outs)

@@ -363,11 +363,14 @@ int gcn_cast_pad_bf16(const float *x_pm, long rows, int C, void *x_pm_bf16, void
 
 /* GroupNorm(G, Cout, eps) + LeakyReLU(slope) on the routed extreme:
  *   out_cm (B,Cout,N) f32 (the reference's layout) and/or out_pm (B,N,Cout); either may be NULL
- *   mean_rstd (B,G,2) f32 (may be NULL): statistics for backward. */
+ *   mean_rstd (B,G,2) f32 (may be NULL): statistics for backward.
+ *   out_pm_bf16 (may be NULL): the point-major result once more, rounded to bf16, rows bf16_pitch elements apart
+ *   (>= Cout) -- a column slice of the consumer's concatenated input (the encoder's cat(x1,x2,x3), M4:507), so that
+ *   neither the cat nor the autocast conversion runs as a separate pass. */
 int gcn_edgeconv_finish(const float *ymax, const float *ymin, const double *gsum,
                         const float *gamma, const float *beta, int B, int N, int k, int Cout,
                         int G, float eps, float slope, float *out_cm, float *out_pm,
-                        float *mean_rstd, void *stream);
+                        float *mean_rstd, void *out_pm_bf16, int bf16_pitch, void *stream);
 
 /* Graph aggregations used by the EdgeConv backward (no counterpart kernel in the reference: its
  * autograd walks the materialised (B,2C,N,k) tensor).  x_pm (B,N,C) f32, idx (B,N,k) int64.
