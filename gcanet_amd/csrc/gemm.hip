@@ -17,6 +17,8 @@
 // accumulator group: 8- or 16-byte stores instead of 2-byte ones.
 #include "common.h"
 
+#include <algorithm>
+
 #include <cstdlib>
 #include <type_traits>
 
@@ -516,6 +518,180 @@ __global__ __launch_bounds__(256) void gemm_wgrad_fold_kernel(const float *__res
   *reinterpret_cast<float4 *>(o) = s;
 }
 
+
+// ------------------------------------------------------------------ weight gradient of the NARROW layers
+// dW (N,K) = dY (M,N)^T . X (M,K), db = column sums of dY, for N <= 32 of any value (the 10-, 22- and 3-wide output layers
+// of the heads, M4:661,678,448; the 30x30 layers of KPAM, M4:351-373) -- shapes the matrix-core kernel above does not take
+// (N % 8, 16-byte rows) and the library serves as split-K bmm + a partial-sum pass + a separate column sum (~55 us a
+// layer at M = 65536).  0.7 GFLOP: a streaming VALU kernel.  Workgroup = 256 rows: the dY slab goes to LDS as f32
+// ([row][NMAX], zero padded), a thread owns 4 columns of X and rows rl, rl + RL, ...; per row 4 x NMAX FMAs against
+// broadcast LDS reads; the row lanes meet by wave butterflies + one LDS tile per wave; per-workgroup partial
+// tiles are added in workgroup order by wgrad_narrow_fold_kernel.  Either operand may be bf16 or f32.
+constexpr int WN_ROWS = 256;     // rows per workgroup
+constexpr int WN_CBG = 16;       // column groups (of 4) per workgroup: 64 columns
+
+template <bool BF>
+__device__ __forceinline__ float wn_load(const void *p, long i) {
+  return BF ? __uint_as_float((unsigned int)((const unsigned short *)p)[i] << 16) : ((const float *)p)[i];
+}
+
+// grid = (row slabs, column blocks).  cbg = column groups per workgroup (a power of two <= 16), RL = 256 / cbg row lanes.
+template <int NMAX, bool BFY, bool BFX>
+__global__ __launch_bounds__(256) void wgrad_narrow_kernel(const void *__restrict__ dY, const void *__restrict__ X, long M, int N,
+                                                           int K, int cbg, float *__restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) float wn_lds[];
+  float *sdy = wn_lds;                       // [WN_ROWS][NMAX]
+  float *sacc = wn_lds + WN_ROWS * NMAX;     // [4 waves][NMAX][64] + [NMAX]   (Kq = cbg * 4 <= 64 columns of this block)
+  const int Kq = cbg * 4;
+  const long r0 = (long)blockIdx.x * WN_ROWS;
+  const int rows = (int)min((long)WN_ROWS, M - r0);
+  // dY slab -> LDS [row][NMAX] f32.  The slab is one contiguous piece of memory: 16-byte chunks, all of a thread's chunks
+  // requested before the first is used (a load-convert-store loop paid the memory latency 64 times: 40-60 us per launch)
+  for (int i = threadIdx.x; i < WN_ROWS * NMAX / 4; i += 256) reinterpret_cast<float4 *>(sdy)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+  {
+    constexpr int EPC = BFY ? 8 : 4;                     // elements per 16-byte chunk
+    constexpr int CH = (WN_ROWS * 32 / EPC + 255) / 256; // chunks per thread at N = 32
+    const long e0 = r0 * N;
+    const int ne = rows * N;
+    const bool al = (((uintptr_t)dY & 15) == 0);         // slab offset e0 * sizeof is a multiple of 16 (512-row slabs)
+    uint4 raw[CH];
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const int e = (threadIdx.x + u * 256) * EPC;
+      raw[u] = make_uint4(0u, 0u, 0u, 0u);
+      if (al && e + EPC <= ne)
+        raw[u] = *reinterpret_cast<const uint4 *>((const char *)dY + (e0 + e) * (BFY ? 2 : 4));
+    }
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const int e = (threadIdx.x + u * 256) * EPC;
+      if (e >= ne) continue;
+      const bool fast = al && e + EPC <= ne;
+      const unsigned int w[4] = {raw[u].x, raw[u].y, raw[u].z, raw[u].w};
+      int r = e / N, n = e - r * N;
+#pragma unroll
+      for (int t = 0; t < EPC; ++t) {
+        if (e + t < ne) {
+          float v;
+          if (fast) v = BFY ? __uint_as_float((t & 1) ? (w[t >> 1] & 0xffff0000u) : (w[t >> 1] << 16)) : __uint_as_float(w[t & 3]);
+          else v = wn_load<BFY>(dY, e0 + e + t);
+          sdy[r * NMAX + n] = v;
+        }
+        if (++n == N) { n = 0; ++r; }
+      }
+    }
+  }
+  __syncthreads();
+  const int cg = threadIdx.x % cbg, rl = threadIdx.x / cbg, RL = 256 / cbg;
+  const int cl = cg * 4;                               // column inside the block
+  const int c0 = blockIdx.y * Kq + cl;                 // column of X
+  float acc[NMAX][4];
+#pragma unroll
+  for (int n = 0; n < NMAX; ++n) acc[n][0] = acc[n][1] = acc[n][2] = acc[n][3] = 0.f;
+  const bool vec = (K % 4 == 0) && c0 < K && (((uintptr_t)X & 15) == 0);
+  auto loadx = [&](int r, float (&xv)[4]) {
+    const long o = (r0 + r) * K + c0;
+    if (vec) {
+      if (BFX) {
+        const ushort4 u = *reinterpret_cast<const ushort4 *>((const unsigned short *)X + o);
+        xv[0] = __uint_as_float((unsigned int)u.x << 16); xv[1] = __uint_as_float((unsigned int)u.y << 16);
+        xv[2] = __uint_as_float((unsigned int)u.z << 16); xv[3] = __uint_as_float((unsigned int)u.w << 16);
+      } else {
+        const float4 f = *reinterpret_cast<const float4 *>((const float *)X + o);
+        xv[0] = f.x; xv[1] = f.y; xv[2] = f.z; xv[3] = f.w;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xv[j] = (c0 + j < K) ? wn_load<BFX>(X, o + j) : 0.f;
+    }
+  };
+  auto fma_row = [&](int r, const float (&xv)[4]) {
+    const float4 *d4 = reinterpret_cast<const float4 *>(sdy + r * NMAX);
+#pragma unroll
+    for (int q = 0; q < NMAX / 4; ++q) {
+      const float4 d = d4[q];
+      const float dd[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[q * 4 + e][j] = fmaf(dd[e], xv[j], acc[q * 4 + e][j]);
+    }
+  };
+  int r = rl;
+  for (; r + 7 * RL < rows; r += 8 * RL) {                   // eight rows in flight per thread
+    float xv[8][4];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) loadx(r + u * RL, xv[u]);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) fma_row(r + u * RL, xv[u]);
+  }
+  for (; r < rows; r += RL) {
+    float xv[4];
+    loadx(r, xv);
+    fma_row(r, xv);
+  }
+  // the row lanes meet: inside a wave by butterflies over the lane bits above the column group; each wave then stores
+  // its tile (compile-time offsets, 16-byte stores) and the four tiles are added on the way out.  (ds_add_f32 retires
+  // 0.33 lanes/clk; read-modify-write rounds with a run-time tile stride serialised into ~8 us per wave.)
+  for (int off = cbg; off < 64; off <<= 1) {
+#pragma unroll
+    for (int n = 0; n < NMAX; ++n)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[n][j] += __shfl_xor(acc[n][j], off);
+  }
+  if ((lane_id() / cbg) == 0) {
+    float *tw = sacc + wave_id() * (NMAX * 64) + cl;
+#pragma unroll
+    for (int n = 0; n < NMAX; ++n) *reinterpret_cast<float4 *>(tw + n * 64) = make_float4(acc[n][0], acc[n][1], acc[n][2], acc[n][3]);
+  }
+  // column sums of dY (the bias gradient), by the workgroups of column block 0: thread t < NMAX walks column t of the slab
+  float *sbias = sacc + 4 * NMAX * 64;
+  if (blockIdx.y == 0 && (int)threadIdx.x < NMAX) {
+    float sb = 0.f;
+    for (int q = 0; q < rows; ++q) sb += sdy[q * NMAX + threadIdx.x];
+    sbias[threadIdx.x] = sb;
+  }
+  __syncthreads();
+  float *pw = part + (size_t)blockIdx.x * ((size_t)N * K + N);
+  const int kb = min(Kq, K - (int)blockIdx.y * Kq);          // columns of this block that exist
+  for (int i = threadIdx.x; i < N * kb; i += 256) {
+    const int n = i / kb, c = i - n * kb;
+    const float *t0 = sacc + n * 64 + c;
+    pw[(long)n * K + blockIdx.y * Kq + c] = ((t0[0] + t0[NMAX * 64]) + t0[2 * NMAX * 64]) + t0[3 * NMAX * 64];
+  }
+  if (blockIdx.y == 0 && (int)threadIdx.x < N) pw[(size_t)N * K + threadIdx.x] = sbias[threadIdx.x];
+}
+
+// dW / db = the row slabs' partial results added in slab order.  Workgroup = 64 results x 4 slab groups (a thread adds
+// every fourth slab, eight loads in flight), the four groups are combined through LDS in group order.
+__global__ __launch_bounds__(256) void wgrad_narrow_fold_kernel(const float *__restrict__ part, int slices, long nw, long nb,
+                                                                float *__restrict__ dW, float *__restrict__ db) {
+  __shared__ float sg[4][64];
+  const int e = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const long i = (long)blockIdx.x * 64 + e;
+  const long pitch = nw + nb;
+  float s = 0.f;
+  if (i < pitch) {
+    int z = grp;
+    for (; z + 28 < slices; z += 32) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = part[(long)(z + 4 * u) * pitch + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; z < slices; z += 4) s += part[(long)z * pitch + i];
+  }
+  sg[grp][e] = s;
+  __syncthreads();
+  if (grp == 0 && i < pitch) {
+    const float t = ((sg[0][e] + sg[1][e]) + sg[2][e]) + sg[3][e];
+    if (i < nw) dW[i] = t;
+    else if (db) db[i - nw] = t;
+  }
+}
+
 }  // namespace gcn
 
 using namespace gcn;
@@ -611,4 +787,63 @@ GCN_EXPORT int gcn_gemm_wgrad_bf16(const void *dY, const void *X, long M, int N,
   const long nw = (long)N * K, nb = N, tot = nw + (db ? nb : 0);
   gemm_wgrad_fold_kernel<<<(int)((tot / 4 + 255) / 256), 256, 0, st>>>(a.part, p.slices, nw, nb, dW, db);
   return check_launch("gemm_wgrad_fold_kernel");
+}
+
+static int wn_kcp(int K) {                 // column groups of 4, rounded up to a power of two
+  int kc = (K + 3) / 4, p = 1;
+  while (p < kc) p <<= 1;
+  return p;
+}
+static int wn_nmax(int N) { return N <= 4 ? 4 : (N <= 16 ? 16 : 32); }
+static size_t wn_lds_bytes(int N, int K) {
+  const int cbg = std::min(wn_kcp(K), WN_CBG);
+  (void)cbg;
+  return sizeof(float) * ((size_t)WN_ROWS * wn_nmax(N) + (size_t)4 * wn_nmax(N) * 64 + wn_nmax(N));
+}
+
+GCN_EXPORT int gcn_wgrad_narrow_supported(long M, int N, int K) {
+  if (M < 1 || N < 1 || N > 32 || K < 1 || K > 1024) return 0;
+  return wn_lds_bytes(N, K) <= 128 * 1024 ? 1 : 0;
+}
+
+GCN_EXPORT long gcn_wgrad_narrow_ws_bytes(long M, int N, int K) {
+  if (!gcn_wgrad_narrow_supported(M, N, K)) return -1;
+  return (long)(sizeof(float) * (size_t)((M + WN_ROWS - 1) / WN_ROWS) * ((size_t)N * K + N));
+}
+
+template <int NMAX>
+static int wn_launch(const void *dY, int y_bf16, const void *X, int x_bf16, long M, int N, int K, float *part, hipStream_t st) {
+  const int kcp = wn_kcp(K), cbg = std::min(kcp, WN_CBG);
+  const size_t lds = wn_lds_bytes(N, K);
+  const dim3 grid((unsigned int)((M + WN_ROWS - 1) / WN_ROWS), (unsigned int)(kcp / cbg));
+#define WN_GO(BY, BX)                                                                                                   \
+  do {                                                                                                                  \
+    GCN_HIP(hipFuncSetAttribute((const void *)wgrad_narrow_kernel<NMAX, BY, BX>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)lds));                                                                             \
+    wgrad_narrow_kernel<NMAX, BY, BX><<<grid, 256, lds, st>>>(dY, X, M, N, K, cbg, part);                                 \
+  } while (0)
+  if (y_bf16 && x_bf16) WN_GO(true, true);
+  else if (y_bf16) WN_GO(true, false);
+  else if (x_bf16) WN_GO(false, true);
+  else WN_GO(false, false);
+#undef WN_GO
+  return check_launch("wgrad_narrow_kernel");
+}
+
+GCN_EXPORT int gcn_wgrad_narrow(const void *dY, int dy_bf16, const void *X, int x_bf16, long M, int N, int K, float *dW,
+                                float *db, void *ws, void *stream) {
+  GCN_REQUIRE(dY && X && dW && ws, "gcn_wgrad_narrow: null pointer");
+  GCN_REQUIRE(gcn_wgrad_narrow_supported(M, N, K), "gcn_wgrad_narrow: need 1 <= N <= 32, 1 <= K <= 1024 within the LDS budget, got N=%d K=%d", N, K);
+  GCN_REQUIRE(((uintptr_t)ws & 15) == 0, "gcn_wgrad_narrow: ws must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  float *part = (float *)ws;
+  int rc;
+  const int nmax = wn_nmax(N);
+  if (nmax == 4) rc = wn_launch<4>(dY, dy_bf16, X, x_bf16, M, N, K, part, st);
+  else if (nmax == 16) rc = wn_launch<16>(dY, dy_bf16, X, x_bf16, M, N, K, part, st);
+  else rc = wn_launch<32>(dY, dy_bf16, X, x_bf16, M, N, K, part, st);
+  if (rc) return rc;
+  const long nw = (long)N * K, nb = N;
+  wgrad_narrow_fold_kernel<<<(int)((nw + nb + 63) / 64), 256, 0, st>>>(part, (int)((M + WN_ROWS - 1) / WN_ROWS), nw, nb, dW, db);
+  return check_launch("wgrad_narrow_fold_kernel");
 }

@@ -279,6 +279,40 @@ def _wgrad_own(dy2, x2, with_bias):
     return dw, db
 
 
+def _wgrad_narrow(dy2, x2, with_bias):
+    """(dW (N,K) f32, db (N,) f32 | None) for a layer with at most 32 outputs -- or, operands swapped, at most 32 inputs --
+    in one streaming pass (csrc/gemm.hip: gcn_wgrad_narrow); None when the shape is not served."""
+    if os.environ.get("GCANET_GEMM", "auto") == "lib" or not (dy2.is_cuda and dy2.is_contiguous() and x2.is_contiguous()):
+        return None
+    ok = (torch.float32, torch.bfloat16)
+    if dy2.dtype not in ok or x2.dtype not in ok:
+        return None
+    M, N = dy2.shape
+    K = x2.shape[1]
+    L = _lib.lib()
+    swap = False
+    # where it wins (tools/wgrad_narrow_bench.py, M = 65536): 3x256 16 us vs 55 (library: split-K bmm + partial sum +
+    # column sum), 30x30 22 vs 45, 3x128 f32 13 vs 52; it is a VALU kernel with 4 N accumulators per lane -- at 10x256
+    # it ties (35 vs 33) and at 22x256 it loses (69 vs 35), so those stay with the library
+    small = lambda n, k: n <= 4 or n * k <= 1024
+    if not (N <= 32 and small(N, K) and L.gcn_wgrad_narrow_supported(M, N, K)):
+        if with_bias or not (K <= 32 and small(K, N) and L.gcn_wgrad_narrow_supported(M, K, N)):
+            return None
+        swap = True                                    # narrow INPUT: dW^T = X^T . dY from the same kernel
+        dy2, x2, N, K = x2, dy2, K, N
+    raw = torch.empty(N * K + (N if with_bias else 0), dtype=torch.float32, device=dy2.device)
+    dw = raw[:N * K].view(N, K)
+    db = raw[N * K:] if with_bias else None
+    need = L.gcn_wgrad_narrow_ws_bytes(M, N, K)
+    ws = _WGRAD_WS.get(("narrow", dy2.device))
+    if ws is None or ws.numel() < need:
+        ws = _WGRAD_WS[("narrow", dy2.device)] = torch.empty(need, dtype=torch.uint8, device=dy2.device)
+    with _lib.on_device(dy2):
+        _lib.call("gcn_wgrad_narrow", _lib.ptr(dy2), int(dy2.dtype == torch.bfloat16), _lib.ptr(x2),
+                  int(x2.dtype == torch.bfloat16), M, N, K, _lib.ptr(dw), _lib.ptr(db), _lib.ptr(ws), _lib.stream_of(dy2))
+    return (dw.t() if swap else dw), db
+
+
 class LinearPMFunction(torch.autograd.Function):
     """y = x @ W^T + b on point-major rows with a split-K weight gradient (see tall_skinny_tn).
     Runs in the autocast dtype (bf16 under torch.autocast, as the plain F.linear would).  With gn_groups > 0 the
@@ -334,9 +368,12 @@ class LinearPMFunction(torch.autograd.Function):
                 N, K = ctx.nk
                 Kx = xc.shape[-1]
                 dx = (dy @ wc[:N]).to(ctx.in_dtypes[0])                   # (.., Kx); the zero-weight padding columns get 0
+                nar = None if N % 8 == 0 else _wgrad_narrow(rows, xc.reshape(-1, Kx), ctx.has_bias)
                 if N % 8 == 0:                                            # csrc/gemm.hip: transpose-read weight gradient
                     dwf, db = _wgrad_own(rows, xc.reshape(-1, Kx), ctx.has_bias)
                     dw = dwf[:, :K].to(ctx.in_dtypes[1])
+                elif nar is not None:                                     # narrow outputs (10, 22, 3, 30): one streaming pass
+                    dw, db = nar[0][:, :K].to(ctx.in_dtypes[1]), nar[1]
                 else:
                     dw = tall_skinny_tn(rows, xc.reshape(-1, Kx), out_dtype=ctx.in_dtypes[1])[:, :K]
             else:
@@ -344,11 +381,16 @@ class LinearPMFunction(torch.autograd.Function):
                 if ctx.kx != wc.shape[1]:
                     dx = torch.nn.functional.pad(dx, (0, ctx.kx - wc.shape[1]))
                 x2 = xc.reshape(-1, xc.shape[-1])
+                nar = None
                 if _own_wgrad(rows, x2):
                     dwf, db = _wgrad_own(rows, x2, ctx.has_bias)
                     dw = dwf.to(ctx.in_dtypes[1])
                 else:
-                    dw = tall_skinny_tn(rows, x2, out_dtype=ctx.in_dtypes[1])
+                    nar = _wgrad_narrow(rows, x2, ctx.has_bias)
+                    if nar is not None:
+                        dw, db = nar[0].to(ctx.in_dtypes[1]), nar[1]
+                    else:
+                        dw = tall_skinny_tn(rows, x2, out_dtype=ctx.in_dtypes[1])
             if ctx.has_bias and db is None:
                 db = rows.sum(0, dtype=torch.float32)                     # f32 accumulation, no f32 copy of dy
         return dx, dw, db, None

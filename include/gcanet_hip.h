@@ -561,6 +561,17 @@ int gcn_gemm_bf16(const void *A, const void *W, const float *bias, void *out, in
 long gcn_gemm_wgrad_ws_bytes(long M, int N, int K);
 int gcn_gemm_wgrad_bf16(const void *dY, const void *X, long M, int N, int K, float *dW, float *db, void *ws, void *stream);
 
+/* Weight (and bias) gradient of a NARROW 1x1 layer: dW (N,K) f32 = dY (M,N)^T . X (M,K), db (N) f32 = column sums of dY
+ * (db may be NULL), for 1 <= N <= 32 and 1 <= K <= 1024 of any value -- the 10-, 22- and 3-wide outputs of the heads
+ * (M4:661,678,448) and KPAM's 30x30 layers (M4:351-373), which gcn_gemm_wgrad_bf16 does not take.  dY and X are
+ * contiguous row-major, each bf16 (flag 1) or f32 (flag 0).  One streaming pass; per-workgroup partial tiles in ws
+ * (gcn_wgrad_narrow_ws_bytes bytes, 16-byte aligned) are added in a fixed order.  dW / db are fully overwritten.
+ * A layer with a narrow INPUT instead (K <= 32 < N) is the same call with the operands swapped: it returns dW^T. */
+int gcn_wgrad_narrow_supported(long M, int N, int K);
+long gcn_wgrad_narrow_ws_bytes(long M, int N, int K);
+int gcn_wgrad_narrow(const void *dY, int dy_bf16, const void *X, int x_bf16, long M, int N, int K, float *dW, float *db,
+                     void *ws, void *stream);
+
 /* ------------------------------------------------------------- attention stacks ------ */
 
 /* Fused scaled-dot-product attention forward (online softmax; the (Lq x Lk) score matrix never

@@ -96,3 +96,66 @@ def test_gemm_weight_gradient(dev, M, N, K):
     _lib.call("gcn_gemm_wgrad_bf16", _lib.ptr(dY), _lib.ptr(X), M, N, K, _lib.ptr(again), _lib.ptr(again[N * K:]), _lib.ptr(ws),
               _lib.stream_of(X))
     assert torch.equal(again, raw)
+
+
+@pytest.mark.parametrize("M,N,K,ybf,xbf", [(65536, 10, 256, 1, 1), (65536, 22, 256, 1, 1), (65536, 3, 256, 1, 1),
+                                           (65536, 30, 30, 1, 1), (65536, 3, 128, 0, 0), (1000, 32, 512, 0, 1),
+                                           (777, 1, 1, 0, 0), (4099, 7, 20, 1, 0), (300, 16, 1024, 1, 1), (257, 5, 262, 0, 1)])
+def test_wgrad_narrow(dev, M, N, K, ybf, xbf):
+    """gcn_wgrad_narrow: dW = dY^T X and db = column sums for the narrow layers (N <= 32, any K <= 1024, bf16 / f32
+    operands) vs f64 torch; fixed fold order -> a second run gives the same bits.  LinearPMFunction's backward goes
+    through it for the 10-, 22-, 3-wide heads and KPAM's 30x30 layers (and, operands swapped, the K = 3 projection)."""
+    from gcanet_amd import _lib
+    g = torch.Generator().manual_seed(M + N + K)
+    dY = torch.randn(M, N, generator=g)
+    X = torch.randn(M, K, generator=g)
+    dY = (dY.bfloat16() if ybf else dY).to(dev)
+    X = (X.bfloat16() if xbf else X).to(dev)
+    assert _lib.lib().gcn_wgrad_narrow_supported(M, N, K)
+    ws = torch.empty(_lib.lib().gcn_wgrad_narrow_ws_bytes(M, N, K), dtype=torch.uint8, device=dev)
+    raw = torch.full((N * K + N,), 7.0, device=dev)
+
+    def run(out):
+        _lib.call("gcn_wgrad_narrow", _lib.ptr(dY), ybf, _lib.ptr(X), xbf, M, N, K, _lib.ptr(out), _lib.ptr(out[N * K:]), _lib.ptr(ws),
+                  _lib.stream_of(X))
+    run(raw)
+    ref = (dY.double().t() @ X.double()).cpu().numpy()
+    dbr = dY.double().sum(0).cpu().numpy()
+    np.testing.assert_allclose(raw[:N * K].view(N, K).cpu().numpy(), ref, rtol=1e-4, atol=2e-5 * float(np.abs(ref).max()) + 1e-6)
+    np.testing.assert_allclose(raw[N * K:].cpu().numpy(), dbr, rtol=1e-4, atol=2e-5 * float(np.abs(dbr).max()) + 1e-6)
+    again = torch.empty_like(raw)
+    run(again)
+    assert torch.equal(again, raw)
+    dW = torch.empty(N, K, device=dev)                          # without the bias gradient
+    _lib.call("gcn_wgrad_narrow", _lib.ptr(dY), ybf, _lib.ptr(X), xbf, M, N, K, _lib.ptr(dW), None, _lib.ptr(ws), _lib.stream_of(X))
+    assert torch.equal(dW.reshape(-1), raw[:N * K])
+
+
+def test_linear_pm_narrow_layers_gradients(dev):
+    """LinearPMFunction with narrow outputs / inputs under bf16 autocast and in f32: weight, bias and input gradients vs
+    torch's own linear in f64 (the narrow weight-gradient kernel and its operand-swapped form sit behind these)."""
+    from gcanet_amd.layers import linear_pm
+    g = torch.Generator().manual_seed(5)
+    for (M, N, K, auto) in ((8192, 10, 256, True), (8192, 22, 256, True), (8192, 3, 256, True), (8192, 30, 30, True),
+                            (8192, 128, 3, False), (8192, 30, 30, False)):
+        x = torch.randn(2, M // 2, K, generator=g)
+        w = torch.randn(N, K, generator=g) / K ** 0.5
+        b = torch.randn(N, generator=g) if K != 3 else None
+        go = torch.randn(2, M // 2, N, generator=g)
+        xd, wd = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True)
+        bd = b.to(dev).requires_grad_(True) if b is not None else None
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=auto):
+            y = linear_pm(xd, wd, bd)
+        y.backward(go.to(dev).to(y.dtype))
+        if auto:            # what the bf16 path sees: rounded operands, f32 accumulation
+            xr, wr, gr = x.bfloat16().double(), w.bfloat16().double(), go.bfloat16().double()
+        else:
+            xr, wr, gr = x.double(), w.double(), go.double()
+        dw = gr.reshape(-1, N).t() @ xr.reshape(-1, K)
+        tol = 2e-2 if auto else 1e-4
+        np.testing.assert_allclose(wd.grad.double().cpu().numpy(), dw.numpy(), rtol=tol, atol=tol * float(dw.abs().max()))
+        if b is not None:
+            db = gr.reshape(-1, N).sum(0)
+            np.testing.assert_allclose(bd.grad.double().cpu().numpy(), db.numpy(), rtol=tol, atol=tol * float(db.abs().max()))
+        dx = gr @ wr
+        np.testing.assert_allclose(xd.grad.double().cpu().numpy(), dx.numpy(), rtol=tol, atol=tol * float(dx.abs().max()))
