@@ -282,7 +282,8 @@ def _wgrad_own(dy2, x2, with_bias):
 def _wgrad_narrow(dy2, x2, with_bias):
     """(dW (N,K) f32, db (N,) f32 | None) for a layer with at most 32 outputs -- or, operands swapped, at most 32 inputs --
     in one streaming pass (csrc/gemm.hip: gcn_wgrad_narrow); None when the shape is not served."""
-    if os.environ.get("GCANET_GEMM", "auto") == "lib" or not (dy2.is_cuda and dy2.is_contiguous() and x2.is_contiguous()):
+    if os.environ.get("GCANET_GEMM", "auto") == "lib" or os.environ.get("GCANET_NARROW", "1") == "0" \
+            or not (dy2.is_cuda and dy2.is_contiguous() and x2.is_contiguous()):
         return None
     ok = (torch.float32, torch.bfloat16)
     if dy2.dtype not in ok or x2.dtype not in ok:
