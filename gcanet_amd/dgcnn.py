@@ -605,6 +605,7 @@ class DGCNNEncoderGn(nn.Module):
         self.mlp1 = nn.Conv1d(256, 1024, 1)
         self.bnmlp1 = nn.GroupNorm(8, 1024)
         self.last_idx = None
+        self.direct_slices = True      # finish kernels write the bf16 slices of cat(x1,x2,x3) (False: torch.cat + conversion)
 
     def forward_pm(self, x_cm, x_pm=None, idxs=None):
         """Point-major core: x_cm (B,Cin,N) feeds the kNN, x_pm (B,N,Cin) the row gathers.
@@ -625,7 +626,8 @@ class DGCNNEncoderGn(nn.Module):
         # under bf16 autocast both consumers of cat(x1,x2,x3) (mlp1 here, conv1's feature half in the caller) read it in
         # bf16: the three finish kernels write their bf16 column slice of that tensor directly (no cat, no conversion
         # pass), and the two input gradients meet in bf16 and come back as three slice conversions
-        direct = bool(x_pm.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16)
+        direct = bool(self.direct_slices and x_pm.is_cuda and torch.is_autocast_enabled()
+                      and torch.get_autocast_dtype("cuda") == torch.bfloat16)
         xf16 = torch.empty(B_, N_, 256, dtype=torch.bfloat16, device=x_pm.device) if direct else None
         sl = (lambda a, b: xf16[:, :, a:b]) if direct else (lambda a, b: None)
         x1, x1_cm = edge_conv_pm(x_pm, idx1, self.conv1._modules["0"].weight, self.bn1, self.dtype, want_cm=not fast,

@@ -179,3 +179,36 @@ def test_full_forward_train_runs_end_to_end(dev):
     assert len(grads) > 100 and all(torch.isfinite(g_).all() for g_ in grads)
     assert net.instance_head.tiny_unet.blocks.block0.conv_branch[2].weight.grad.abs().sum() > 0
     assert net.point_net.mlp_seg_prob2.weight.grad.abs().sum() > 0          # the embedding feeds the sparse head
+
+
+def test_encoder_direct_bf16_slices_equal_cat(dev):
+    """Under bf16 autocast the three EdgeConv finish kernels write their column slice of cat(x1,x2,x3) in bf16 themselves
+    (gcn_edgeconv_finish out_pm_bf16 / dgcnn.ConcatSlicesFunction) instead of torch.cat + the autocast conversion: the
+    encoder's outputs must be bit-identical either way (same values, rounded once), and so must the gradients that come
+    back through the slices (given the same neighbour lists; f32 atomics-free backward kernels on both sides)."""
+    from gcanet_amd import dgcnn
+    g = torch.Generator().manual_seed(9)
+    B, N, k = 2, 640, 16
+    pts = torch.cat([torch.rand(B, N, 3, generator=g), torch.nn.functional.normalize(torch.randn(B, N, 3, generator=g), dim=-1)], -1)
+    wout = torch.randn(B, N, 256, generator=g).to(dev)
+    w4 = torch.randn(B, 1024, generator=g).to(dev)
+    res = {}
+    idxs = None
+    for direct in (True, False):
+        torch.manual_seed(0)
+        enc = dgcnn.DGCNNEncoderGn(mode=5, nn_nb=k, input_channels=6, dtype="bf16").to(dev)
+        enc.direct_slices = direct
+        x_pm = pts.to(dev).requires_grad_(False)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            xf, x4 = enc.forward_pm(x_pm.transpose(1, 2).contiguous(), x_pm, idxs=idxs)
+        if idxs is None:
+            idxs = enc.last_idx
+        assert xf.dtype == torch.bfloat16 and xf.shape == (B, N, 256)
+        ((xf.float() * wout).sum() + (x4.float() * w4).sum()).backward()
+        res[direct] = (xf.detach().float(), x4.detach().float(),
+                       {n_: p_.grad.clone() for n_, p_ in enc.named_parameters() if p_.grad is not None})
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    for n_, gb in res[False][2].items():
+        ga = res[True][2][n_]
+        d = (ga - gb).abs().max().item()
+        assert d <= 1e-5 * max(gb.abs().max().item(), 1e-6) + 1e-8, (n_, d)
