@@ -619,12 +619,13 @@ __global__ __launch_bounds__(256) void wgrad_narrow_kernel(const void *__restric
     }
   };
   int r = rl;
-  for (; r + 7 * RL < rows; r += 8 * RL) {                   // eight rows in flight per thread
-    float xv[8][4];
+  constexpr int UF = NMAX > 16 ? 4 : 8;                      // rows in flight per thread (register budget: 4 NMAX accumulators)
+  for (; r + (UF - 1) * RL < rows; r += UF * RL) {
+    float xv[UF][4];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) loadx(r + u * RL, xv[u]);
+    for (int u = 0; u < UF; ++u) loadx(r + u * RL, xv[u]);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) fma_row(r + u * RL, xv[u]);
+    for (int u = 0; u < UF; ++u) fma_row(r + u * RL, xv[u]);
   }
   for (; r < rows; r += RL) {
     float xv[4];
