@@ -619,7 +619,7 @@ __global__ __launch_bounds__(256) void wgrad_narrow_kernel(const void *__restric
     }
   };
   int r = rl;
-  constexpr int UF = NMAX > 16 ? 4 : 8;                      // rows in flight per thread (register budget: 4 NMAX accumulators)
+  constexpr int UF = NMAX >= 16 ? 4 : 8;                     // rows in flight per thread (register budget: 4 NMAX accumulators)
   for (; r + (UF - 1) * RL < rows; r += UF * RL) {
     float xv[UF][4];
 #pragma unroll
@@ -647,13 +647,31 @@ __global__ __launch_bounds__(256) void wgrad_narrow_kernel(const void *__restric
     for (int n = 0; n < NMAX; ++n) *reinterpret_cast<float4 *>(tw + n * 64) = make_float4(acc[n][0], acc[n][1], acc[n][2], acc[n][3]);
   }
   // column sums of dY (the bias gradient), by the workgroups of column block 0: thread t < NMAX walks column t of the slab
-  float *sbias = sacc + 4 * NMAX * 64;
-  if (blockIdx.y == 0 && (int)threadIdx.x < NMAX) {
+  // (256 / NMAX row lanes per column, eight independent LDS reads in flight, then one add per lane in lane order: a single
+  // thread per column walking 256 rows was a serial ~8-us tail in every workgroup of column block 0)
+  float *sbias = sacc + 4 * NMAX * 64;          // [256 / NMAX][NMAX] partial sums
+  if (blockIdx.y == 0) {
+    constexpr int BL = 256 / NMAX;
+    const int n = threadIdx.x % NMAX, bl = threadIdx.x / NMAX;
     float sb = 0.f;
-    for (int q = 0; q < rows; ++q) sb += sdy[q * NMAX + threadIdx.x];
-    sbias[threadIdx.x] = sb;
+    int q = bl;
+    for (; q + 7 * BL < WN_ROWS; q += 8 * BL) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = sdy[(q + u * BL) * NMAX + n];     // rows >= `rows` are zero
+#pragma unroll
+      for (int u = 0; u < 8; ++u) sb += v[u];
+    }
+    for (; q < WN_ROWS; q += BL) sb += sdy[q * NMAX + n];
+    sbias[bl * NMAX + n] = sb;
   }
   __syncthreads();
+  float sbt = 0.f;
+  if (blockIdx.y == 0 && (int)threadIdx.x < NMAX) {
+    constexpr int BL = 256 / NMAX;
+#pragma unroll
+    for (int u = 0; u < BL; ++u) sbt += sbias[u * NMAX + threadIdx.x];
+  }
   float *pw = part + (size_t)blockIdx.x * ((size_t)N * K + N);
   const int kb = min(Kq, K - (int)blockIdx.y * Kq);          // columns of this block that exist
   for (int i = threadIdx.x; i < N * kb; i += 256) {
@@ -661,7 +679,7 @@ __global__ __launch_bounds__(256) void wgrad_narrow_kernel(const void *__restric
     const float *t0 = sacc + n * 64 + c;
     pw[(long)n * K + blockIdx.y * Kq + c] = ((t0[0] + t0[NMAX * 64]) + t0[2 * NMAX * 64]) + t0[3 * NMAX * 64];
   }
-  if (blockIdx.y == 0 && (int)threadIdx.x < N) pw[(size_t)N * K + threadIdx.x] = sbias[threadIdx.x];
+  if (blockIdx.y == 0 && (int)threadIdx.x < N) pw[(size_t)N * K + threadIdx.x] = sbt;
 }
 
 // dW / db = the row slabs' partial results added in slab order.  Workgroup = 64 results x 4 slab groups (a thread adds
@@ -799,7 +817,7 @@ static int wn_nmax(int N) { return N <= 4 ? 4 : (N <= 16 ? 16 : 32); }
 static size_t wn_lds_bytes(int N, int K) {
   const int cbg = std::min(wn_kcp(K), WN_CBG);
   (void)cbg;
-  return sizeof(float) * ((size_t)WN_ROWS * wn_nmax(N) + (size_t)4 * wn_nmax(N) * 64 + wn_nmax(N));
+  return sizeof(float) * ((size_t)WN_ROWS * wn_nmax(N) + (size_t)4 * wn_nmax(N) * 64 + 256);
 }
 
 GCN_EXPORT int gcn_wgrad_narrow_supported(long M, int N, int K) {

@@ -293,9 +293,9 @@ def _wgrad_narrow(dy2, x2, with_bias):
     L = _lib.lib()
     swap = False
     # where it wins (tools/wgrad_narrow_bench.py, M = 65536): 3x256 16 us vs 55 (library: split-K bmm + partial sum +
-    # column sum), 30x30 22 vs 45, 3x128 f32 13 vs 52; it is a VALU kernel with 4 N accumulators per lane -- at 10x256
-    # it ties (35 vs 33) and at 22x256 it loses (69 vs 35), so those stay with the library
-    small = lambda n, k: n <= 4 or n * k <= 1024
+    # column sum), 30x30 21 vs 34-45, 3x128 f32 11 vs 52, 10x256 25 vs 35; it is a VALU kernel with 4 N accumulators per
+    # lane -- beyond 16 outputs only two waves fit a SIMD and 22x256 loses (48 vs 35): that one stays with the library
+    small = lambda n, k: n <= 4 or n * k <= 1024 or (n <= 16 and k <= 256)
     if not (N <= 32 and small(N, K) and L.gcn_wgrad_narrow_supported(M, N, K)):
         if with_bias or not (K <= 32 and small(K, N) and L.gcn_wgrad_narrow_supported(M, K, N)):
             return None
