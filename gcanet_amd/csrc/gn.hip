@@ -48,29 +48,36 @@ __device__ __forceinline__ void store4(void *p, long i, const float (&v)[4]) {
 struct Slab {
   int c4, row0, rstep, nc4, reps;  // reps > 1 when C/4 > 256: thread also owns c4 + 1024*i
 };
-__device__ __forceinline__ Slab make_slab(int C) {
+__device__ __forceinline__ Slab make_slab(int C, int nt = 256) {
   Slab s;
   const int q = C / 4;
-  if (q <= 256) {
-    s.c4 = (threadIdx.x % q) * 4; s.row0 = threadIdx.x / q; s.rstep = 256 / q; s.nc4 = q; s.reps = 1;
+  if (q <= nt) {
+    s.c4 = (threadIdx.x % q) * 4; s.row0 = threadIdx.x / q; s.rstep = nt / q; s.nc4 = q; s.reps = 1;
   } else {
-    s.c4 = threadIdx.x * 4; s.row0 = 0; s.rstep = 1; s.nc4 = q; s.reps = q / 256;
+    s.c4 = threadIdx.x * 4; s.row0 = 0; s.rstep = 1; s.nc4 = q; s.reps = (q + nt - 1) / nt;   // callers skip c >= C
   }
   return s;
 }
 
+// threads per workgroup of the backward reduction pass: same row slabs, twice the waves of a 256-thread workgroup -- the
+// 512 workgroups of a (8, 8192, C) tensor left 1.8 waves per SIMD resident, 72 % of their cycles waiting on memory (SQ
+// counters): 31 -> 29 us per launch on average.  The forward statistics pass (one tensor) got slower that way: 256.
+constexpr int GN_RT = 512;
+constexpr int GN_ST = 256;
+
 template <bool BF16>
-__global__ __launch_bounds__(256) void gn_stats_kernel(const void *__restrict__ x, int N, int C, int G, int rows_per_block,
+__global__ __launch_bounds__(GN_ST) void gn_stats_kernel(const void *__restrict__ x, int N, int C, int G, int rows_per_block,
                                                        double *__restrict__ gsum) {
   extern __shared__ double sm[];
-  for (int i = threadIdx.x; i < 2 * G; i += 256) sm[i] = 0.0;
+  for (int i = threadIdx.x; i < 2 * G; i += GN_ST) sm[i] = 0.0;
   __syncthreads();
   const int b = blockIdx.y;
   const int r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, N);
-  const Slab s = make_slab(C);
+  const Slab s = make_slab(C, GN_ST);
   const int cpg = C / G;
   for (int rep = 0; rep < s.reps; ++rep) {
-    const int c = s.c4 + rep * 1024;
+    const int c = s.c4 + rep * (GN_ST * 4);
+    if (c >= C) break;                                          // C/4 a multiple of 256 but not of GN_ST
     float a1 = 0.f, a2 = 0.f;
     // four rows in flight per thread (8-byte loads: one row at a time leaves the memory system idle -- 3 TB/s)
     int r = r0 + s.row0;
@@ -248,24 +255,25 @@ __global__ void gn_max_unpack_kernel(const unsigned long long *__restrict__ best
 
 // backward pass 1: S (B,G,2) = [sum gamma*g, sum gamma*g*xhat], dgamma/dbeta (C) (accumulated, pre-zeroed)
 template <bool BF16>
-__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const void *__restrict__ dy, const void *__restrict__ x,
+__global__ __launch_bounds__(GN_RT) void gn_bwd_reduce_kernel(const void *__restrict__ dy, const void *__restrict__ x,
                                                             const float *__restrict__ gamma, const float *__restrict__ beta,
                                                             const float *__restrict__ mean_rstd, int N, int C, int G,
                                                             int relu, int rows_per_block, double *__restrict__ part_s,
                                                             float *__restrict__ part_c) {
   extern __shared__ double sm[];
-  for (int i = threadIdx.x; i < 2 * G; i += 256) sm[i] = 0.0;
+  for (int i = threadIdx.x; i < 2 * G; i += GN_RT) sm[i] = 0.0;
   {
     float *cs0 = reinterpret_cast<float *>(sm + 2 * G);
-    for (int i = threadIdx.x; i < 2 * C; i += 256) cs0[i] = 0.f;
+    for (int i = threadIdx.x; i < 2 * C; i += GN_RT) cs0[i] = 0.f;
   }
   __syncthreads();
   const int b = blockIdx.y;
   const int r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, N);
-  const Slab s = make_slab(C);
+  const Slab s = make_slab(C, GN_RT);
   const int cpg = C / G;
   for (int rep = 0; rep < s.reps; ++rep) {
-    const int c = s.c4 + rep * 1024;
+    const int c = s.c4 + rep * (GN_RT * 4);
+    if (c >= C) break;                                          // C/4 a multiple of 256 but not of GN_RT
     const int g = c / cpg;
     const float mean = mean_rstd[((long)b * G + g) * 2], rstd = mean_rstd[((long)b * G + g) * 2 + 1];
     const float4 ga = *reinterpret_cast<const float4 *>(gamma + c);
@@ -322,7 +330,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const void *__restri
   if ((int)threadIdx.x < 2 * G) part_s[blk * 2 * G + threadIdx.x] = sm[threadIdx.x];
   {
     const float *cs = reinterpret_cast<const float *>(sm + 2 * G);
-    for (int i = threadIdx.x; i < 2 * C; i += 256) part_c[blk * 2 * C + i] = cs[i];
+    for (int i = threadIdx.x; i < 2 * C; i += GN_RT) part_c[blk * 2 * C + i] = cs[i];
   }
 }
 
@@ -533,10 +541,10 @@ GCN_EXPORT int gcn_gn_fwd(const void *x, int dtype, const float *gamma, const fl
   const dim3 g1(cdiv(N, rows), B);
   const int g2 = (int)(((long)N * C / 4 + 255) / 256 > 2048 ? 2048 : ((long)N * C / 4 + 255) / 256);
   if (dtype == 1) {
-    gn_stats_kernel<true><<<g1, 256, sizeof(double) * 2 * G, st>>>(x, N, C, G, rows, gsum_ws);
+    gn_stats_kernel<true><<<g1, GN_ST, sizeof(double) * 2 * G, st>>>(x, N, C, G, rows, gsum_ws);
     gn_apply_kernel<true><<<dim3(g2, B), 256, 0, st>>>(x, gsum_ws, gamma, beta, N, C, G, eps, relu, y, mean_rstd);
   } else {
-    gn_stats_kernel<false><<<g1, 256, sizeof(double) * 2 * G, st>>>(x, N, C, G, rows, gsum_ws);
+    gn_stats_kernel<false><<<g1, GN_ST, sizeof(double) * 2 * G, st>>>(x, N, C, G, rows, gsum_ws);
     gn_apply_kernel<false><<<dim3(g2, B), 256, 0, st>>>(x, gsum_ws, gamma, beta, N, C, G, eps, relu, y, mean_rstd);
   }
   return check_launch("gn_fwd");
@@ -578,11 +586,11 @@ GCN_EXPORT int gcn_gn_bwd(const void *dy, const void *x, int dtype, const float 
   const dim3 g1(nblk, B);
   const int g2 = (int)(((long)N * C / 4 + 255) / 256 > 2048 ? 2048 : ((long)N * C / 4 + 255) / 256);
   if (dtype == 1) {
-    gn_bwd_reduce_kernel<true><<<g1, 256, sizeof(double) * 2 * G + sizeof(float) * 2 * C, st>>>(dy, x, gamma, beta, mean_rstd, N, C, G, relu, rows, part_s, part_c);
+    gn_bwd_reduce_kernel<true><<<g1, GN_RT, sizeof(double) * 2 * G + sizeof(float) * 2 * C, st>>>(dy, x, gamma, beta, mean_rstd, N, C, G, relu, rows, part_s, part_c);
     fold_partials_kernel<<<cdiv(2 * C, 64) + cdiv(B * 2 * G, 64), 256, 0, st>>>(part_s, part_c, nblk, B, C, G, S, dgamma, dbeta);
     gn_bwd_apply_kernel<true><<<dim3(g2, B), 256, 0, st>>>(dy, x, gamma, beta, mean_rstd, S, N, C, G, relu, dx);
   } else {
-    gn_bwd_reduce_kernel<false><<<g1, 256, sizeof(double) * 2 * G + sizeof(float) * 2 * C, st>>>(dy, x, gamma, beta, mean_rstd, N, C, G, relu, rows, part_s, part_c);
+    gn_bwd_reduce_kernel<false><<<g1, GN_RT, sizeof(double) * 2 * G + sizeof(float) * 2 * C, st>>>(dy, x, gamma, beta, mean_rstd, N, C, G, relu, rows, part_s, part_c);
     fold_partials_kernel<<<cdiv(2 * C, 64) + cdiv(B * 2 * G, 64), 256, 0, st>>>(part_s, part_c, nblk, B, C, G, S, dgamma, dbeta);
     gn_bwd_apply_kernel<false><<<dim3(g2, B), 256, 0, st>>>(dy, x, gamma, beta, mean_rstd, S, N, C, G, relu, dx);
   }
@@ -603,10 +611,10 @@ GCN_EXPORT int gcn_gn_max_fwd(const void *x, int dtype, const float *gamma, cons
   const dim3 g1(cdiv(N, rows), B);
   unsigned long long *best = (unsigned long long *)best_ws;
   if (dtype == 1) {
-    gn_stats_kernel<true><<<g1, 256, sizeof(double) * 2 * G, st>>>(x, N, C, G, rows, gsum_ws);
+    gn_stats_kernel<true><<<g1, GN_ST, sizeof(double) * 2 * G, st>>>(x, N, C, G, rows, gsum_ws);
     gn_apply_max_kernel<true><<<g1, 256, 0, st>>>(x, gsum_ws, gamma, beta, N, C, G, eps, relu, rows, best, mean_rstd);
   } else {
-    gn_stats_kernel<false><<<g1, 256, sizeof(double) * 2 * G, st>>>(x, N, C, G, rows, gsum_ws);
+    gn_stats_kernel<false><<<g1, GN_ST, sizeof(double) * 2 * G, st>>>(x, N, C, G, rows, gsum_ws);
     gn_apply_max_kernel<false><<<g1, 256, 0, st>>>(x, gsum_ws, gamma, beta, N, C, G, eps, relu, rows, best, mean_rstd);
   }
   gn_max_unpack_kernel<<<cdiv((long)B * C, 256), 256, 0, st>>>(best, (long)B * C, out_max, out_arg);

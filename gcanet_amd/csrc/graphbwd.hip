@@ -23,7 +23,10 @@ struct DspBuckets {
   int rshift, P;               // rows per partition = 1 << rshift, partitions per cloud
 };
 
-__global__ __launch_bounds__(256) void route_bwd_kernel(const float *__restrict__ dout, const float *__restrict__ ymax,
+// RB_NT threads per workgroup: the loop is a chain of dependent loads (extreme -> neighbour id -> staging slot); with 256
+// threads the 512 workgroups of the bench shape left 1.7 waves per SIMD resident, 85 % of their cycles waiting (SQ counters)
+constexpr int RB_NT = 1024;
+__global__ __launch_bounds__(RB_NT) void route_bwd_kernel(const float *__restrict__ dout, const float *__restrict__ ymax,
                                                         const float *__restrict__ ymin, const unsigned char *__restrict__ amax,
                                                         const unsigned char *__restrict__ amin, const float *__restrict__ gamma,
                                                         const float *__restrict__ beta, const float *__restrict__ mean_rstd,
@@ -35,13 +38,13 @@ __global__ __launch_bounds__(256) void route_bwd_kernel(const float *__restrict_
                                                         DspBuckets bk, double *__restrict__ part_s,
                                                         float *__restrict__ part_c) {
   extern __shared__ double sm[];             // 2*G doubles, then 2*Cout floats
-  __shared__ float amax_s[4];
+  __shared__ float amax_s[RB_NT / 64];
   __shared__ int bcnt[64];                   // entries this workgroup has filed per destination partition
   float cfmax = 0.f;                         // max |coef| of this thread (scale of the fixed-point scatter)
   if (bk.stag_coef && threadIdx.x < 64) bcnt[threadIdx.x] = 0;
   float *cs = reinterpret_cast<float *>(sm + 2 * G);
-  for (int i = threadIdx.x; i < 2 * G; i += 256) sm[i] = 0.0;
-  for (int i = threadIdx.x; i < 2 * Cout; i += 256) cs[i] = 0.f;
+  for (int i = threadIdx.x; i < 2 * G; i += RB_NT) sm[i] = 0.0;
+  for (int i = threadIdx.x; i < 2 * Cout; i += RB_NT) cs[i] = 0.f;
   __syncthreads();
   int tile, b;
   xcd_tile_cloud(tile, b);
@@ -49,7 +52,7 @@ __global__ __launch_bounds__(256) void route_bwd_kernel(const float *__restrict_
   const int cpg = Cout / G;
   // thread -> fixed channel (Cout <= 256 and divides 256, or a multiple of 256)
   const int nct = Cout <= 256 ? Cout : 256;
-  const int rstep = 256 / nct > 0 ? 256 / nct : 1;
+  const int rstep = RB_NT / nct;
   for (int c = threadIdx.x % nct; c < Cout; c += 256) {
     const int g = c / cpg;
     const float mean = mean_rstd[((long)b * G + g) * 2], rstd = mean_rstd[((long)b * G + g) * 2 + 1];
@@ -104,7 +107,12 @@ __global__ __launch_bounds__(256) void route_bwd_kernel(const float *__restrict_
   __syncthreads();
   if (bk.stag_coef) {
     if (threadIdx.x == 0)                      // non-negative floats order like their bit patterns
-      atomicMax(bk.absmax, __float_as_uint(fmaxf(fmaxf(amax_s[0], amax_s[1]), fmaxf(amax_s[2], amax_s[3]))));
+    {
+      float mx = 0.f;
+#pragma unroll
+      for (int w = 0; w < RB_NT / 64; ++w) mx = fmaxf(mx, amax_s[w]);
+      atomicMax(bk.absmax, __float_as_uint(mx));
+    }
     if ((int)threadIdx.x < bk.P) bk.counts[((long)b * bk.P + threadIdx.x) * gridDim.x + tile] = min(bcnt[threadIdx.x], DSP_CAP);
   }
   if (part_s) {
@@ -112,11 +120,11 @@ __global__ __launch_bounds__(256) void route_bwd_kernel(const float *__restrict_
     // cost ~25 us of contention per launch and made the sums order-dependent)
     const long blk = (long)b * gridDim.x + tile;
     if ((int)threadIdx.x < 2 * G) part_s[blk * 2 * G + threadIdx.x] = sm[threadIdx.x];
-    for (int i = threadIdx.x; i < 2 * Cout; i += 256) part_c[blk * 2 * Cout + i] = cs[i];
+    for (int i = threadIdx.x; i < 2 * Cout; i += RB_NT) part_c[blk * 2 * Cout + i] = cs[i];
     return;
   }
   if ((int)threadIdx.x < 2 * G) atomicAdd(S + (long)b * G * 2 + threadIdx.x, sm[threadIdx.x]);
-  for (int i = threadIdx.x; i < Cout; i += 256) {
+  for (int i = threadIdx.x; i < Cout; i += RB_NT) {
     atomicAdd(dgamma + i, cs[i]);
     atomicAdd(dbeta + i, cs[Cout + i]);
   }
@@ -506,7 +514,7 @@ GCN_EXPORT int gcn_route_bwd(const float *dout_pm, const float *ymax, const floa
                        {lds_scatter ? dsp_ws : nullptr, lds_scatter ? 256u : 0u}));
   }
   if (dsp && !lds_scatter) GCN_HIP(zero_dev(dsp, sizeof(float) * (size_t)B * N * Cout, st));
-  route_bwd_kernel<<<dim3(cdiv(N, rows), B), 256, sizeof(double) * 2 * G + sizeof(float) * 2 * Cout, st>>>(
+  route_bwd_kernel<<<dim3(cdiv(N, rows), B), RB_NT, sizeof(double) * 2 * G + sizeof(float) * 2 * Cout, st>>>(
       dout_pm, ymax, ymin, amax, amin, gamma, beta, mean_rstd, idx, N, k, Cout, G, slope, rows, coef, jsel, msel, dsp,
       dgamma, dbeta, S, bk, part_s, part_c);
   int rc = check_launch("route_bwd_kernel");

@@ -7,7 +7,7 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("B,N,C,G", [(2, 300, 64, 2), (1, 1000, 256, 4), (2, 513, 512, 8), (1, 128, 1024, 8), (2, 77, 128, 4)])
+@pytest.mark.parametrize("B,N,C,G", [(2, 300, 64, 2), (1, 1000, 256, 4), (2, 513, 512, 8), (1, 128, 1024, 8), (2, 77, 128, 4), (1, 40, 3072, 8)])
 @pytest.mark.parametrize("relu", [True, False])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_group_norm_relu_fwd_bwd(dev, B, N, C, G, relu, dtype):
@@ -34,7 +34,7 @@ def test_group_norm_relu_fwd_bwd(dev, B, N, C, G, relu, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("B,N,C,G", [(2, 300, 64, 2), (3, 1000, 1024, 8), (1, 17, 256, 4), (2, 64, 2048, 1), (2, 40, 2048, 4)])
+@pytest.mark.parametrize("B,N,C,G", [(2, 300, 64, 2), (3, 1000, 1024, 8), (1, 17, 256, 4), (2, 64, 2048, 1), (2, 40, 2048, 4), (1, 33, 3072, 8)])
 def test_group_norm_relu_max_matches_two_step(dev, dtype, B, N, C, G):
     """Fused GN+ReLU+max-over-points equals group_norm_relu followed by max(dim=1), values and gradients."""
     from gcanet_amd import layers
