@@ -493,31 +493,44 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_bf16_kernel(WgradArgs a) {
 // the reads and the MFMAs of a stage run back to back.  A 128 x 128 wave tile needs all 256 AGPRs as accumulators and
 // hipcc then moves ~200 registers between the two halves of the register file per stage, with builtins and with
 // "+a"-constrained asm alike.  The four-wave workgroups below at least overlap across waves.)
-// dW (and db) = the slices' partial results added in slice order; thread = 4 consecutive values, 8 slices in flight
+// dW (and db) = the slices' partial results added in a fixed order.  Workgroup = 64 x 4 consecutive values x 4 slice
+// groups: a thread adds every fourth slice, eight 16-byte loads in flight, the four group sums meet in LDS in group
+// order.  (One thread walking all ~128 slices of a narrow layer, eight at a time, was 16 dependent memory round trips:
+// 8.7 us per launch, eight launches per step, 0.3 resident waves per SIMD.)
 __global__ __launch_bounds__(256) void gemm_wgrad_fold_kernel(const float *__restrict__ part, int slices, long nw, long nb,
                                                               float *__restrict__ dW, float *__restrict__ db) {
-  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  __shared__ float4 sg[4][64];
+  const int e = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const long i = ((long)blockIdx.x * 64 + e) * 4;
   const long tot = nw + (db ? nb : 0);
-  if (i >= tot) return;
   const long pitch = nw + nb;
-  const float4 *p = reinterpret_cast<const float4 *>(part + i);
   float4 s = {0.f, 0.f, 0.f, 0.f};
-  int z = 0;
-  for (; z + 8 <= slices; z += 8) {
-    float4 v[8];
+  if (i < tot) {
+    const float4 *p = reinterpret_cast<const float4 *>(part + i);
+    int z = grp;
+    for (; z + 28 < slices; z += 32) {
+      float4 v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = p[(long)(z + u) * (pitch / 4)];
+      for (int u = 0; u < 8; ++u) v[u] = p[(long)(z + 4 * u) * (pitch / 4)];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+      for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+    }
+    for (; z < slices; z += 4) {
+      const float4 v = p[(long)z * (pitch / 4)];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
   }
-  for (; z < slices; ++z) {
-    const float4 v = p[(long)z * (pitch / 4)];
-    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  sg[grp][e] = s;
+  __syncthreads();
+  if (grp == 0 && i < tot) {
+    const float4 a0 = sg[0][e], a1 = sg[1][e], a2 = sg[2][e], a3 = sg[3][e];
+    float4 t;
+    t.x = ((a0.x + a1.x) + a2.x) + a3.x; t.y = ((a0.y + a1.y) + a2.y) + a3.y;
+    t.z = ((a0.z + a1.z) + a2.z) + a3.z; t.w = ((a0.w + a1.w) + a2.w) + a3.w;
+    float *o = i < nw ? dW + i : db + (i - nw);
+    *reinterpret_cast<float4 *>(o) = t;
   }
-  float *o = i < nw ? dW + i : db + (i - nw);
-  *reinterpret_cast<float4 *>(o) = s;
 }
-
 
 // ------------------------------------------------------------------ weight gradient of the NARROW layers
 // dW (N,K) = dY (M,N)^T . X (M,K), db = column sums of dY, for N <= 32 of any value (the 10-, 22- and 3-wide output layers
@@ -804,7 +817,7 @@ GCN_EXPORT int gcn_gemm_wgrad_bf16(const void *dY, const void *X, long M, int N,
   int rc = check_launch("gemm_wgrad_bf16_kernel");
   if (rc) return rc;
   const long nw = (long)N * K, nb = N, tot = nw + (db ? nb : 0);
-  gemm_wgrad_fold_kernel<<<(int)((tot / 4 + 255) / 256), 256, 0, st>>>(a.part, p.slices, nw, nb, dW, db);
+  gemm_wgrad_fold_kernel<<<(int)((tot / 4 + 63) / 64), 256, 0, st>>>(a.part, p.slices, nw, nb, dW, db);
   return check_launch("gemm_wgrad_fold_kernel");
 }
 
