@@ -271,6 +271,10 @@ __global__ __launch_bounds__(GN_RT) void gn_bwd_reduce_kernel(const void *__rest
   const int r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, N);
   const Slab s = make_slab(C, GN_RT);
   const int cpg = C / G;
+  const int lpg = cpg / 4;                                      // lanes (4-channel groups) per GroupNorm group
+  // slot scheme: one row-lane tile slot per thread, group sums by wave butterflies (needs one channel group per thread and
+  // a power-of-two lpg <= 64, true for every layer of the model; the host sizes the LDS accordingly)
+  const bool slots = s.reps == 1 && lpg <= 64 && (lpg & (lpg - 1)) == 0;
   for (int rep = 0; rep < s.reps; ++rep) {
     const int c = s.c4 + rep * (GN_RT * 4);
     if (c >= C) break;                                          // C/4 a multiple of 256 but not of GN_RT
@@ -312,21 +316,54 @@ __global__ __launch_bounds__(GN_RT) void gn_bwd_reduce_kernel(const void *__rest
       load4<BF16>(dy, o, gv);
       accum(xv, gv);
     }
-    // per-channel partials: combine the row slices of the workgroup in LDS, then ONE global atomic per
-    // (workgroup, channel) -- per-thread global atomics on C addresses were 14x contended
-    float *cs = reinterpret_cast<float *>(sm + 2 * G);   // [2][C]
+    if (slots) {
+      // every thread owns one slot of the [row lane][2][C] tile (16-byte stores, no atomics: ds_add_f32 from 512 threads
+      // x 8 values was 10 of the kernel's 29 us); the group sums meet by butterflies over the lpg lanes of a group
+      float *tile = reinterpret_cast<float *>(sm + 2 * G + 2 * GN_RT);      // [RL][2][C]
+      const int rl = threadIdx.x / s.nc4;
+      *reinterpret_cast<float4 *>(tile + ((long)rl * 2) * C + c) = make_float4(dg[0], dg[1], dg[2], dg[3]);
+      *reinterpret_cast<float4 *>(tile + ((long)rl * 2 + 1) * C + c) = make_float4(db[0], db[1], db[2], db[3]);
+      double d1 = (double)s1, d2 = (double)s2;
+      for (int off = 1; off < lpg; off <<= 1) { d1 += __shfl_xor(d1, off); d2 += __shfl_xor(d2, off); }
+      if ((threadIdx.x % lpg) == 0) {
+        double *seg = sm + 2 * G;                                            // [GN_RT / lpg][2]  (<= 2 GN_RT doubles)
+        seg[(threadIdx.x / lpg) * 2] = d1;
+        seg[(threadIdx.x / lpg) * 2 + 1] = d2;
+      }
+    } else {
+      // generic shapes: combine the row slices of the workgroup with LDS atomics
+      float *cs = reinterpret_cast<float *>(sm + 2 * G);   // [2][C]
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      atomicAdd(&cs[c + i], dg[i]);
-      atomicAdd(&cs[C + c + i], db[i]);
+      for (int i = 0; i < 4; ++i) {
+        atomicAdd(&cs[c + i], dg[i]);
+        atomicAdd(&cs[C + c + i], db[i]);
+      }
+      atomicAdd(&sm[g * 2], (double)s1);
+      atomicAdd(&sm[g * 2 + 1], (double)s2);
     }
-    atomicAdd(&sm[g * 2], (double)s1);
-    atomicAdd(&sm[g * 2 + 1], (double)s2);
   }
   __syncthreads();
   // per-workgroup partials, folded by fold_partials_kernel (common.h): 512 workgroups adding to the same 2C + 2G addresses
   // cost ~25 us of contention per launch, whatever the tensor size (and made the sums order-dependent)
   const long blk = (long)b * gridDim.x + blockIdx.x;
+  if (slots) {
+    const int RL = GN_RT / s.nc4, nseg = GN_RT / lpg;
+    if ((int)threadIdx.x < 2 * G) {                     // group g = segment index mod G; fixed order
+      const double *seg = sm + 2 * G;
+      const int g = threadIdx.x >> 1, j = threadIdx.x & 1;
+      double t = 0.0;
+      for (int q = g; q < nseg; q += G) t += seg[q * 2 + j];
+      part_s[blk * 2 * G + threadIdx.x] = t;
+    }
+    const float *tile = reinterpret_cast<const float *>(sm + 2 * G + 2 * GN_RT);
+    for (int i = threadIdx.x; i < 2 * C; i += GN_RT) {
+      const int which = i / C, c = i - which * C;
+      float t = 0.f;
+      for (int rl = 0; rl < RL; ++rl) t += tile[((long)rl * 2 + which) * C + c];
+      part_c[blk * 2 * C + i] = t;
+    }
+    return;
+  }
   if ((int)threadIdx.x < 2 * G) part_s[blk * 2 * G + threadIdx.x] = sm[threadIdx.x];
   {
     const float *cs = reinterpret_cast<const float *>(sm + 2 * G);
@@ -519,6 +556,13 @@ static int gn_check(const char *who, int B, int N, int C, int G, int dtype) {
   return GCN_OK;
 }
 
+// dynamic LDS of gn_bwd_reduce_kernel: [2G] f64 group sums, [2 GN_RT] f64 segment sums (2 per lpg lanes), then the larger
+// of the slot tile (GN_RT x 8 f32) and the atomic path's [2][C] f32
+static size_t gn_reduce_lds(int C, int G) {
+  const size_t fl = (size_t)GN_RT * 8 > (size_t)2 * C ? (size_t)GN_RT * 8 : (size_t)2 * C;
+  return sizeof(double) * (2 * (size_t)G + 2 * GN_RT) + sizeof(float) * fl;
+}
+
 static int slab_rows(int N, int B) {
   int blocks = (512 + B - 1) / B;  // ~2 workgroups per CU in total
   int rows = (N + blocks - 1) / blocks;
@@ -586,11 +630,11 @@ GCN_EXPORT int gcn_gn_bwd(const void *dy, const void *x, int dtype, const float 
   const dim3 g1(nblk, B);
   const int g2 = (int)(((long)N * C / 4 + 255) / 256 > 2048 ? 2048 : ((long)N * C / 4 + 255) / 256);
   if (dtype == 1) {
-    gn_bwd_reduce_kernel<true><<<g1, GN_RT, sizeof(double) * 2 * G + sizeof(float) * 2 * C, st>>>(dy, x, gamma, beta, mean_rstd, N, C, G, relu, rows, part_s, part_c);
+    gn_bwd_reduce_kernel<true><<<g1, GN_RT, gn_reduce_lds(C, G), st>>>(dy, x, gamma, beta, mean_rstd, N, C, G, relu, rows, part_s, part_c);
     fold_partials_kernel<<<cdiv(2 * C, 64) + cdiv(B * 2 * G, 64), 256, 0, st>>>(part_s, part_c, nblk, B, C, G, S, dgamma, dbeta);
     gn_bwd_apply_kernel<true><<<dim3(g2, B), 256, 0, st>>>(dy, x, gamma, beta, mean_rstd, S, N, C, G, relu, dx);
   } else {
-    gn_bwd_reduce_kernel<false><<<g1, GN_RT, sizeof(double) * 2 * G + sizeof(float) * 2 * C, st>>>(dy, x, gamma, beta, mean_rstd, N, C, G, relu, rows, part_s, part_c);
+    gn_bwd_reduce_kernel<false><<<g1, GN_RT, gn_reduce_lds(C, G), st>>>(dy, x, gamma, beta, mean_rstd, N, C, G, relu, rows, part_s, part_c);
     fold_partials_kernel<<<cdiv(2 * C, 64) + cdiv(B * 2 * G, 64), 256, 0, st>>>(part_s, part_c, nblk, B, C, G, S, dgamma, dbeta);
     gn_bwd_apply_kernel<false><<<dim3(g2, B), 256, 0, st>>>(dy, x, gamma, beta, mean_rstd, S, N, C, G, relu, dx);
   }
