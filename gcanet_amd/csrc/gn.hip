@@ -75,6 +75,8 @@ __global__ __launch_bounds__(GN_ST) void gn_stats_kernel(const void *__restrict_
   const int r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, N);
   const Slab s = make_slab(C, GN_ST);
   const int cpg = C / G;
+  const int lpg = cpg / 4;
+  const bool slots = s.reps == 1 && lpg <= 64 && (lpg & (lpg - 1)) == 0;     // see gn_bwd_reduce_kernel
   for (int rep = 0; rep < s.reps; ++rep) {
     const int c = s.c4 + rep * (GN_ST * 4);
     if (c >= C) break;                                          // C/4 a multiple of 256 but not of GN_ST
@@ -97,8 +99,24 @@ __global__ __launch_bounds__(GN_ST) void gn_stats_kernel(const void *__restrict_
       for (int i = 0; i < 4; ++i) { a1 += v[i]; a2 = fmaf(v[i], v[i], a2); }
     }
     // 4 consecutive channels share a group (cpg % 4 == 0)
-    atomicAdd(&sm[(c / cpg) * 2], (double)a1);
-    atomicAdd(&sm[(c / cpg) * 2 + 1], (double)a2);
+    if (slots) {                 // group sums by butterflies over the lpg lanes of a group, one slot per segment (no LDS atomics)
+      double d1 = (double)a1, d2 = (double)a2;
+      for (int off = 1; off < lpg; off <<= 1) { d1 += __shfl_xor(d1, off); d2 += __shfl_xor(d2, off); }
+      if ((threadIdx.x % lpg) == 0) {
+        sm[2 * G + (threadIdx.x / lpg) * 2] = d1;
+        sm[2 * G + (threadIdx.x / lpg) * 2 + 1] = d2;
+      }
+    } else {
+      atomicAdd(&sm[(c / cpg) * 2], (double)a1);
+      atomicAdd(&sm[(c / cpg) * 2 + 1], (double)a2);
+    }
+  }
+  __syncthreads();
+  if (slots && (int)threadIdx.x < 2 * G) {             // group g = segment index mod G; fixed order
+    const int g = threadIdx.x >> 1, j = threadIdx.x & 1, nseg = GN_ST / lpg;
+    double t = 0.0;
+    for (int q = g; q < nseg; q += G) t += sm[2 * G + q * 2 + j];
+    sm[threadIdx.x] = t;          // (threads < 2G only read segment slots and write their own sm[t])
   }
   __syncthreads();
   if ((int)threadIdx.x < 2 * G) atomicAdd(gsum + (long)b * G * 2 + threadIdx.x, sm[threadIdx.x]);
@@ -585,10 +603,10 @@ GCN_EXPORT int gcn_gn_fwd(const void *x, int dtype, const float *gamma, const fl
   const dim3 g1(cdiv(N, rows), B);
   const int g2 = (int)(((long)N * C / 4 + 255) / 256 > 2048 ? 2048 : ((long)N * C / 4 + 255) / 256);
   if (dtype == 1) {
-    gn_stats_kernel<true><<<g1, GN_ST, sizeof(double) * 2 * G, st>>>(x, N, C, G, rows, gsum_ws);
+    gn_stats_kernel<true><<<g1, GN_ST, sizeof(double) * (2 * G + 2 * GN_ST), st>>>(x, N, C, G, rows, gsum_ws);
     gn_apply_kernel<true><<<dim3(g2, B), 256, 0, st>>>(x, gsum_ws, gamma, beta, N, C, G, eps, relu, y, mean_rstd);
   } else {
-    gn_stats_kernel<false><<<g1, GN_ST, sizeof(double) * 2 * G, st>>>(x, N, C, G, rows, gsum_ws);
+    gn_stats_kernel<false><<<g1, GN_ST, sizeof(double) * (2 * G + 2 * GN_ST), st>>>(x, N, C, G, rows, gsum_ws);
     gn_apply_kernel<false><<<dim3(g2, B), 256, 0, st>>>(x, gsum_ws, gamma, beta, N, C, G, eps, relu, y, mean_rstd);
   }
   return check_launch("gn_fwd");
@@ -655,10 +673,10 @@ GCN_EXPORT int gcn_gn_max_fwd(const void *x, int dtype, const float *gamma, cons
   const dim3 g1(cdiv(N, rows), B);
   unsigned long long *best = (unsigned long long *)best_ws;
   if (dtype == 1) {
-    gn_stats_kernel<true><<<g1, GN_ST, sizeof(double) * 2 * G, st>>>(x, N, C, G, rows, gsum_ws);
+    gn_stats_kernel<true><<<g1, GN_ST, sizeof(double) * (2 * G + 2 * GN_ST), st>>>(x, N, C, G, rows, gsum_ws);
     gn_apply_max_kernel<true><<<g1, 256, 0, st>>>(x, gsum_ws, gamma, beta, N, C, G, eps, relu, rows, best, mean_rstd);
   } else {
-    gn_stats_kernel<false><<<g1, GN_ST, sizeof(double) * 2 * G, st>>>(x, N, C, G, rows, gsum_ws);
+    gn_stats_kernel<false><<<g1, GN_ST, sizeof(double) * (2 * G + 2 * GN_ST), st>>>(x, N, C, G, rows, gsum_ws);
     gn_apply_max_kernel<false><<<g1, 256, 0, st>>>(x, gsum_ws, gamma, beta, N, C, G, eps, relu, rows, best, mean_rstd);
   }
   gn_max_unpack_kernel<<<cdiv((long)B * C, 256), 256, 0, st>>>(best, (long)B * C, out_max, out_arg);
