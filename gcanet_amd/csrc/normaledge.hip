@@ -208,16 +208,19 @@ __global__ __launch_bounds__(1024) void normal_edge_bwd_kernel(const float *__re
     }
   }
   // workgroup-level sums in LDS first
-  __shared__ float red[128 * NE_F + NE_F + NE_F * NE_F];
-  float *rdw = red, *res = red + 128 * NE_F, *rgr = res + NE_F;
-  for (int i = threadIdx.x; i < 128 * NE_F + NE_F + NE_F * NE_F; i += 1024) red[i] = 0.f;
+  __shared__ float red[NE_F + NE_F * NE_F];
+  float *res = red, *rgr = res + NE_F;
+  for (int i = threadIdx.x; i < NE_F + NE_F * NE_F; i += 1024) red[i] = 0.f;
   __syncthreads();
+  // per-wave slots, added in wave order on the way out (7 ds_add_f32 per lane from 16 waves onto the same words were
+  // ~7000 LDS atomics per workgroup at 0.33 lanes/clk; stride 7 between lanes is conflict free)
+  __shared__ float wdw[16][128 * NE_F];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const int c = h * 64 + lane;
     if (c < Cout) {
 #pragma unroll
-      for (int f = 0; f < NE_F; ++f) atomicAdd(&rdw[c * NE_F + f], dw[h][f]);
+      for (int f = 0; f < NE_F; ++f) wdw[wave_id()][c * NE_F + f] = dw[h][f];
     }
   }
 #pragma unroll
@@ -241,7 +244,12 @@ __global__ __launch_bounds__(1024) void normal_edge_bwd_kernel(const float *__re
       }
     }
   __syncthreads();
-  for (int i = threadIdx.x; i < Cout * NE_F; i += 1024) atomicAdd(dWsp + (long)b * Cout * NE_F + i, rdw[i]);
+  for (int i = threadIdx.x; i < Cout * NE_F; i += 1024) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += wdw[w][i];
+    atomicAdd(dWsp + (long)b * Cout * NE_F + i, t);
+  }
   if (threadIdx.x < NE_F) atomicAdd(esum + (long)b * NE_F + threadIdx.x, res[threadIdx.x]);
   if (threadIdx.x < NE_F * NE_F) atomicAdd(gram + (long)b * NE_F * NE_F + threadIdx.x, rgr[threadIdx.x]);
 }
