@@ -20,6 +20,11 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# ROCm 7.2's HIP-graph "packet capture" fast path faults (memory access fault raised by the command processor, no wave
+# active) when a captured step is replayed again after the queue has gone idle -- reproduced 3 runs out of 4 at 2 clouds
+# per GPU, never with the fast path off (tools/debug/replay_sync_loop.py).  Must be set before the
+# HIP runtime loads, i.e. before `import torch`.
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 
 
 def parse_args(argv=None):
@@ -273,6 +278,59 @@ def full_workload(args, dev, steps=5, warmup=2):
             "proposals": info.get("proposals"), "members": info.get("members"), "loss": info.get("loss")}
 
 
+def make_step(model, pts, nrm, world=1, lr=1e-3):
+    """The training step bench.py times, as one closure (tests/test_step_parity_gpu.py runs exactly this):
+    zero_grad -> arena.begin_step -> one multi-tensor bf16 weight cast -> forward under bf16 autocast -> synthetic
+    objective -> backward -> gradient packing (+ RCCL all-reduce when world > 1) -> flat Adam.
+    Returns dict(step, fwd_bwd, dp, opt, arena, casts)."""
+    from gcanet_amd import parallel
+    from gcanet_amd.layers import CastCache, ZeroArena
+    from gcanet_amd.optim import FlatAdam
+    dev = pts.device
+    dp = parallel.FlatGradDP(model, world, late=model.encoder.parameters())   # heads' all-reduce overlaps the encoder's backward
+    dp.sync_params()
+    # option_new.py:83-90 trains with Adam(lr=1e-3): the same rule as ONE elementwise kernel over the flat parameter /
+    # gradient / moment buffers (gcanet_amd/optim.py; torch's multi-tensor launches take 0.2 ms for these 57 tensors)
+    opt = FlatAdam(dp, lr=lr)
+    arena = ZeroArena(dev)            # the small accumulators of a step come pre-zeroed from one allocation: one fill per step
+    # bf16 weight copies (in the GEMM kernel's padded operand layout): one multi-tensor cast per step, not one per layer
+    casts = CastCache(model, pad_k={model.conv3.weight: (model.conv3.weight.shape[1] + 15) // 16 * 16})
+
+    def fwd_bwd():
+        dp.zero_grad()
+        arena.begin_step()
+        casts.refresh()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = model(pts, nrm)
+        loss = loss_of(out)
+        loss.backward()
+        return loss
+
+    def step():
+        loss = fwd_bwd()
+        dp.all_reduce_grads()
+        opt.step()
+        return loss
+
+    return dict(step=step, fwd_bwd=fwd_bwd, dp=dp, opt=opt, arena=arena, casts=casts)
+
+
+def capture_step(step, warmup):
+    """Warm `step` up on a side stream (as graph capture wants it), capture ONE call into a HIP graph and return
+    (graph, loss_buffer); graph.replay() then is one step."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(warmup):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        loss = step()                                     # not executed: recorded; `loss` is the graph's output buffer
+    return graph, loss
+
+
 def _event_ms(fn, iters=20, warm=3):
     for _ in range(warm):
         fn()
@@ -453,41 +511,13 @@ def main():
     # One process per GPU.  With a single rank the whole step (forward, backward, gradient packing, Adam) is captured
     # ONCE into a HIP graph after the warm-up and the timed steps are replays: ~390 launches cost the host ~7.5 ms per
     # step otherwise, about as long as the GPU needs to execute them.  Multi-rank runs launch every kernel from the host
-    # (the heads' RCCL all-reduce is started from a backward hook and overlaps the encoder's backward).  A graph of
-    # forward + backward followed by an eager all-reduce was tried with two ranks sharing the one GPU available here:
-    # every step -- and every eager step after the first replay -- stalled for seconds (tools/debug/two_rank_graph.py),
-    # presumably a queue-oversubscription artefact of two processes on one device; it cannot be checked on a real
-    # multi-GPU node from here, so the proven path stays.
+    # (the heads' RCCL all-reduce is started from a backward hook and overlaps the encoder's backward); see DESIGN.md
+    # section 6 for what was observed with a captured step followed by an eager all-reduce.
     use_graph = world == 1 and not args.no_graph
-    dp = parallel.FlatGradDP(model, world, late=model.encoder.parameters())   # heads' all-reduce overlaps the encoder's backward
-    dp.sync_params()
-    # option_new.py:83-90 trains with Adam(lr=1e-3): the same rule as ONE elementwise kernel over the flat parameter /
-    # gradient / moment buffers (gcanet_amd/optim.py; torch's multi-tensor launches take 0.2 ms for these 57 tensors)
-    from gcanet_amd.optim import FlatAdam
-    opt = FlatAdam(dp, lr=1e-3)
     B, N = args.batch, args.points
     pts, nrm = synth_clouds(range(rank * B, rank * B + B), N, dev)
-
-    from gcanet_amd.layers import CastCache, ZeroArena
-    arena = ZeroArena(dev)            # the small accumulators of a step come pre-zeroed from one allocation: one fill per step
-    # bf16 weight copies (in the GEMM kernel's padded operand layout): one multi-tensor cast per step, not one per layer
-    casts = CastCache(model, pad_k={model.conv3.weight: (model.conv3.weight.shape[1] + 15) // 16 * 16})
-
-    def fwd_bwd():
-        dp.zero_grad()
-        arena.begin_step()
-        casts.refresh()
-        with torch.autocast("cuda", dtype=torch.bfloat16):
-            out = model(pts, nrm)
-        loss = loss_of(out)
-        loss.backward()
-        return loss
-
-    def step():
-        loss = fwd_bwd()
-        dp.all_reduce_grads()
-        opt.step()
-        return loss
+    st = make_step(model, pts, nrm, world)
+    dp, step = st["dp"], st["step"]
 
     def barrier():
         if world > 1:
@@ -495,16 +525,7 @@ def main():
 
     run_step = step
     if use_graph:
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):                     # warm-up off the default stream, as graph capture wants it
-            for _ in range(args.warmup):
-                step()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            loss = step()                                 # not executed: recorded; `loss` is the graph's output buffer
+        graph, loss = capture_step(step, args.warmup)
         run_step = graph.replay
     else:
         for _ in range(args.warmup):

@@ -13,9 +13,6 @@ def _zeroed_like(shape, dtype, device):
     return zeroed_like(shape, dtype, device)
 
 
-_KNN_WS = {}
-
-
 def _knn_model(x, k1, k2, metric):
     if x.dim() != 3:
         raise RuntimeError("knn: x must be (B, C, N)")
@@ -33,10 +30,10 @@ def _knn_model(x, k1, k2, metric):
     # 3-D clouds (xyz, or xyz + normal) at N % 1024 == 0: threshold + filter + re-rank in exact arithmetic
     # (csrc/knn_normal.hip)
     if ((metric == 1 and C == 6) or (metric == 0 and C == 3)) and _lib.lib().gcn_knn_normal_supported(B, N, k2):
-        key = ("normal", B, C, N, x.device)
-        if key not in _KNN_WS:        # one scratch buffer per shape and device (calls are stream-ordered)
-            _KNN_WS[key] = torch.empty(_lib.lib().gcn_knn_tiles_ws_bytes(B, C, N), dtype=torch.uint8, device=x.device)
-        tile_ws = _KNN_WS[key]
+        # scratch per call: the caching allocator makes that free, and inside a HIP-graph capture the buffer lands in the
+        # graph's private pool and stays valid for every replay (a process-global cache handed replays a stale address
+        # once a later call had outgrown and replaced the buffer)
+        tile_ws = torch.empty(_lib.lib().gcn_knn_tiles_ws_bytes(B, C, N), dtype=torch.uint8, device=x.device)
     elif k2 <= 64 and N >= 512 and metric == 0 and C == 3:
         tile_ws = torch.empty(_lib.lib().gcn_knn_tiles_ws_bytes(B, C, N), dtype=torch.uint8, device=x.device)
     with _lib.on_device(x):
@@ -55,12 +52,10 @@ def knn_feature_pm(x_pm, k1, k2):
     x_pm = x_pm.float().contiguous()
     step = k2 // k1
     kout = len(range(0, k2, step))
-    key = (B, N, C, x_pm.device)
-    if key not in _KNN_WS:            # one scratch buffer per shape and device (calls are stream-ordered)
-        _KNN_WS[key] = torch.empty(lib.gcn_knn_feature_ws_bytes(B, N, C), dtype=torch.uint8, device=x_pm.device)
+    ws = torch.empty(lib.gcn_knn_feature_ws_bytes(B, N, C), dtype=torch.uint8, device=x_pm.device)   # per call, see _knn_model
     idx = torch.empty(B, N, kout, dtype=torch.int64, device=x_pm.device)
     with _lib.on_device(x_pm):
-        _lib.call("gcn_knn_feature", _lib.ptr(x_pm), B, N, C, k1, k2, _lib.ptr(idx), _lib.ptr(_KNN_WS[key]),
+        _lib.call("gcn_knn_feature", _lib.ptr(x_pm), B, N, C, k1, k2, _lib.ptr(idx), _lib.ptr(ws),
                   _lib.stream_of(x_pm), tag="knn_model[B=%d,C=%d,N=%d,k=%d]" % (B, C, N, k2))
     return idx
 
@@ -605,6 +600,8 @@ class DGCNNEncoderGn(nn.Module):
         self.mlp1 = nn.Conv1d(256, 1024, 1)
         self.bnmlp1 = nn.GroupNorm(8, 1024)
         self.last_idx = None
+        self.keep_feats = False        # True: also keep the inputs of the two feature-space searches in `last_feats`
+        self.last_feats = None
         self.direct_slices = True      # finish kernels write the bf16 slices of cat(x1,x2,x3) (False: torch.cat + conversion)
 
     def forward_pm(self, x_cm, x_pm=None, idxs=None):
@@ -641,6 +638,8 @@ class DGCNNEncoderGn(nn.Module):
         x3, _ = edge_conv_pm(x2, idx3, self.conv3._modules["0"].weight, self.bn3, self.dtype, want_cm=False,
                              bf_out=sl(128, 256))
         self.last_idx = (idx1, idx2, idx3)
+        if self.keep_feats:
+            self.last_feats = (x1.detach(), x2.detach())
         if direct:
             x_features = ConcatSlicesFunction.apply(xf16, x1, x2, x3)           # (B,N,256) bf16
         else:

@@ -15,6 +15,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from . import _lib
 from .pointnet2_ops.pointnet2_utils import grouping_operation
 from .search_knn import group_points
 
@@ -80,10 +81,9 @@ class OFFSET_PRED_MODULE(nn.Module):
         _, distances_instance = inst_and_seg_dist(semantic_feature, semantic_feature_knn, instance_feature,
                                                   instance_feature_knn)
         f = self.attention_inst(f, distances_instance)                                 # M2:445
-        if f.is_cuda:       # Conv2d(131->128) + GroupNorm + LeakyReLU + max over k as ONE fused grouped block
-            y = grouped_block(f, self.conv1[0].weight, self.bn1.weight, self.bn1.bias, self.bn1.num_groups,
-                              self.bn1.eps, 0.2, dtype="f32")                          # (B,128,N)
-        else:
-            y = self.conv1(f.permute(0, 3, 2, 1)).max(dim=-2)[0]
+        _lib.require_cuda(f)   # no CPU path in the product (the ops above raise on CPU tensors as well)
+        # Conv2d(131->128) + GroupNorm + LeakyReLU + max over k as ONE fused grouped block
+        y = grouped_block(f, self.conv1[0].weight, self.bn1.weight, self.bn1.bias, self.bn1.num_groups,
+                          self.bn1.eps, 0.2, dtype="f32")                              # (B,128,N)
         y = torch.cat([y, feature.permute(0, 2, 1)], dim=1)                            # (B,256,N)
         return self.mlp_offset(y)

@@ -258,9 +258,6 @@ def _own_wgrad(dy2, x2):
             and x2.shape[1] % 8 == 0 and dy2.shape[0] >= 512 and dy2.is_contiguous() and x2.is_contiguous())
 
 
-_WGRAD_WS = {}
-
-
 def _wgrad_own(dy2, x2, with_bias):
     """(dW (N,K) f32, db (N,) f32 | None) = (dy2^T @ x2, column sums of dy2) in ONE pass over the rows (csrc/gemm.hip):
     the row slices' partial tiles are folded in a fixed order by the same call, the bias gradient rides along."""
@@ -269,10 +266,9 @@ def _wgrad_own(dy2, x2, with_bias):
     raw = torch.empty(N * K + (N if with_bias else 0), dtype=torch.float32, device=dy2.device)
     dw = raw[:N * K].view(N, K)
     db = raw[N * K:] if with_bias else None
-    need = _lib.lib().gcn_gemm_wgrad_ws_bytes(M, N, K)
-    ws = _WGRAD_WS.get(dy2.device)
-    if ws is None or ws.numel() < need:           # one scratch buffer per device for the row slices' partial results
-        ws = _WGRAD_WS[dy2.device] = torch.empty(need, dtype=torch.uint8, device=dy2.device)   # (calls are stream-ordered)
+    # partial tiles of the row slices: scratch per call (free with the caching allocator; inside a HIP-graph capture it
+    # belongs to the graph's pool -- a process-global buffer that a later, larger call replaces leaves replays a stale address)
+    ws = torch.empty(_lib.lib().gcn_gemm_wgrad_ws_bytes(M, N, K), dtype=torch.uint8, device=dy2.device)
     with _lib.on_device(dy2):
         _lib.call("gcn_gemm_wgrad_bf16", _lib.ptr(dy2), _lib.ptr(x2), M, N, K, _lib.ptr(dw), _lib.ptr(db), _lib.ptr(ws),
                   _lib.stream_of(dy2))
@@ -304,10 +300,7 @@ def _wgrad_narrow(dy2, x2, with_bias):
     raw = torch.empty(N * K + (N if with_bias else 0), dtype=torch.float32, device=dy2.device)
     dw = raw[:N * K].view(N, K)
     db = raw[N * K:] if with_bias else None
-    need = L.gcn_wgrad_narrow_ws_bytes(M, N, K)
-    ws = _WGRAD_WS.get(("narrow", dy2.device))
-    if ws is None or ws.numel() < need:
-        ws = _WGRAD_WS[("narrow", dy2.device)] = torch.empty(need, dtype=torch.uint8, device=dy2.device)
+    ws = torch.empty(L.gcn_wgrad_narrow_ws_bytes(M, N, K), dtype=torch.uint8, device=dy2.device)
     with _lib.on_device(dy2):
         _lib.call("gcn_wgrad_narrow", _lib.ptr(dy2), int(dy2.dtype == torch.bfloat16), _lib.ptr(x2),
                   int(x2.dtype == torch.bfloat16), M, N, K, _lib.ptr(dw), _lib.ptr(db), _lib.ptr(ws), _lib.stream_of(dy2))

@@ -94,9 +94,10 @@ class SumMeanSquaresFunction(torch.autograd.Function):
         vs = tuple(v.contiguous() for v in vs)
         dev = vs[0].device
         pv, _, pn, pb = SumMeanSquaresFunction._host_lists(vs)
-        done = SumMeanSquaresFunction._done.get(dev)
-        if done is None:                       # the kernel leaves the counter zero: one allocation per device, for good
-            done = SumMeanSquaresFunction._done[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
+        key = (dev, _lib.stream_of(vs[0]))     # calls on one stream are ordered; another stream gets its own counter
+        done = SumMeanSquaresFunction._done.get(key)
+        if done is None:                       # the kernel leaves the counter zero: one 4-byte allocation per stream, for good
+            done = SumMeanSquaresFunction._done[key] = torch.zeros(1, dtype=torch.int32, device=dev)
         part = torch.empty(_lib.lib().gcn_multi_mean_square_ws_chunks(pn, len(vs)), dtype=torch.float64, device=dev)
         loss = torch.empty((), dtype=torch.float32, device=dev)
         with _lib.on_device(loss):
