@@ -13,27 +13,42 @@
 //                APPROXIMATE squared distances a(q,j) = |ut_q - ut_j|^2 under it, from a 1-in-8 strided sample of
 //                the candidates: the m-th smallest sample value with m ~ k/8 + 5 sqrt(k/8).
 //   3. filter    (knnf_stream_kernel<MODE 1>) a(q,j) <= tau for ALL pairs, one bit per pair (B*N*N/8 bytes).
-//   4. re-rank   (knnf_rerank_kernel) one wave per query: expand the bits (~3k candidates), gather their f32 rows,
+//   4. re-rank   (knnf_keys_kernel + knnf_rank_kernel) one wave per query: expand the bits (~3k candidates), gather their f32 rows,
 //                evaluate the reference's arithmetic exactly (ascending-channel fmaf chain, fl(fl(2 dot - xx_j) -
 //                xx_q), the same expression as knn_mfma16 / oracle/gcanet_oracle.c:model_pd), sort by (key, index)
 //                -> the lowest index wins ties, as in the oracle -- and VERIFY a posteriori, with the exact k-th key
 //                d_k in hand, that no pair the filter dropped can beat it (bound below).  Fewer than k or more than
 //                CAP candidates, or a failed verification -> the query goes on the fallback list and
-//   5. fallback  the listed queries are searched exhaustively in the same exact arithmetic: a short list one query per
+//   5. fallback  the listed queries are searched exhaustively in the same exact arithmetic (k <= 64, N % 4 == 0; otherwise
+//                knn_select_kernel in its flagged mode serves them): a short list one query per
 //                workgroup (knnf_fallback_kernel); a long one (> KNNF_LONG_LIST: clouds whose neighbours sit closer
 //                than bf16 resolves, e.g. near-identical features on flat regions) on the f32 matrix cores
 //                (knn.hip: knn_mfma16_kernel in its flagged mode, after a transpose to its channel-major layout) --
 //                1.4 ms for ALL 65536 queries at C = 64 where one workgroup per query took 20 ms.
 // The result is therefore ALWAYS the exact one; the sample statistics only decide how long the fallback list is.
 //
-// Verification bound.  Let D = |x_q - x_j| (reals), Dt = |ut_q - ut_j|.  ut = bf16(fl(x - mu)) = u (1 + d) with
-// |d| <= 2^-9 (1 + 2^-9) + 2^-24 per element, so |Dt - D| <= eta_q := 0.00198 (|ut_q| + R), R = max_j |ut_j|.  The f32
-// evaluation errors of the reference's key (expanded form: <= (C+4) 2^-24 (|x_q| + |x_j|)^2) and of the filter's
-// a(q,j) (f32 accumulation of exact bf16 products, three-piece bf16 image of the threshold, rounded hn) are each
-// below Delta_q := 4 (C+8) 2^-24 (max(|x_q|, |ut_q|) + max(X, R))^2, X = max_j |x_j|.  A dropped pair has
-// a > tau, hence Dt^2 > tau - Delta, D > sqrt(tau - Delta) - eta, and a reference key > (sqrt(tau - Delta) - eta)^2
-// - Delta =: L.  If L > d_k, every dropped pair loses against the k-th kept one: the k smallest kept keys ARE the
-// reference's k nearest.  (tau comes from a sample rank ~3k, d_k is rank k: the gap is several eta wide.)
+// Verification bound (round 3: re-derived; round 2 used 2^-9 for the bf16 rounding and one loose constant for every
+// f32 error).  u = 2^-24, bf16 rounds to 8 significant bits: relative error <= 2^-8.  Let D = |x_q - x_j| (reals),
+// Dt = |ut_q - ut_j|.  ut = bf16(fl(x - mu)) = (x - mu)(1 + d), |d| <= 2^-8 + u + 2^-8 u per element, so
+// |ut - (x - mu)| <= d |x - mu| <= d / (1 - d) |ut| and |Dt - D| <= eta_q := 0.00393 (|ut_q| + R), R = max_j |ut_j|.
+//   Filter.  A pair passes iff acc' >= hn'_j, which in exact arithmetic is a(q,j) := Dt^2 <= tau.  The computed test
+// differs by the f32 accumulation of the (exact) bf16 products over Cp + 16 terms, the three-piece bf16 image of
+// theta = (|ut_q|^2 - tau)/2 and the roundings of hn, theta: together below Delta_f := 8 (Cp + 16) u (|ut_q| + R)^2
+// in units of a (the centred norms: a translation of the cloud does not enter).
+//   Reference key.  K = -fl(fl(2 dot' - xx'_j) - xx'_q) with dot' an ascending fmaf chain and xx' rounded squares added
+// in order: |K - D^2| <= gamma_C (|x_q| + |x_j|)^2 + 2u (...)^2 <= Delta_ref := (C + 3) u (|x_q| + X)^2, X = max_j |x_j|
+// (the UNcentred norms: the reference evaluates the expanded form on the raw features).
+//   A dropped pair has a > tau - Delta_f, hence Dt > sqrt(tau - Delta_f), D > sqrt(tau - Delta_f) - eta =: root, and a
+// reference key > root^2 - Delta_ref =: L.  If L > d_k (the exact k-th smallest key among the kept pairs), every dropped
+// pair loses against the k-th kept one: the k smallest kept keys ARE the reference's k nearest.
+//   Threshold.  tau = the m-th smallest approximate distance over a 1-in-8 pseudo-random sample (m ~ k/8 + 5 sqrt(k/8):
+// the number of candidates under an order statistic of a sample does not depend on the distance distribution, ~8 m
+// with a standard deviation of 7.5 sqrt(m)), raised to the smallest value at which the proof can succeed for a query
+// whose neighbours are (near-)duplicates, tau_floor = (eta + sqrt(2 Delta_ref))^2 + Delta_f: clusters tighter than
+// bf16 resolves keep all their members as candidates instead of failing (tools/knn_provability.py: with the right
+// threshold the bf16 filter serves every real feature distribution met so far -- blobs, flat patches -- with ~70-130
+// candidates; only clouds whose spread is below the reference's own f32 noise, Delta_ref >~ the rank-k..3k gap, need
+// the exhaustive kernel, and there no approximate filter of any precision can prove anything).
 //
 // Geometry (wave64, v_mfma_f32_32x32x16_bf16): workgroup = 4 waves x 32 queries; candidate tiles of 128 rows
 // [row][Cp] bf16 stream through LDS (LDS-DMA, double buffered, source-side XOR swizzle as in edgeconv_fwd.hip);
@@ -53,14 +68,13 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 constexpr int KNNF_CAP = 512;        // candidates a query may keep (8 per lane)
-constexpr int KNNF_STRIDE = 8;       // sample every 8th candidate
-constexpr int KNNF_PHASE = 3;
+constexpr int KNNF_STRIDE = 8;       // the sample holds N/8 hashed candidate rows (knn_topb.h: knn_sample_row)
 constexpr unsigned int KNNF_LONG_LIST = 4096;   // flagged queries beyond which the matrix-core kernel does the exhaustive search
 
 struct KnnfArgs {
   const float *x;            // (B,N,C) f32 point-major
-  unsigned short *ut;        // (B,N,Cp) bf16 centred rows
-  float *hn;                 // (B,N) |ut|^2 / 2
+  unsigned short *ut;        // (B,Np,Cp) bf16 centred rows (rows >= N: zeros)
+  float *hn;                 // (B,Np) |ut|^2 / 2 (rows >= N: +inf -- a padding candidate never passes the filter)
   float *xx;                 // (B,N) the oracle's squared norms (squares rounded, added in channel order)
   float *msum;               // (B,Cp) channel sums
   unsigned int *stat;        // (B,2) float bits: max |ut|^2, max xx
@@ -76,7 +90,7 @@ struct KnnfArgs {
   int *ccnt;                 // (B,N) number of candidates (0: the query went to the fallback list)
   float *xcm;                // (B,C,N) channel-major copy (long fallback lists only)
   unsigned int long_list;    // list length beyond which the matrix-core kernel searches the flagged queries
-  int B, N, C, Cp, NW, k, step, kout, m_rank;
+  int B, N, Np, C, Cp, NW, k, step, kout, m_rank;     // Np = N rounded up to 128: rows of ut / hn, bits of a bitmap row
 };
 
 __device__ __forceinline__ unsigned short f2bf(float f) {
@@ -151,16 +165,16 @@ __global__ __launch_bounds__(256) void knnf_prep_kernel(KnnfArgs a) {
     const int rr = live ? r : a.N - 1;
     const float4 v = *reinterpret_cast<const float4 *>(a.x + ((long)b * a.N + rr) * a.C + c4);
     const unsigned short h0 = f2bf(v.x - mean4.x), h1 = f2bf(v.y - mean4.y), h2 = f2bf(v.z - mean4.z), h3 = f2bf(v.w - mean4.w);
-    if (live) {
+    if (r < a.Np) {                                          // padding rows (N <= r < Np): zeros
       uint2 o;
-      o.x = (unsigned int)h0 | ((unsigned int)h1 << 16);
-      o.y = (unsigned int)h2 | ((unsigned int)h3 << 16);
-      *reinterpret_cast<uint2 *>(a.ut + ((long)b * a.N + r) * a.Cp + c4) = o;
+      o.x = live ? (unsigned int)h0 | ((unsigned int)h1 << 16) : 0u;
+      o.y = live ? (unsigned int)h2 | ((unsigned int)h3 << 16) : 0u;
+      *reinterpret_cast<uint2 *>(a.ut + ((long)b * a.Np + r) * a.Cp + c4) = o;
     }
     const float u0 = bf2f(h0), u1 = bf2f(h1), u2 = bf2f(h2), u3 = bf2f(h3);
     float nt = fmaf(u3, u3, fmaf(u2, u2, fmaf(u1, u1, u0 * u0)));
     for (int o = lpr >> 1; o >= 1; o >>= 1) nt += __shfl_xor(nt, o);
-    if (live && (lane % lpr) == 0) a.hn[(long)b * a.N + r] = 0.5f * nt;
+    if (r < a.Np && (lane % lpr) == 0) a.hn[(long)b * a.Np + r] = live ? 0.5f * nt : __builtin_inff();
     if (live) ntmax = fmaxf(ntmax, nt);
   }
 #pragma unroll
@@ -197,6 +211,24 @@ __global__ __launch_bounds__(256) void knnf_prep_kernel(KnnfArgs a) {
   }
 }
 
+// the error bounds of the header for one query: nq = |ut_q|^2, xxq = |x_q|^2 (f32 values: the 1.0001 factors absorb their
+// own rounding), Rt2 = max |ut|^2, X2 = max |x|^2 of the cloud
+struct KnnfBounds { float eta, delta_f, delta_ref; };
+__device__ __forceinline__ KnnfBounds knnf_bounds(float nq, float xxq, float Rt2, float X2, int C, int Cp) {
+  KnnfBounds r;
+  const float s = (sqrtf(nq) + sqrtf(Rt2)) * 1.0001f;
+  const float sx = (sqrtf(fmaxf(xxq, 0.f)) + sqrtf(X2)) * 1.0001f;
+  r.eta = 0.00393f * s;
+  r.delta_f = 8.f * (float)(Cp + 16) * 5.9604645e-8f * s * s;
+  r.delta_ref = (float)(C + 3) * 5.9604645e-8f * sx * sx * 1.0001f;
+  return r;
+}
+// the proof: no pair the filter dropped at threshold tau can have a reference key <= dk
+__device__ __forceinline__ bool knnf_proven(const KnnfBounds &bd, float tau, float dk) {
+  const float root = sqrtf(fmaxf(tau - bd.delta_f, 0.f)) * 0.99999f - bd.eta;
+  return root > 0.f && (root * root) * 0.99999f - bd.delta_ref > dk;
+}
+
 // ------------------------------------------------------------------ 2./3. streaming kernel
 template <int KS, int MODE>   // KS = Cp/16 k-steps; MODE 0 = thresholds from the strided sample, 1 = filter all pairs
 __global__ __launch_bounds__(256, 2) void knnf_stream_kernel(KnnfArgs a) {
@@ -216,11 +248,12 @@ __global__ __launch_bounds__(256, 2) void knnf_stream_kernel(KnnfArgs a) {
   const int lin = blockIdx.x + gridDim.x * blockIdx.y;     // cloud = id % B: one cloud per XCD at 8 clouds
   const int b = lin % (int)gridDim.y;
   const int q0 = ((lin / (int)gridDim.y) * 4 + wave) * 32;
-  const int N = a.N;
-  const unsigned char *utb = reinterpret_cast<const unsigned char *>(a.ut) + (long)b * N * ROW_BYTES;
-  const float *hnb = a.hn + (long)b * N;
+  const int N = a.N, Np = a.Np;
+  const unsigned char *utb = reinterpret_cast<const unsigned char *>(a.ut) + (long)b * Np * ROW_BYTES;
+  const float *hnb = a.hn + (long)b * Np;
+  const int ns = N / KNNF_STRIDE;                           // sample slots (MODE 0)
 
-  // query fragments: row q0 + lr, k-chunk 2s + lh
+  // query fragments: row q0 + lr (< Np: padding queries compute on zero rows and store nothing), k-chunk 2s + lh
   bf16x8 qf[KS];
 #pragma unroll
   for (int s = 0; s < KS; ++s)
@@ -232,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void knnf_stream_kernel(KnnfArgs a) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) { thf[i] = 0; onef[i] = 0; }
   if (MODE == 1 && lh == 0) {
-    const float th = -a.theta[(long)b * N + q0 + lr];
+    const float th = -a.theta[(long)b * N + min(q0 + lr, N - 1)];
     const unsigned short p1 = f2bf(th);
     const float r1 = th - bf2f(p1);
     const unsigned short p2 = f2bf(r1);
@@ -260,10 +293,10 @@ __global__ __launch_bounds__(256, 2) void knnf_stream_kernel(KnnfArgs a) {
   // candidate index of tile row `row` of tile t
   auto src_row = [&](int t, int row) -> int {
     if (MODE == 1) return t * 128 + row;
-    const int j = KNNF_STRIDE * (t * 128 + row) + KNNF_PHASE;
-    return j < N ? j : N - 1;
+    const int i = t * 128 + row;
+    return i < ns ? knn_sample_row(i, N) : 0;
   };
-  const int ntiles = MODE == 1 ? N / 128 : (N / KNNF_STRIDE + 127) / 128;
+  const int ntiles = MODE == 1 ? Np / 128 : (ns + 127) / 128;
 
   auto issue = [&](int t, int buf) {
 #pragma unroll
@@ -329,7 +362,7 @@ __global__ __launch_bounds__(256, 2) void knnf_stream_kernel(KnnfArgs a) {
 #pragma unroll
         for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[s], cf[s], acc, 0, 0, 0);
         const float hc = reinterpret_cast<const float *>(tb + A_BYTES)[cb * 32 + lr];
-        const bool valid = KNNF_STRIDE * (t * 128 + cb * 32 + lr) + KNNF_PHASE < N;
+        const bool valid = t * 128 + cb * 32 + lr < ns;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const float g = valid ? hc - acc[i] : __builtin_inff();      // (a(q,j) - |ut_q|^2) / 2
@@ -341,7 +374,7 @@ __global__ __launch_bounds__(256, 2) void knnf_stream_kernel(KnnfArgs a) {
         }
       }
     }
-    if (MODE == 1 && lh == 0) {
+    if (MODE == 1 && lh == 0 && q0 + lr < N) {
       uint4 v = {words[0], words[1], words[2], words[3]};
       *reinterpret_cast<uint4 *>(a.bitmap + ((long)b * N + q0 + lr) * a.NW + t * 4) = v;
     }
@@ -371,19 +404,33 @@ __global__ __launch_bounds__(256, 2) void knnf_stream_kernel(KnnfArgs a) {
         p = c >= m ? p : trial;
       }
       const float G = key_u2f(p | 0xffu);
-      if (lr == 0) {
-        const int q = q0 + 4 * lh + (i & 3) + 8 * (i >> 2);
+      // second smallest sample value of the query (its half's 32 lanes): the distance scale of its nearest neighbours
+      float g1 = t0[i];
+#pragma unroll
+      for (int o = 16; o >= 1; o >>= 1) g1 = fminf(g1, __shfl_xor(g1, o));
+      float g2 = t0[i] > g1 ? t0[i] : t1[i];
+#pragma unroll
+      for (int o = 16; o >= 1; o >>= 1) g2 = fminf(g2, __shfl_xor(g2, o));
+      const int q = q0 + 4 * lh + (i & 3) + 8 * (i >> 2);
+      if (lr == 0 && q < N) {
         const float nq = 2.f * hnb[q];                              // |ut_q|^2
-        float tau = fmaf(2.f, G, nq);                               // approximate squared-distance threshold
-        // A threshold inside the bf16 noise floor (sqrt(tau - Delta) <= eta, the re-rank's own expressions) can never
-        // be verified, whatever the k-th key turns out to be: such a query keeps no candidate (the filter passes
-        // nothing below -1e30) and goes straight to the exhaustive stage instead of through a re-rank that must fail.
-        const float xxq = a.xx[(long)b * N + q];
-        const float Rt2 = __uint_as_float(a.stat[b * 2]), X2 = __uint_as_float(a.stat[b * 2 + 1]);
-        const float eta = 0.00198f * (sqrtf(nq) + sqrtf(Rt2)) * 1.0001f;
-        const float big = fmaxf(sqrtf(nq), sqrtf(xxq)) + fmaxf(sqrtf(Rt2), sqrtf(X2));
-        const float Delta = 4.f * (float)(a.C + 8) * 5.9604645e-8f * big * big * 1.0001f;
-        if (sqrtf(fmaxf(tau - Delta, 0.f)) * 0.99999f - eta <= 0.f) tau = -1e30f;
+        float tau = fmaxf(fmaf(2.f, G, nq), 0.f);                   // approximate squared-distance threshold
+        const KnnfBounds bd = knnf_bounds(nq, a.xx[(long)b * N + q], __uint_as_float(a.stat[b * 2]), __uint_as_float(a.stat[b * 2 + 1]), a.C, a.Cp);
+        // Tight clusters: when the sampled threshold sits within a few eta of the nearest neighbours' own distance the
+        // rank-k..3k gap is too narrow for the proof, although the sample statistic is right (at least k candidates
+        // lie under tau).  There the threshold is WIDENED by the error bounds -- L(tau') >= tau >= d_k by construction
+        // (header) -- which costs the candidates of a thin extra shell; smooth clouds (gap >> eta) keep the sampled
+        // value and its ~8 m candidates.
+        const float near2 = fmaxf(fmaf(2.f, g2, nq), 0.f);
+        if (sqrtf(tau) - sqrtf(near2) < 8.f * bd.eta) {
+          const float rw = (sqrtf(tau + bd.delta_ref) + bd.eta) * 1.001f;
+          tau = fmaf(rw, rw, bd.delta_f) * 1.001f;
+        }
+        // never below the smallest threshold at which the proof can hold when the neighbours are (near-)duplicates of
+        // the query (exact k-th key within +-Delta_ref of zero): a cluster tighter than bf16 resolves keeps all its
+        // members as candidates instead of a threshold that could not be verified (header: tau_floor)
+        const float rt = (bd.eta + sqrtf(2.f * bd.delta_ref)) * 1.001f;
+        tau = fmaxf(tau, fmaf(rt, rt, bd.delta_f) * 1.001f);
         a.tau[(long)b * N + q] = tau;
         a.theta[(long)b * N + q] = 0.5f * (nq - tau);
       }
@@ -411,103 +458,8 @@ __device__ __forceinline__ float knnf_exact_key(const float *__restrict__ row_g,
   return -pd;
 }
 
-// ------------------------------------------------------------------ 4. exact re-rank of the survivors
-template <int CC>
-__global__ __launch_bounds__(256) void knnf_rerank_kernel(KnnfArgs a) {
-  __shared__ unsigned short cand_s[4][KNNF_CAP];
-  __shared__ __attribute__((aligned(16))) float qrow_s[4][CC];
-  const int lane = lane_id(), wave = wave_id();
-  const int lin = blockIdx.x + gridDim.x * blockIdx.y;
-  const int b = lin % (int)gridDim.y;
-  const int q = (lin / (int)gridDim.y) * 4 + wave;
-  const int N = a.N, NW = a.NW;
-  if (q >= N) return;
-  const unsigned int *bm = a.bitmap + ((long)b * N + q) * NW;
-  unsigned int words[8];
-  int cnt = 0;
-#pragma unroll
-  for (int w = 0; w < 8; ++w) {
-    const int wi = lane + 64 * w;
-    words[w] = wi < NW ? bm[wi] : 0u;
-    cnt += __popc(words[w]);
-  }
-  int incl = cnt;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int y = __shfl_up(incl, d);
-    if (lane >= d) incl += y;
-  }
-  const int total = __builtin_amdgcn_readlane(incl, 63);
-  const bool bad = total < a.k || total > KNNF_CAP;
-  if (bad) {                                                 // the fallback handles this query exhaustively
-    if (lane == 0) {
-      a.flag[(long)b * N + q] = 1;
-    }
-    return;
-  }
-
-  unsigned short *cand = cand_s[wave];
-  float *qrow = qrow_s[wave];
-  const float *xb = a.x + (long)b * N * CC;
-  for (int c = lane; c < CC; c += 64) qrow[c] = xb[(long)q * CC + c];
-  int pos = incl - cnt;
-#pragma unroll
-  for (int w = 0; w < 8; ++w) {
-    unsigned int word = words[w];
-    const int base = (lane + 64 * w) * 32;
-    while (word) {
-      const int p = __ffs((int)word) - 1;
-      word &= word - 1;
-      const int i = p & 15;
-      cand[pos++] = (unsigned short)(base + 4 * (p >> 4) + (i & 3) + 8 * (i >> 2));
-    }
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-
-  const float xxq = a.xx[(long)b * N + q];
-  // exact keys of all candidates (up to 8 per lane), as monotone integers
-  unsigned int kf[8];
-  int cj[8];
-  // Row fetch: each lane reads its own candidate's row in 16-byte pieces.  The kernel runs at the rate the vector
-  // memory path accepts such scattered requests (~1 per clock and CU).  Two attempts to coalesce the fetch were slower
-  // at C = 64 (0.46 ms this form): whole rows by LDS-DMA into a 16-KB per-wave stage with lane = row reads (0.57 ms:
-  // a quarter of the occupancy and a full wait per stage), and four lanes per 64 bytes through a 4-KB LDS transposer
-  // (0.90 ms: a dependent load -> write -> read -> fmaf chain per 16 channels).
-#pragma unroll
-  for (int bt = 0; bt < 8; ++bt) {
-    kf[bt] = 0xFFFFFFFFu;
-    cj[bt] = q;
-    if (bt * 64 < total) {                                   // wave-uniform
-      const int c = bt * 64 + lane;
-      const bool valid = c < total;
-      const int j = valid ? (int)cand[c] : q;
-      const float key = knnf_exact_key<CC>(xb + (long)j * CC, qrow, a.xx[(long)b * N + j], xxq);
-      kf[bt] = valid ? key_f2u(key) : 0xFFFFFFFFu;
-      cj[bt] = j;
-    }
-  }
-  TopB tb;
-  rank_candidates(kf, cj, total, a.k, lane, tb);
-  const bool overflow = false;
-  // a-posteriori check with the exact k-th key (header comment)
-  const float dk = key_u2f((unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(tb.lst >> 32), a.k - 1));
-  const float nq = 2.f * a.hn[(long)b * N + q];
-  const float Rt2 = __uint_as_float(a.stat[b * 2]), X2 = __uint_as_float(a.stat[b * 2 + 1]);
-  const float eta = 0.00198f * (sqrtf(nq) + sqrtf(Rt2)) * 1.0001f;
-  const float big = fmaxf(sqrtf(nq), sqrtf(xxq)) + fmaxf(sqrtf(Rt2), sqrtf(X2));
-  const float Delta = 4.f * (float)(CC + 8) * 5.9604645e-8f * big * big * 1.0001f;
-  const float root = sqrtf(fmaxf(a.tau[(long)b * N + q] - Delta, 0.f)) * 0.99999f - eta;
-  const bool proven = !overflow && root > 0.f && (root * root) * 0.99999f - Delta > dk;
-  if (lane == 0) {
-    a.flag[(long)b * N + q] = proven ? 0 : 1;
-  }
-  if (proven && lane < a.k && (lane % a.step) == 0)
-    a.idx[((long)b * N + q) * a.kout + lane / a.step] = (int64_t)(unsigned int)tb.lst;
-}
-
-// ------------------------------------------------------------------ 4'. re-rank in two kernels (default)
-// knnf_rerank_kernel above fetches a candidate's 256-byte row with sixteen 16-byte loads of ONE lane: every
+// ------------------------------------------------------------------ 4. exact re-rank of the survivors, in two kernels
+// A single-kernel re-rank (round 2, removed) fetched a candidate's 256-byte row with sixteen 16-byte loads of ONE lane: every
 // instruction touches 64 different 128-byte lines and the texture-address unit takes a clock per line -- 0.36 of the
 // kernel's 0.43 ms at C = 64 (PMC: 69 such loads per query, waves waiting 60 % of their cycles).  Here the rows are
 // fetched COOPERATIVELY -- 16 lanes per 256-byte row piece, four rows per instruction: 8 lines instead of 64 -- and
@@ -668,6 +620,7 @@ __global__ __launch_bounds__(256) void knnf_keys_kernel(KnnfArgs a) {
 
 template <int CC>
 __global__ __launch_bounds__(256) void knnf_rank_kernel(KnnfArgs a) {
+  __shared__ u64 sortbuf[4][128];                            // 64 < k <= 128 only (knn_topb.h: rank_candidates)
   const int lane = lane_id(), wave = wave_id();
   const int lin = blockIdx.x + gridDim.x * blockIdx.y;
   const int b = lin % (int)gridDim.y;
@@ -690,22 +643,20 @@ __global__ __launch_bounds__(256) void knnf_rank_kernel(KnnfArgs a) {
     }
   }
   TopB tb;
-  rank_candidates(kf, cj, total, a.k, lane, tb);
+  const unsigned int pk = rank_candidates(kf, cj, total, a.k, lane, tb, sortbuf[wave]);
   // a-posteriori check with the exact k-th key (header comment)
-  const float xxq = a.xx[(long)b * N + q];
-  const float dk = key_u2f((unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(tb.lst >> 32), a.k - 1));
-  const float nq = 2.f * a.hn[(long)b * N + q];
-  const float Rt2 = __uint_as_float(a.stat[b * 2]), X2 = __uint_as_float(a.stat[b * 2 + 1]);
-  const float eta = 0.00198f * (sqrtf(nq) + sqrtf(Rt2)) * 1.0001f;
-  const float big = fmaxf(sqrtf(nq), sqrtf(xxq)) + fmaxf(sqrtf(Rt2), sqrtf(X2));
-  const float Delta = 4.f * (float)(CC + 8) * 5.9604645e-8f * big * big * 1.0001f;
-  const float root = sqrtf(fmaxf(a.tau[(long)b * N + q] - Delta, 0.f)) * 0.99999f - eta;
-  const bool proven = root > 0.f && (root * root) * 0.99999f - Delta > dk;
+  const float dk = key_u2f(pk);
+  const KnnfBounds bd = knnf_bounds(2.f * a.hn[(long)b * a.Np + q], a.xx[(long)b * N + q], __uint_as_float(a.stat[b * 2]),
+                                    __uint_as_float(a.stat[b * 2 + 1]), CC, a.Cp);
+  const bool proven = knnf_proven(bd, a.tau[(long)b * N + q], dk);
   if (lane == 0) {
     a.flag[(long)b * N + q] = proven ? 0 : 1;
   }
-  if (proven && lane < a.k && (lane % a.step) == 0)
-    a.idx[((long)b * N + q) * a.kout + lane / a.step] = (int64_t)(unsigned int)tb.lst;
+  if (proven) {
+    int64_t *o = a.idx + ((long)b * N + q) * a.kout;
+    if (lane < a.k && (lane % a.step) == 0) o[lane / a.step] = (int64_t)(unsigned int)tb.lst;
+    if (lane + 64 < a.k && ((lane + 64) % a.step) == 0) o[(lane + 64) / a.step] = (int64_t)(unsigned int)tb.pnd;
+  }
 }
 
 // ------------------------------------------------------------------ 5. exhaustive exact search of the listed queries
@@ -726,8 +677,15 @@ __global__ __launch_bounds__(256) void knnf_list_kernel(KnnfArgs a) {
   }
 }
 
-// One workgroup per listed query; its four waves scan a quarter of the cloud each (rows are consecutive: a batch of 64
-// candidates is 64 contiguous rows), keep a buffered bitonic top-64, and wave 0 merges the four lists.
+// Short lists.  A listed query is cut into KNNF_SLICES candidate ranges, one workgroup per (query, range): its four waves
+// scan a quarter of the range each (rows are consecutive: a batch of 64 candidates is 64 contiguous rows), keep a
+// buffered bitonic top-64 and merge into one list of the range; knnf_fallback_merge_kernel then merges a query's
+// KNNF_SLICES lists (one wave per query).  One workgroup per QUERY (round 2) took ~90 us for a list of three queries --
+// the latency of one wave walking 2048 rows -- which is what a well-behaved cloud pays once the bf16 bound is the
+// correct 2^-8: two or three of its 65536 queries miss the proof by a hair.  The lists live in the `keys` scratch of
+// the re-rank, dead by now (long_list is capped so that they fit).
+constexpr int KNNF_SLICES = 16;
+
 template <int CC>
 __global__ __launch_bounds__(256) void knnf_fallback_kernel(KnnfArgs a) {
   __shared__ u64 lists[4][64];
@@ -737,11 +695,15 @@ __global__ __launch_bounds__(256) void knnf_fallback_kernel(KnnfArgs a) {
   if (nlist > a.long_list) return;                         // knn_mfma16_kernel<flagged> serves a long list
   const int N = a.N;
   const int klane = (a.k - 1) & 63;
-  for (unsigned int e = blockIdx.x; e < nlist; e += gridDim.x) {
+  u64 *out = reinterpret_cast<u64 *>(a.keys);
+  const int per_slice = ((N + KNNF_SLICES - 1) / KNNF_SLICES + 3) & ~3;
+  for (unsigned int w = blockIdx.x; w < nlist * KNNF_SLICES; w += gridDim.x) {
+    const unsigned int e = w / KNNF_SLICES;
+    const int sl = (int)(w % KNNF_SLICES);
     const unsigned int bq = a.flist[e];
     const int b = (int)(bq / (unsigned int)N), q = (int)(bq % (unsigned int)N);
     const float *xb = a.x + (long)b * N * CC;
-    __syncthreads();                                       // previous query's lists / row are no longer read
+    __syncthreads();                                       // previous item's lists / row are no longer read
     for (int c = threadIdx.x; c < CC; c += 256) qrow[c] = xb[(long)q * CC + c];
     __syncthreads();
     const float xxq = a.xx[(long)b * N + q];
@@ -749,9 +711,10 @@ __global__ __launch_bounds__(256) void knnf_fallback_kernel(KnnfArgs a) {
     tb.init();
     int cnt = 0;
     float thr = __builtin_inff();
-    const int per = (N + 3) / 4;
-    const int j_end = min(N, (wave + 1) * per);
-    for (int j0 = wave * per; j0 < j_end; j0 += 64) {
+    const int s_lo = min(N, sl * per_slice), s_hi = min(N, s_lo + per_slice);
+    const int per = (s_hi - s_lo + 3) / 4;
+    const int j_lo = min(s_hi, s_lo + wave * per), j_end = min(s_hi, j_lo + per);
+    for (int j0 = j_lo; j0 < j_end; j0 += 64) {
       const int j = j0 + lane;
       const bool valid = j < j_end;
       const int jc = valid ? j : j_end - 1;
@@ -772,13 +735,32 @@ __global__ __launch_bounds__(256) void knnf_fallback_kernel(KnnfArgs a) {
     __syncthreads();
     if (wave == 0) {
 #pragma unroll
-      for (int w = 1; w < 4; ++w) {
-        tb.pnd = lists[w][lane];
+      for (int ww = 1; ww < 4; ++ww) {
+        tb.pnd = lists[ww][lane];
         tb.merge(64, lane);
       }
-      if (lane < a.k && (lane % a.step) == 0)
-        a.idx[((long)b * N + q) * a.kout + lane / a.step] = (int64_t)(unsigned int)tb.lst;
+      out[(long)w * 64 + lane] = tb.lst;
     }
+  }
+}
+
+__global__ __launch_bounds__(256) void knnf_fallback_merge_kernel(KnnfArgs a) {
+  const int lane = lane_id();
+  const unsigned int nlist = *a.nflag;
+  if (nlist > a.long_list) return;
+  const u64 *in = reinterpret_cast<const u64 *>(a.keys);
+  for (unsigned int e = blockIdx.x * 4 + wave_id(); e < nlist; e += gridDim.x * 4) {
+    const unsigned int bq = a.flist[e];
+    TopB tb;
+    tb.init();
+    tb.lst = in[((long)e * KNNF_SLICES) * 64 + lane];
+#pragma unroll 1
+    for (int sl = 1; sl < KNNF_SLICES; ++sl) {
+      tb.pnd = in[((long)e * KNNF_SLICES + sl) * 64 + lane];
+      tb.merge(64, lane);
+    }
+    if (lane < a.k && (lane % a.step) == 0)
+      a.idx[(long)bq * a.kout + lane / a.step] = (int64_t)(unsigned int)tb.lst;
   }
 }
 
@@ -789,13 +771,15 @@ __global__ __launch_bounds__(256) void knnf_transpose_kernel(KnnfArgs a) {
   const int b = blockIdx.y, r0 = blockIdx.x * 64, C = a.C;
   const float *xb = a.x + ((long)b * a.N + r0) * C;
   for (int e = threadIdx.x; e < 64 * C / 4; e += 256) {
-    const float4 v = *reinterpret_cast<const float4 *>(xb + (long)e * 4);
     const int r = (e * 4) / C, c = (e * 4) % C;
+    if (r0 + r >= a.N) continue;                               // last tile of a ragged cloud
+    const float4 v = *reinterpret_cast<const float4 *>(xb + (long)e * 4);
     t[r][c] = v.x; t[r][c + 1] = v.y; t[r][c + 2] = v.z; t[r][c + 3] = v.w;
   }
   __syncthreads();
   const int lane = threadIdx.x & 63;
-  for (int c = threadIdx.x >> 6; c < C; c += 4) a.xcm[((long)b * C + c) * a.N + r0 + lane] = t[lane][c];
+  if (r0 + lane < a.N)
+    for (int c = threadIdx.x >> 6; c < C; c += 4) a.xcm[((long)b * C + c) * a.N + r0 + lane] = t[lane][c];
 }
 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -804,20 +788,23 @@ struct KnnfWs {
   size_t ut, hn, xx, msum, stat, nflag, theta, tau, bitmap, flag, flist, keys, cjs, ccnt, xcm, total;
 };
 
+static int knnf_np(int N) { return (N + 127) / 128 * 128; }
+
 static KnnfWs knnf_layout(int B, int N, int Cp) {
   KnnfWs w{};
   size_t o = 0;
+  const int Np = knnf_np(N);
   w.msum = o; o += align256(sizeof(float) * (size_t)B * Cp);
   w.stat = o; o += align256(sizeof(unsigned int) * (size_t)B * 2);      // msum, stat and nflag are zeroed together
   w.nflag = o; o += 256;
-  w.ut = o; o += align256(2 * (size_t)B * N * Cp);
-  w.hn = o; o += align256(sizeof(float) * (size_t)B * N);
+  w.ut = o; o += align256(2 * (size_t)B * Np * Cp);
+  w.hn = o; o += align256(sizeof(float) * (size_t)B * Np);
   w.xx = o; o += align256(sizeof(float) * (size_t)B * N);
   w.theta = o; o += align256(sizeof(float) * (size_t)B * N);
   w.tau = o; o += align256(sizeof(float) * (size_t)B * N);
   w.flag = o; o += align256((size_t)B * N);
   w.flist = o; o += align256(sizeof(unsigned int) * (size_t)B * N);
-  w.bitmap = o; o += align256(sizeof(unsigned int) * (size_t)B * N * (N / 32));
+  w.bitmap = o; o += align256(sizeof(unsigned int) * (size_t)B * N * (Np / 32));
   w.keys = o; o += align256(sizeof(float) * (size_t)B * N * KNNF_CAP);
   w.cjs = o; o += align256(sizeof(unsigned short) * (size_t)B * N * KNNF_CAP);
   w.ccnt = o; o += align256(sizeof(int) * (size_t)B * N);
@@ -833,11 +820,11 @@ static int knnf_padded(int C) { return C <= 32 ? 32 : (C <= 64 ? 64 : 128); }
 using namespace gcn;
 
 GCN_EXPORT int gcn_knn_feature_supported(int B, int N, int C, int k2) {
-  return (B >= 1 && (C == 32 || C == 64 || C == 128) && N % 128 == 0 && N >= 1024 && N <= 16384 && k2 >= 1 && k2 <= 64) ? 1 : 0;
+  return (B >= 1 && (C == 32 || C == 64 || C == 128) && N >= 1024 && N <= 16384 && k2 >= 1 && k2 <= 128) ? 1 : 0;
 }
 
 GCN_EXPORT long gcn_knn_feature_ws_bytes(int B, int N, int C) {
-  if (B < 1 || N < 128 || N % 128 != 0 || C < 1 || C > 128) return -1;
+  if (B < 1 || N < 128 || N > 16384 || C < 1 || C > 128) return -1;
   return (long)knnf_layout(B, N, knnf_padded(C)).total;
 }
 
@@ -845,11 +832,12 @@ GCN_EXPORT int gcn_knn_feature(const float *x_pm, int B, int N, int C, int k1, i
                                void *stream) {
   GCN_REQUIRE(x_pm && idx && ws, "gcn_knn_feature: null pointer");
   GCN_REQUIRE(gcn_knn_feature_supported(B, N, C, k2), "gcn_knn_feature: unsupported shape B=%d N=%d C=%d k=%d "
-              "(need C in {32,64,128}, N %% 128 == 0, 1024 <= N <= 16384, k <= 64)", B, N, C, k2);
+              "(need C in {32,64,128}, 1024 <= N <= 16384, k <= 128)", B, N, C, k2);
   GCN_REQUIRE(k1 >= 1 && k1 <= k2, "gcn_knn_feature: need 1 <= k1 <= k2");
   GCN_REQUIRE(((uintptr_t)ws & 255) == 0 && ((uintptr_t)x_pm & 15) == 0, "gcn_knn_feature: ws must be 256-B aligned, x 16-B aligned");
   hipStream_t st = (hipStream_t)stream;
   const int Cp = knnf_padded(C);
+  const int Np = knnf_np(N);
   const KnnfWs w = knnf_layout(B, N, Cp);
   char *base = (char *)ws;
   KnnfArgs a{};
@@ -861,7 +849,9 @@ GCN_EXPORT int gcn_knn_feature(const float *x_pm, int B, int N, int C, int k1, i
   a.xcm = (float *)(base + w.xcm);
   a.long_list = KNNF_LONG_LIST;
   if (const char *e = getenv("GCANET_KNN_LONG_LIST")) a.long_list = (unsigned int)atol(e);   // test knob: 0 = always the matrix-core search
-  a.B = B; a.N = N; a.C = C; a.Cp = Cp; a.NW = N / 32; a.k = k2; a.step = k2 / k1;
+  // the short-list stage keeps KNNF_SLICES lists of 64 entries per listed query in the re-rank's `keys` scratch
+  a.long_list = std::min<unsigned int>(a.long_list, (unsigned int)((size_t)B * N * KNNF_CAP * sizeof(float) / (KNNF_SLICES * 64 * sizeof(u64))));
+  a.B = B; a.N = N; a.Np = Np; a.C = C; a.Cp = Cp; a.NW = Np / 32; a.k = k2; a.step = k2 / k1;
   a.kout = (k2 + a.step - 1) / a.step;
   // rank of the sample order statistic: mean k/8 of the true neighbours fall into the 1-in-8 sample
   const double mu = (double)k2 / KNNF_STRIDE;
@@ -872,8 +862,8 @@ GCN_EXPORT int gcn_knn_feature(const float *x_pm, int B, int N, int C, int k1, i
   a.m_rank = m;
   GCN_HIP(hipMemsetAsync(base + w.msum, 0, w.ut - w.msum, st));
   knnf_colsum_kernel<<<dim3(64, B), 256, 0, st>>>(a);
-  knnf_prep_kernel<<<dim3(cdiv(N, 64), B), 256, 0, st>>>(a);
-  const dim3 grid(N / 128, B);
+  knnf_prep_kernel<<<dim3(Np / 64, B), 256, 0, st>>>(a);
+  const dim3 grid(Np / 128, B);
 #define KNNF_STREAM(KSV)                                                                                           \
   {                                                                                                                 \
     constexpr int LDSB = 2 * (128 * KSV * 32 + 512);                                                                \
@@ -886,33 +876,32 @@ GCN_EXPORT int gcn_knn_feature(const float *x_pm, int B, int N, int C, int k1, i
 #undef KNNF_STREAM
   int rc = check_launch("knnf_stream_kernel");
   if (rc) return rc;
-  const dim3 rgrid(N / 4, B);
-  const char *rr_env = getenv("GCANET_KNN_RERANK");
-  if (rr_env && atoi(rr_env) == 1) {                         // the single-kernel form (kept for comparison)
-    if (C == 32) knnf_rerank_kernel<32><<<rgrid, 256, 0, st>>>(a);
-    else if (C == 64) knnf_rerank_kernel<64><<<rgrid, 256, 0, st>>>(a);
-    else knnf_rerank_kernel<128><<<rgrid, 256, 0, st>>>(a);
-  } else {
+  const dim3 rgrid(cdiv(N, 4), B);
 #define KNNF_RERANK2(CCV)                                                                                          \
-    {                                                                                                               \
-      constexpr int PBV = 8 * 16;                                                                                   \
-      constexpr int LDSV = 4 * (64 * PBV + 2 * KNNF_CAP);                                                           \
-      GCN_HIP(hipFuncSetAttribute((const void *)knnf_keys_kernel<CCV>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSV)); \
-      knnf_keys_kernel<CCV><<<rgrid, 256, LDSV, st>>>(a);                                                           \
-      knnf_rank_kernel<CCV><<<rgrid, 256, 0, st>>>(a);                                                              \
-    }
-    if (C == 32) KNNF_RERANK2(32) else if (C == 64) KNNF_RERANK2(64) else KNNF_RERANK2(128)
-#undef KNNF_RERANK2
+  {                                                                                                                 \
+    constexpr int PBV = 8 * 16;                                                                                     \
+    constexpr int LDSV = 4 * (64 * PBV + 2 * KNNF_CAP);                                                             \
+    GCN_HIP(hipFuncSetAttribute((const void *)knnf_keys_kernel<CCV>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSV)); \
+    knnf_keys_kernel<CCV><<<rgrid, 256, LDSV, st>>>(a);                                                             \
+    knnf_rank_kernel<CCV><<<rgrid, 256, 0, st>>>(a);                                                                \
   }
-  rc = check_launch("knnf_rerank_kernel");
+  if (C == 32) KNNF_RERANK2(32) else if (C == 64) KNNF_RERANK2(64) else KNNF_RERANK2(128)
+#undef KNNF_RERANK2
+  rc = check_launch("knnf_rank_kernel");
   if (rc) return rc;
+  // the exhaustive stage for the flagged queries.  k <= 64 on a cloud the f32 matrix-core kernel accepts: a short list
+  // one workgroup per query, a long one on the matrix cores; otherwise the VALU selection kernel in its flagged mode
+  // (one wave scans per flagged query; free when nothing is flagged)
+  if (k2 > 64 || (N % 4) != 0)
+    return launch_knn_flagged(x_pm, a.xx, a.flag, B, N, C, k2, a.step, a.kout, idx, st);
   knnf_list_kernel<<<std::min(256, cdiv(B * N, 256)), 256, 0, st>>>(a);
-  if (C == 32) knnf_fallback_kernel<32><<<256, 256, 0, st>>>(a);
-  else if (C == 64) knnf_fallback_kernel<64><<<256, 256, 0, st>>>(a);
-  else knnf_fallback_kernel<128><<<256, 256, 0, st>>>(a);
+  if (C == 32) knnf_fallback_kernel<32><<<1024, 256, 0, st>>>(a);
+  else if (C == 64) knnf_fallback_kernel<64><<<1024, 256, 0, st>>>(a);
+  else knnf_fallback_kernel<128><<<1024, 256, 0, st>>>(a);
+  knnf_fallback_merge_kernel<<<256, 256, 0, st>>>(a);
   rc = check_launch("knnf_fallback_kernel");
   if (rc) return rc;
-  knnf_transpose_kernel<<<dim3(N / 64, B), 256, 0, st>>>(a);
+  knnf_transpose_kernel<<<dim3(cdiv(N, 64), B), 256, 0, st>>>(a);
   rc = check_launch("knnf_transpose_kernel");
   if (rc) return rc;
   return launch_knn_mfma16_flagged(a.xcm, a.xx, a.flag, a.nflag, a.long_list, B, N, C, k2, a.step, a.kout, idx, st);
@@ -924,7 +913,7 @@ GCN_EXPORT int gcn_knn_feature_stats(const void *ws, int B, int N, int C, long *
   const KnnfWs w = knnf_layout(B, N, knnf_padded(C));
   const size_t nb = (size_t)B * N;
   unsigned char *hf = (unsigned char *)malloc(nb);
-  const size_t words = (size_t)B * N * (N / 32);
+  const size_t words = (size_t)B * N * (knnf_np(N) / 32);
   unsigned int *hb = (unsigned int *)malloc(words * 4);
   if (!hf || !hb) { free(hf); free(hb); set_error("gcn_knn_feature_stats: out of host memory"); return GCN_EINVAL; }
   GCN_HIP(hipStreamSynchronize((hipStream_t)stream));

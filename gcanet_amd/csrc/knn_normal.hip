@@ -7,7 +7,7 @@
 // per query.  Box pruning (knn_tiles_kernel) does not help when the normals are incoherent: the factor 3 - 2 n.n spans
 // [1,5] and more than half of the Morton tiles survive.  Here nothing is inserted during the N^2 pass:
 //   1. prep       (B,6,N) channel-major -> 32-byte rows {x y z nx ny nz |xyz|^2 0}.
-//   2. threshold  knnn_sample_kernel: for every query the m-th smallest key over a 1-in-8 strided sample of the
+//   2. threshold  knnn_sample_kernel: for every query the m-th smallest key over a 1-in-8 pseudo-random sample of the
 //                 candidates (m ~ k/8 + 6 sqrt(k/8)): a value tau with, almost surely, at least k keys under it.
 //                 Four lanes share a query (a quarter of the sample each, three smallest per group of samples kept in
 //                 registers), the order statistic comes from an MSB-first search on the monotone integer image.
@@ -18,6 +18,8 @@
 //                 64 pairs instead of 13 + list upkeep.
 //   4. re-rank    knnn_rerank_kernel: one wave per query expands its ~3k bits, re-evaluates those keys (bitwise the
 //                 same expression as the filter), and sorts by (key, index): lowest index wins ties, as in the oracle.
+//      Clouds of any size 1024 <= N <= 16384 (rows padded to a multiple of 1024 with far-away points whose key exceeds
+//      every threshold), k <= 128 (two sorted entries per lane beyond 64).
 //   5. fallback   a query with fewer than k or more than 512 bits is flagged and searched exhaustively by
 //                 knn_select_kernel in its flagged-only mode (knn.hip).
 // Every key is the oracle's expression (oracle/gcanet_oracle.c:model_pd, metric 1), so the result is exact by
@@ -30,8 +32,7 @@ namespace gcn {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int KNNN_CAP = 512;
-constexpr int KNNN_STRIDE = 8;
-constexpr int KNNN_PHASE = 3;
+constexpr int KNNN_STRIDE = 8;       // the sample holds N/8 hashed candidate rows (knn_topb.h: knn_sample_row)
 constexpr int KNNN_CS = 8;           // candidate ranges per query block in the filter pass
 
 // M = 1: oracle/gcanet_oracle.c:model_pd metric 1 (M4:62-75): q = query i, c = candidate j; rows {x y z nx | ny nz xx 0}
@@ -66,17 +67,23 @@ __device__ __forceinline__ float knnn_key(const float4 q0, const float4 q1, cons
 
 // ------------------------------------------------------------------ 1. rows
 __global__ __launch_bounds__(256) void knnn_prep_kernel(const float *__restrict__ x, const float *__restrict__ xx,
-                                                        float *__restrict__ rows, int N, int C, long sb, long sd, long sn) {
+                                                        float *__restrict__ rows, int N, int Np, int C, long sb, long sd, long sn) {
   const int j = blockIdx.x * 256 + threadIdx.x;
   const int b = blockIdx.y;
-  if (j >= N) return;
+  if (j >= Np) return;
+  if (j >= N) {       // padding candidate: far away, finite in every metric's key (> any threshold), never a NaN
+    float4 *o = reinterpret_cast<float4 *>(rows + ((long)b * Np + j) * 8);
+    o[0] = make_float4(1e18f, 1e18f, 1e18f, 0.f);
+    o[1] = make_float4(0.f, 0.f, 3e36f, 0.f);
+    return;
+  }
   const float *p = x + (long)b * sb + (long)j * sn;         // element (b, d, j) at b*sb + d*sd + j*sn
   float4 r0, r1;
   r0.x = p[0]; r0.y = p[sd]; r0.z = p[2 * sd];
   r0.w = C >= 6 ? p[3 * sd] : 0.f;
   r1.x = C >= 6 ? p[4 * sd] : 0.f; r1.y = C >= 6 ? p[5 * sd] : 0.f;
   r1.z = xx ? xx[(long)b * N + j] : 0.f; r1.w = 0.f;
-  float4 *o = reinterpret_cast<float4 *>(rows + ((long)b * N + j) * 8);
+  float4 *o = reinterpret_cast<float4 *>(rows + ((long)b * Np + j) * 8);
   o[0] = r0;
   o[1] = r1;
 }
@@ -86,7 +93,7 @@ __global__ __launch_bounds__(256) void knnn_prep_kernel(const float *__restrict_
 // LDS; the four quarters of a wave read rows one apart (different banks), every 16-lane group the same address.
 template <int M>
 __global__ __launch_bounds__(256) void knnn_sample_kernel(const float *__restrict__ rows, float *__restrict__ tau, int N,
-                                                          int m_rank) {
+                                                          int Np, int m_rank) {
   extern __shared__ __attribute__((aligned(16))) float4 smp[];      // (N/8, 2)
   const int lane = lane_id(), wave = wave_id();
   const int lin = blockIdx.x + gridDim.x * blockIdx.y;              // cloud = id % B: one cloud per XCD at 8 clouds
@@ -94,11 +101,12 @@ __global__ __launch_bounds__(256) void knnn_sample_kernel(const float *__restric
   const int q = (lin / (int)gridDim.y) * 64 + wave * 16 + (lane & 15);
   const int part = lane >> 4;
   const int ns = N / KNNN_STRIDE;
-  const float4 *rb = reinterpret_cast<const float4 *>(rows + (long)b * N * 8);
-  for (int i = threadIdx.x; i < 2 * ns; i += 256) smp[i] = rb[(long)(KNNN_STRIDE * (i >> 1) + KNNN_PHASE) * 2 + (i & 1)];
-  const float4 q0 = rb[(long)q * 2], q1 = rb[(long)q * 2 + 1];
+  const float4 *rb = reinterpret_cast<const float4 *>(rows + (long)b * Np * 8);
+  for (int i = threadIdx.x; i < 2 * ns; i += 256) smp[i] = rb[(long)knn_sample_row(i >> 1, N) * 2 + (i & 1)];
+  const int qc = min(q, N - 1);
+  const float4 q0 = rb[(long)qc * 2], q1 = rb[(long)qc * 2 + 1];
   __syncthreads();
-  const int gs = ns / 32;                                            // samples per (quarter, group)
+  const int gs = (ns + 31) / 32;                                     // samples per (quarter, group); slots >= ns are empty
   float t0[8], t1[8], t2[8];
 #pragma unroll
   for (int g = 0; g < 8; ++g) {
@@ -107,8 +115,9 @@ __global__ __launch_bounds__(256) void knnn_sample_kernel(const float *__restric
     for (int s = 0; s < gs; ++s) {
       int ss = s + part;
       ss = ss >= gs ? ss - gs : ss;
-      const float4 c0 = smp[(base + ss) * 2], c1 = smp[(base + ss) * 2 + 1];
-      const float key = knnn_key<M>(q0, q1, c0, c1);
+      const int si = min(base + ss, ns - 1);
+      const float4 c0 = smp[si * 2], c1 = smp[si * 2 + 1];
+      const float key = base + ss < ns ? knnn_key<M>(q0, q1, c0, c1) : __builtin_inff();
       const float x1 = fmaxf(t0[g], key);
       t0[g] = fminf(t0[g], key);
       const float x2 = fmaxf(t1[g], x1);
@@ -131,7 +140,7 @@ __global__ __launch_bounds__(256) void knnn_sample_kernel(const float *__restric
     c += __shfl_xor(c, 32);
     p = c >= m_rank ? p : trial;
   }
-  if (part == 0) tau[(long)b * N + q] = key_u2f(p | 0xffu);
+  if (part == 0 && q < N) tau[(long)b * N + q] = key_u2f(p | 0xffu);
 }
 
 // ------------------------------------------------------------------ 3. filter: one bit per (query, candidate)
@@ -139,7 +148,7 @@ __global__ __launch_bounds__(256) void knnn_sample_kernel(const float *__restric
 // wave-uniform: the loads below are scalar (s_load_dwordx8 through the scalar cache).
 template <int M>
 __global__ __launch_bounds__(256) void knnn_filter_kernel(const float *__restrict__ rows, const float *__restrict__ tau,
-                                                          unsigned int *__restrict__ bitmap, int N, int B) {
+                                                          unsigned int *__restrict__ bitmap, int N, int Np, int B) {
   const int lane = lane_id(), wave = wave_id();
   const int lin = blockIdx.x;
   const int b = lin % B;
@@ -147,8 +156,8 @@ __global__ __launch_bounds__(256) void knnn_filter_kernel(const float *__restric
   const int range = rest % KNNN_CS;
   const int qa = (rest / KNNN_CS) * 512 + wave * 128 + lane;
   if (qa - lane >= N) return;
-  const int NW = N / 32;
-  const float *rb = rows + (long)b * N * 8;
+  const int NW = Np / 32;
+  const float *rb = rows + (long)b * Np * 8;
   const int qA = min(qa, N - 1), qB = min(qa + 64, N - 1);
   const float4 a0 = reinterpret_cast<const float4 *>(rb)[(long)qA * 2], a1 = reinterpret_cast<const float4 *>(rb)[(long)qA * 2 + 1];
   const float4 b0 = reinterpret_cast<const float4 *>(rb)[(long)qB * 2], b1 = reinterpret_cast<const float4 *>(rb)[(long)qB * 2 + 1];
@@ -156,7 +165,7 @@ __global__ __launch_bounds__(256) void knnn_filter_kernel(const float *__restric
               qnz = {a1.y, b1.y}, qxx = {a1.z, b1.z};
   const float tauA = tau[(long)b * N + qA], tauB = tau[(long)b * N + qB];
   const f32x2 zero2 = {0.f, 0.f}, two2 = {2.f, 2.f}, one2 = {1.f, 1.f}, m2 = {-2.f, -2.f};
-  const int per = N / KNNN_CS;                 // candidates of this range: a multiple of 128
+  const int per = Np / KNNN_CS;                // candidates of this range: a multiple of 128 (Np % 1024 == 0)
   const int j0 = range * per;
   for (int w4 = 0; w4 < per / 128; ++w4) {
     unsigned int wa[4], wb[4];
@@ -217,15 +226,15 @@ __global__ __launch_bounds__(256) void knnn_filter_kernel(const float *__restric
 template <int M>
 __global__ __launch_bounds__(256) void knnn_rerank_kernel(const float *__restrict__ rows, const unsigned int *__restrict__ bitmap,
                                                           unsigned char *__restrict__ flag, int64_t *__restrict__ idx,
-                                                          float *__restrict__ val, int N, int k, int step, long o_sb, long o_sk,
-                                                          long o_sq) {
-  __shared__ unsigned short cand_s[4][KNNN_CAP];
+                                                          float *__restrict__ val, int N, int Np, int k, int step, long o_sb,
+                                                          long o_sk, long o_sq) {
+  __shared__ __attribute__((aligned(16))) unsigned short cand_s[4][KNNN_CAP];     // later the 128-entry sort buffer (k > 64)
   const int lane = lane_id(), wave = wave_id();
   const int lin = blockIdx.x + gridDim.x * blockIdx.y;
   const int b = lin % (int)gridDim.y;
   const int q = (lin / (int)gridDim.y) * 4 + wave;
   if (q >= N) return;
-  const int NW = N / 32;
+  const int NW = Np / 32;
   const unsigned int *bm = bitmap + ((long)b * N + q) * NW;
   unsigned int words[8];
   int cnt = 0;
@@ -261,7 +270,7 @@ __global__ __launch_bounds__(256) void knnn_rerank_kernel(const float *__restric
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
 
-  const float4 *rb = reinterpret_cast<const float4 *>(rows + (long)b * N * 8);
+  const float4 *rb = reinterpret_cast<const float4 *>(rows + (long)b * Np * 8);
   const float4 q0 = rb[(long)q * 2], q1 = rb[(long)q * 2 + 1];
   unsigned int kf[8];
   int cj[8];
@@ -279,24 +288,33 @@ __global__ __launch_bounds__(256) void knnn_rerank_kernel(const float *__restric
     }
   }
   TopB tb;
-  rank_candidates(kf, cj, total, k, lane, tb);
-  if (lane < k && (lane % step) == 0) {
-    const long o = (long)b * o_sb + (long)(lane / step) * o_sk + (long)q * o_sq;    // output element (b, t, q)
-    idx[o] = (int64_t)(unsigned int)tb.lst;
-    const float kv = key_u2f((unsigned int)(tb.lst >> 32));
-    if (val) val[o] = M == 0 ? sqrtf(kv) : -kv;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // the candidate list is dead: its LDS becomes the sort buffer
+  __builtin_amdgcn_wave_barrier();
+  rank_candidates(kf, cj, total, k, lane, tb, reinterpret_cast<u64 *>(cand));
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int pos = lane + 64 * h;
+    const u64 e = h ? tb.pnd : tb.lst;
+    if (pos < k && (pos % step) == 0) {
+      const long o = (long)b * o_sb + (long)(pos / step) * o_sk + (long)q * o_sq;    // output element (b, t, q)
+      idx[o] = (int64_t)(unsigned int)e;
+      const float kv = key_u2f((unsigned int)(e >> 32));
+      if (val) val[o] = M == 0 ? sqrtf(kv) : -kv;
+    }
   }
 }
 
 static size_t knnn_align(size_t v) { return (v + 255) & ~(size_t)255; }
 
+static int knnn_np(int N) { return (N + 1023) / 1024 * 1024; }
+
 bool knn_normal_supported(int B, int N, int k) {
-  return B >= 1 && N % 1024 == 0 && N >= 1024 && N <= 16384 && k >= 1 && k <= 64;
+  return B >= 1 && N >= 1024 && N <= 16384 && k >= 1 && k <= 128 && k <= N;
 }
 
 size_t knn_normal_ws_bytes(int B, int N) {
-  const size_t n = (size_t)B * N;
-  return knnn_align(n * 32) + knnn_align(n * 4) + knnn_align(n) + knnn_align(n * (size_t)(N / 8));
+  const size_t n = (size_t)B * N, np = (size_t)B * knnn_np(N);
+  return knnn_align(np * 32) + knnn_align(n * 4) + knnn_align(n) + knnn_align(n * (size_t)(knnn_np(N) / 8));
 }
 
 // metric 1: x (B,6,N) xyz + normal, xx (B,N) |xyz|^2 in the oracle's order (knn_points_normals); metric 2: the in-model
@@ -308,33 +326,27 @@ int run_knn_normal(int metric, const float *x, long sb, long sd, long sn, const 
                    long o_sb, long o_sk, long o_sq, int64_t *idx, float *val, void *ws, const unsigned char **flag_out,
                    hipStream_t st) {
   char *base = (char *)ws;
-  const size_t n = (size_t)B * N;
-  float *rows = (float *)base; base += knnn_align(n * 32);
+  const int Np = knnn_np(N);
+  const size_t n = (size_t)B * N, np = (size_t)B * Np;
+  float *rows = (float *)base; base += knnn_align(np * 32);
   float *tau = (float *)base; base += knnn_align(n * 4);
   unsigned char *flag = (unsigned char *)base; base += knnn_align(n);
   unsigned int *bitmap = (unsigned int *)base;
-  knnn_prep_kernel<<<dim3(cdiv(N, 256), B), 256, 0, st>>>(x, xx, rows, N, metric == 1 ? 6 : 3, sb, sd, sn);
+  knnn_prep_kernel<<<dim3(cdiv(Np, 256), B), 256, 0, st>>>(x, xx, rows, N, Np, metric == 1 ? 6 : 3, sb, sd, sn);
   const double mu = (double)k / KNNN_STRIDE;
   int m = (int)(mu + 6.0 * __builtin_sqrt(mu) + 2.0);
   if (m > 96) m = 96;
   const int lds = (N / KNNN_STRIDE) * 32;
-  const dim3 gs(N / 64, B), gf((N / 512) * KNNN_CS * B), gr(N / 4, B);
-  if (metric == 1) {
-    GCN_HIP(hipFuncSetAttribute((const void *)knnn_sample_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    knnn_sample_kernel<1><<<gs, 256, lds, st>>>(rows, tau, N, m);
-    knnn_filter_kernel<1><<<gf, 256, 0, st>>>(rows, tau, bitmap, N, B);
-    knnn_rerank_kernel<1><<<gr, 256, 0, st>>>(rows, bitmap, flag, idx, val, N, k, step, o_sb, o_sk, o_sq);
-  } else if (metric == 2) {
-    GCN_HIP(hipFuncSetAttribute((const void *)knnn_sample_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    knnn_sample_kernel<2><<<gs, 256, lds, st>>>(rows, tau, N, m);
-    knnn_filter_kernel<2><<<gf, 256, 0, st>>>(rows, tau, bitmap, N, B);
-    knnn_rerank_kernel<2><<<gr, 256, 0, st>>>(rows, bitmap, flag, idx, val, N, k, step, o_sb, o_sk, o_sq);
-  } else {
-    GCN_HIP(hipFuncSetAttribute((const void *)knnn_sample_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    knnn_sample_kernel<0><<<gs, 256, lds, st>>>(rows, tau, N, m);
-    knnn_filter_kernel<0><<<gf, 256, 0, st>>>(rows, tau, bitmap, N, B);
-    knnn_rerank_kernel<0><<<gr, 256, 0, st>>>(rows, bitmap, flag, idx, val, N, k, step, o_sb, o_sk, o_sq);
+  const dim3 gs(cdiv(N, 64), B), gf((Np / 512) * KNNN_CS * B), gr(cdiv(N, 4), B);
+#define KNNN_RUN(MV)                                                                                               \
+  {                                                                                                                 \
+    GCN_HIP(hipFuncSetAttribute((const void *)knnn_sample_kernel<MV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+    knnn_sample_kernel<MV><<<gs, 256, lds, st>>>(rows, tau, N, Np, m);                                              \
+    knnn_filter_kernel<MV><<<gf, 256, 0, st>>>(rows, tau, bitmap, N, Np, B);                                        \
+    knnn_rerank_kernel<MV><<<gr, 256, 0, st>>>(rows, bitmap, flag, idx, val, N, Np, k, step, o_sb, o_sk, o_sq);     \
   }
+  if (metric == 1) KNNN_RUN(1) else if (metric == 2) KNNN_RUN(2) else KNNN_RUN(0)
+#undef KNNN_RUN
   *flag_out = flag;
   return check_launch("knnn_rerank_kernel");
 }

@@ -75,12 +75,34 @@ struct TopB {
 };
 
 
+// ascending bitonic sort of 128 entries held two per lane: `a` = position lane, `b` = position lane + 64
+__device__ __forceinline__ void sort128(u64 &a, u64 &b, int lane) {
+#pragma unroll
+  for (int sz = 2; sz <= 64; sz <<= 1)
+#pragma unroll
+    for (int j = sz >> 1; j >= 1; j >>= 1) {
+      a = TopB::cex(a, lane, j, (lane & sz) == 0);
+      b = TopB::cex(b, lane, j, ((lane + 64) & sz) == 0);          // sz == 64: the upper half sorts descending
+    }
+  {                                                                  // sz = 128, j = 64: partner sits in the same lane
+    const u64 lo = a < b ? a : b, hi = a < b ? b : a;
+    a = lo; b = hi;
+  }
+#pragma unroll
+  for (int j = 32; j >= 1; j >>= 1) {
+    a = TopB::cex(a, lane, j, true);
+    b = TopB::cex(b, lane, j, true);
+  }
+}
+
 // The k smallest of up to 512 candidates held 8 per lane as (monotone integer key kf[bt], index cj[bt]), batch bt valid
-// when bt*64 < total (empty slots carry 0xFFFFFFFF), sorted by (key, index) into tb.lst.  The k-th smallest key VALUE
-// comes from an MSB-first search with wave-wide counts (scalar unit), then ONE bitonic sort of the candidates at or
-// below it instead of a sort + merge per batch of 64.  Used by the re-rank kernels of knn_filter.hip / knn_normal.hip.
-__device__ __forceinline__ void rank_candidates(const unsigned int (&kf)[8], const int (&cj)[8], int total, int k, int lane,
-                                                TopB &tb) {
+// when bt*64 < total (empty slots carry 0xFFFFFFFF), sorted by (key, index): positions 0..63 in tb.lst, and -- for
+// 64 < k <= 128 -- positions 64..127 in tb.pnd (buf: a per-wave LDS buffer of 128 entries, used only then).  The k-th
+// smallest key VALUE comes from an MSB-first search with wave-wide counts (scalar unit), then ONE bitonic sort of the
+// candidates at or below it instead of a sort + merge per batch of 64.  Returns the k-th smallest key (integer image).
+// Used by the re-rank kernels of knn_filter.hip / knn_normal.hip.
+__device__ __forceinline__ unsigned int rank_candidates(const unsigned int (&kf)[8], const int (&cj)[8], int total, int k, int lane,
+                                                        TopB &tb, u64 *buf = nullptr) {
   const int nb = (total + 63) >> 6;
   auto kth_key = [&](auto nbc) -> unsigned int {
     constexpr int NB = decltype(nbc)::value;
@@ -118,7 +140,7 @@ __device__ __forceinline__ void rank_candidates(const unsigned int (&kf)[8], con
   // the remaining k - nlt places (ties -> lowest index, as the reference's stable insertion).  Usually nle == k and
   // the index bound is the maximum.
   int jmax = 0x7fffffff;
-  if (nle > 64) {                                            // wave-uniform, rare: an exact tie straddles the k-th place
+  if (nle > k) {                                             // wave-uniform, rare: an exact tie straddles the k-th place
     const int need = k - nlt;
     int pj = 0;
     for (int bit = 15; bit >= 0; --bit) {                    // largest pj with fewer than `need` tied indices below it
@@ -131,14 +153,37 @@ __device__ __forceinline__ void rank_candidates(const unsigned int (&kf)[8], con
     }
     jmax = pj;                                               // the need-th smallest tied index
   }
+  if (k <= 64) {
+#pragma unroll
+    for (int bt = 0; bt < 8; ++bt)
+      if (bt * 64 < total) {
+        const bool pass = kf[bt] < pk || (kf[bt] == pk && cj[bt] <= jmax);
+        const unsigned long long m = __ballot(pass);
+        if (m) npend = tb.append(m, pass, key_u2f(kf[bt]), cj[bt], npend, lane);
+      }
+    tb.sort_pending(npend, lane);
+    return pk;
+  }
+  // 64 < k <= 128: the (exactly k) passing candidates are compacted into the LDS buffer, two entries per lane are sorted
+  buf[lane] = TOPB_SENT;
+  buf[lane + 64] = TOPB_SENT;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
 #pragma unroll
   for (int bt = 0; bt < 8; ++bt)
     if (bt * 64 < total) {
       const bool pass = kf[bt] < pk || (kf[bt] == pk && cj[bt] <= jmax);
       const unsigned long long m = __ballot(pass);
-      if (m) npend = tb.append(m, pass, key_u2f(kf[bt]), cj[bt], npend, lane);
+      const int rank = __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0));
+      if (pass && npend + rank < 128) buf[npend + rank] = ((u64)kf[bt] << 32) | (unsigned int)cj[bt];
+      npend += __popcll(m);
     }
-  tb.sort_pending(npend, lane);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  tb.lst = buf[lane];
+  tb.pnd = buf[lane + 64];
+  sort128(tb.lst, tb.pnd, lane);
+  return pk;
 }
 
 // exact kNN in the model's expanded form for the queries whose flag byte is set (the safety net of knn_filter.hip);
@@ -152,6 +197,16 @@ int launch_knn_flagged(const float *x_pm, const float *xx, const unsigned char *
 // set) through knn_select_kernel afterwards.
 bool knn_normal_supported(int B, int N, int k);
 size_t knn_normal_ws_bytes(int B, int N);
+// The candidate row of slot i of the N/8-row sample the threshold passes use: a hash of the slot number, i.e. rows drawn
+// (with replacement) independently of the cloud's storage order.  A strided sample (round 2: row 8 i + 3) meets a cloud
+// stored cluster by cluster in rotation at the same few clusters for every query; and one row of every 8 consecutive
+// ones still ties the slot number -- hence the lane that keeps the slot's value -- to the cluster: every query of
+// bench.blob_clouds then overshoots its threshold (tools/debug/knn_flagged_why.py).
+__host__ __device__ __forceinline__ int knn_sample_row(int i, int N) {
+  unsigned int h = (unsigned int)i + 0x9E3779B9u;
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;        // murmur3 finaliser
+  return (int)(((unsigned long long)h * (unsigned int)N) >> 32);
+}
 int run_knn_normal(int metric, const float *x, long sb, long sd, long sn, const float *xx, int B, int C, int N, int k, int step,
                    long o_sb, long o_sk, long o_sq, int64_t *idx, float *val, void *ws, const unsigned char **flag_out,
                    hipStream_t st);

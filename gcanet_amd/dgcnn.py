@@ -27,7 +27,7 @@ def _knn_model(x, k1, k2, metric):
     # 3-D clouds: Morton-tiled kernel with box pruning (identical results).  Not used for the normal metric: its
     # factor (3 - 2 n_i.n_j) in [1,5] inflates the k-th key relative to the Euclidean bound, and with incoherent
     # normals (the synthetic benchmark clouds) more than half of the tiles survive -- slower than the full scan.
-    # 3-D clouds (xyz, or xyz + normal) at N % 1024 == 0: threshold + filter + re-rank in exact arithmetic
+    # 3-D clouds (xyz, or xyz + normal), 1024 <= N <= 16384, k <= 128: threshold + filter + re-rank in exact arithmetic
     # (csrc/knn_normal.hip)
     if ((metric == 1 and C == 6) or (metric == 0 and C == 3)) and _lib.lib().gcn_knn_normal_supported(B, N, k2):
         # scratch per call: the caching allocator makes that free, and inside a HIP-graph capture the buffer lands in the
@@ -42,9 +42,11 @@ def _knn_model(x, k1, k2, metric):
     return idx
 
 
-def knn_feature_pm(x_pm, k1, k2):
+def knn_feature_pm(x_pm, k1, k2, stats=None):
     """`knn` on POINT-major features x_pm (B,N,C) f32, C in {32,64,128}: bf16 matrix-core prefilter + exact f32
-    re-rank (csrc/knn_filter.hip) -- bit-identical indices to `knn`.  Returns None when the shape is not served."""
+    re-rank (csrc/knn_filter.hip) -- bit-identical indices to `knn`.  Returns None when the shape is not served.
+    stats: an optional dict that receives `flagged` (queries that went to the exhaustive stage) and `candidates`
+    (prefilter survivors over all queries) of this call -- diagnostics, synchronises."""
     B, N, C = x_pm.shape
     lib = _lib.lib()
     if not (x_pm.is_cuda and lib.gcn_knn_feature_supported(B, N, C, k2)):
@@ -57,6 +59,11 @@ def knn_feature_pm(x_pm, k1, k2):
     with _lib.on_device(x_pm):
         _lib.call("gcn_knn_feature", _lib.ptr(x_pm), B, N, C, k1, k2, _lib.ptr(idx), _lib.ptr(ws),
                   _lib.stream_of(x_pm), tag="knn_model[B=%d,C=%d,N=%d,k=%d]" % (B, C, N, k2))
+        if stats is not None:
+            import ctypes
+            fl, ca = ctypes.c_long(0), ctypes.c_long(0)
+            _lib.call("gcn_knn_feature_stats", _lib.ptr(ws), B, N, C, ctypes.addressof(fl), ctypes.addressof(ca), _lib.stream_of(x_pm))
+            stats.update(flagged=fl.value, candidates=ca.value)
     return idx
 
 

@@ -67,8 +67,9 @@ long gcn_knn_tiles_ws_bytes(int B, int C, int N);
 
 /* knn_points_normals (metric 1, C == 6) is served by threshold + filter + re-rank in the reference's exact arithmetic
  * (csrc/knn_normal.hip: sampled order statistic -> one bit per pair -> exact ranking of ~3k survivors; identical
- * indices/values) when this returns 1 (N % 1024 == 0, 1024 <= N <= 16384, k2 <= 64) AND tile_ws is given:
- * gcn_knn_tiles_ws_bytes(B, 6, N) then includes the B*N*N/8-byte bitmap.  The same scheme serves gcn_knn_cuda for a
+ * indices/values) when this returns 1 (1024 <= N <= 16384 -- any N: the candidate rows are padded to a multiple of 1024
+ * with far-away points --, k2 <= 128) AND tile_ws is given: gcn_knn_tiles_ws_bytes(B, 6, N) then includes the
+ * B*N*Np/8-byte bitmap.  The same scheme serves gcn_knn_cuda for a
  * 3-D cloud searched against itself (KNN(k)(x, x), squared distances by differences) under the same size conditions,
  * with gcn_knn_tiles_ws_bytes(B, 3, nr) bytes of workspace. */
 int gcn_knn_normal_supported(int B, int N, int k2);
@@ -79,8 +80,9 @@ int gcn_knn_normal_supported(int B, int N, int k2);
  *   x_pm (B,N,C) f32 POINT-major rows (the layout the fused EdgeConv already keeps), idx (B,N,kout) int64 as
  *   gcn_knn_model; ws: gcn_knn_feature_ws_bytes(B,N,C) bytes of device scratch, 256-B aligned (B*N*N/8 bytes of
  *   candidate bits dominate: 67 MB at B=8, N=8192).
- * gcn_knn_feature_supported: 1 when the shape is served (C in {32,64,128}, N % 128 == 0, 1024 <= N <= 16384,
- * k2 <= 64); other shapes use gcn_knn_model.
+ * gcn_knn_feature_supported: 1 when the shape is served (C in {32,64,128}, 1024 <= N <= 16384 -- any N, e.g. the
+ * reference's default 7000: candidate rows are padded to a multiple of 128 --, k2 <= 128, e.g. its default 80); other
+ * shapes use gcn_knn_model.
  * gcn_knn_feature_stats (diagnostics, synchronises): queries of the last call that fell back to the exact brute-force
  * search, and the total number of prefilter candidates. */
 int gcn_knn_feature_supported(int B, int N, int C, int k2);

@@ -272,18 +272,30 @@ def _feature_cloud(kind, B, C, N, seed):
         x = torch.nn.functional.leaky_relu(x + 0.5, 0.2)
     elif kind == "offset":               # tiny spread around a large mean: the reference's own f32 noise decides
         x = x * 0.05 + 4.0               # the order -> the a-posteriori check fails and the exhaustive path runs
+    elif kind == "offset2":              # the same, harsher: the reference's f32 error bound exceeds every neighbour distance
+        x = x * 0.01 + 8.0
     elif kind == "dups":                 # exact duplicates: exact key ties straddling the k-th place
         x[:, :, N // 2:] = x[:, :, :N // 2]
     elif kind == "clusters":             # tight clusters of ~40 points: the k-th neighbour is far beyond the first few
         centres = torch.randn(B, C, N // 40 + 1, generator=g) * 3
         x = centres[:, :, torch.arange(N) // 40] + 0.01 * x
+    elif kind == "blobs":                # 64 blobs stored in ROTATION (point i belongs to blob i % 64, as bench.blob_clouds
+        centres = torch.randn(B, C, 64, generator=g)      # lays its clouds out): a fixed-phase strided sample meets the
+        x = centres[:, :, torch.arange(N) % 64] + 0.03 * x   # same 8 blobs for every query (round 2: every query flagged)
+    elif kind == "flat":                 # 64 patches of near-identical features (a CAD part's flat faces), same layout
+        x = torch.randn(B, C, 64, generator=g)[:, :, torch.arange(N) % 64] + 1e-4 * x
     return x
 
 
 @pytest.mark.parametrize("kind,C,N,k1,k2", [
     ("normal", 64, 1024, 16, 16), ("normal", 32, 2048, 20, 20), ("relu", 64, 4096, 33, 33), ("normal", 128, 2048, 64, 64),
     ("normal", 64, 2048, 8, 64), ("dups", 64, 2048, 64, 64), ("dups", 32, 1024, 7, 7), ("offset", 64, 1024, 16, 16),
-    ("clusters", 64, 2048, 64, 64), ("normal", 64, 1152, 10, 10)])
+    ("clusters", 64, 2048, 64, 64), ("normal", 64, 1152, 10, 10),
+    # round 3: any 1024 <= N <= 16384 (candidate rows padded to a multiple of 128) and 64 < k <= 128 -- the reference's own
+    # default shape is N = 7000, k = 80 (option_new.py:58, M4:544-550) -- and clouds stored cluster by cluster in rotation
+    ("normal", 64, 1100, 80, 80), ("relu", 64, 7000, 80, 80), ("clusters", 32, 1500, 100, 100), ("dups", 64, 1300, 128, 128),
+    ("normal", 128, 2000, 20, 100), ("blobs", 64, 4096, 64, 64), ("blobs", 64, 7000, 80, 80), ("flat", 64, 4096, 64, 64),
+    ("flat", 32, 3000, 80, 80)])
 def test_knn_feature_prefilter_matches_exact_kernel_and_oracle(dev, kind, C, N, k1, k2):
     """csrc/knn_filter.hip (bf16 matrix-core prefilter + exact f32 re-rank + exhaustive fallback) returns the SAME
     indices as the exact matrix-core kernel (csrc/knn.hip) and as the CPU oracle, whatever the data does to the
@@ -294,26 +306,31 @@ def test_knn_feature_prefilter_matches_exact_kernel_and_oracle(dev, kind, C, N, 
     x = _feature_cloud(kind, 2, C, N, 11 + C + N)
     xd = x.to(dev)
     assert _lib.lib().gcn_knn_feature_supported(2, N, C, k2) == 1
-    new = dgcnn.knn_feature_pm(xd.transpose(1, 2).contiguous(), k1, k2)
+    st = {}
+    new = dgcnn.knn_feature_pm(xd.transpose(1, 2).contiguous(), k1, k2, stats=st)
     old = dgcnn._knn_model(xd, k1, k2, 0)
     assert torch.equal(new, old)
     np.testing.assert_array_equal(new.cpu().numpy(), oracle.knn_model(x.numpy(), k1, k2, 0))
     assert torch.equal(dgcnn.knn(xd, k1, k2), old)                      # the drop-in entry takes the same path
-    fl, ca = ctypes.c_long(0), ctypes.c_long(0)
-    ws = dgcnn._KNN_WS[(2, N, C, xd.device)]
-    _lib.call("gcn_knn_feature_stats", _lib.ptr(ws), 2, N, C, ctypes.addressof(fl), ctypes.addressof(ca), _lib.stream_of(xd))
-    if kind in ("normal", "relu"):
-        assert fl.value <= 2, "the prefilter should prove (nearly) every query of well-spread data"
-        assert ca.value / (2 * N) < 6 * k2 + 64
+    print("%s C=%d N=%d k=%d: %d of %d queries flagged, %.0f candidates per query" % (kind, C, N, k2, st["flagged"], 2 * N, st["candidates"] / (2 * N)))
+    if kind in ("normal", "relu", "blobs", "flat", "clusters"):
+        # (a handful of queries per 10^4 miss the proof by a hair -- a sample order statistic at the low end of its
+        # spread -- and take the exhaustive stage; "clusters": the members of a cluster whose k-th neighbour sits in
+        # another cluster right at the threshold)
+        limit = 4 + N // 500 if kind != "clusters" else 2 * N // 50
+        assert st["flagged"] <= limit, "the prefilter should prove (nearly) every query of data it can resolve"
+        assert st["candidates"] / (2 * N) < 6 * k2 + 64
     if kind == "offset":
-        assert fl.value > 0, "this cloud is meant to exercise the exhaustive path"
+        assert st["flagged"] > 0, "this cloud is meant to exercise the exhaustive path"
 
 
 @pytest.mark.parametrize("kind,C,N,k1,k2,long_list", [
-    ("offset", 64, 4096, 16, 16, None),      # every query flagged, 8192 > the default list limit -> matrix-core search
-    ("offset", 32, 2048, 20, 20, 0), ("offset", 128, 1024, 64, 64, 0), ("halfoffset", 64, 2048, 8, 64, 0),
+    ("offset2", 64, 4096, 16, 16, None),     # every query flagged, 8192 > the default list limit -> matrix-core search
+    ("offset2", 32, 2048, 20, 20, 0), ("offset2", 128, 1024, 64, 64, 0), ("halfoffset", 64, 2048, 8, 64, 0),
     ("normal", 64, 1024, 16, 16, 0),         # nothing flagged: the gated kernels are no-ops
-    ("flat", 64, 8192, 64, 64, None)])
+    ("offset2", 64, 8192, 64, 64, None),     # the size bench.py runs
+    ("offset", 64, 2048, 64, 64, None),      # a few hundred flagged: the sliced short-list stage
+    ("offset2", 64, 1500, 80, 80, None), ("halfoffset", 32, 1100, 20, 100, None)])   # k > 64 / ragged N: the VALU selection kernel
 def test_knn_feature_long_fallback_list_runs_on_the_matrix_cores(dev, monkeypatch, kind, C, N, k1, k2, long_list):
     """Clouds whose neighbours sit closer than the bf16 prefilter resolves put (nearly) every query on the fallback
     list; beyond KNNF_LONG_LIST entries the list is searched by the exact f32 matrix-core kernel in its flagged mode
@@ -325,37 +342,36 @@ def test_knn_feature_long_fallback_list_runs_on_the_matrix_cores(dev, monkeypatc
         monkeypatch.setenv("GCANET_KNN_LONG_LIST", str(long_list))
     if kind == "halfoffset":                 # every other block of 24 points comes from the unresolvable cloud
         x = _feature_cloud("normal", 2, C, N, 5 + C + N)
-        y = _feature_cloud("offset", 2, C, N, 6 + C + N)
+        y = _feature_cloud("offset2", 2, C, N, 6 + C + N)
         sel = (torch.arange(N) // 24) % 2 == 0
-        x[:, :, sel] = y[:, :, sel] - 4.0 + 0.5
-    elif kind == "flat":                     # 64 patches of near-identical features (a CAD part's flat faces)
-        g = torch.Generator().manual_seed(77)
-        x = torch.randn(2, C, 64, generator=g)[:, :, torch.arange(N) % 64] + 1e-4 * torch.randn(2, C, N, generator=g)
+        x[:, :, sel] = y[:, :, sel] - 8.0 + 0.5
     else:
         x = _feature_cloud(kind, 2, C, N, 11 + C + N)
     xd = x.to(dev)
-    new = dgcnn.knn_feature_pm(xd.transpose(1, 2).contiguous(), k1, k2)
+    st = {}
+    new = dgcnn.knn_feature_pm(xd.transpose(1, 2).contiguous(), k1, k2, stats=st)
     old = dgcnn._knn_model(xd, k1, k2, 0)                   # the exact kernel, unflagged (itself checked against the oracle)
     assert torch.equal(new, old)
     if N <= 4096:
         np.testing.assert_array_equal(new.cpu().numpy(), oracle.knn_model(x.numpy(), k1, k2, 0))
-    fl, ca = ctypes.c_long(0), ctypes.c_long(0)
-    ws = dgcnn._KNN_WS[(2, N, C, xd.device)]
-    _lib.call("gcn_knn_feature_stats", _lib.ptr(ws), 2, N, C, ctypes.addressof(fl), ctypes.addressof(ca), _lib.stream_of(xd))
-    if kind in ("offset", "flat"):
-        assert fl.value > (4096 if long_list is None else N)
+    print("%s C=%d N=%d k=%d: %d of %d queries flagged" % (kind, C, N, k2, st["flagged"], 2 * N))
+    if kind == "offset2":
+        assert st["flagged"] > (4096 if long_list is None and N >= 4096 else N)
+    if kind == "offset":
+        assert 0 < st["flagged"] <= 4096
     if kind == "halfoffset":
-        assert 0 < fl.value < 2 * N
+        assert 0 < st["flagged"] < 2 * N
     if kind == "normal":
-        assert fl.value <= 2
+        assert st["flagged"] <= 2
 
 
 def test_knn_feature_unsupported_shapes_use_the_exact_kernel(dev):
     from gcanet_amd import _lib, dgcnn
     lib = _lib.lib()
-    assert lib.gcn_knn_feature_supported(2, 1000, 64, 16) == 0           # N % 128
-    assert lib.gcn_knn_feature_supported(2, 2048, 64, 80) == 0           # k > 64
+    assert lib.gcn_knn_feature_supported(2, 1000, 64, 16) == 0           # N < 1024
+    assert lib.gcn_knn_feature_supported(2, 2048, 64, 129) == 0          # k > 128
     assert lib.gcn_knn_feature_supported(2, 2048, 48, 16) == 0           # channel count
+    assert lib.gcn_knn_feature_supported(3, 7000, 64, 80) == 1           # the reference's default shape (option_new.py:58)
     assert dgcnn.knn_feature_pm(torch.randn(2, 1000, 64, device=dev), 16, 16) is None
     with pytest.raises(RuntimeError, match="unsupported shape"):
         idx = torch.empty(2, 1000, 16, dtype=torch.int64, device=dev)

@@ -41,9 +41,9 @@ def timed(fn, iters=10):
 ms_old, idx_old = timed(lambda: dgcnn._knn_model(x, k, k, 0))
 ms_new, idx_new = timed(lambda: dgcnn.knn_feature_pm(x_pm, k, k))
 same = torch.equal(idx_old, idx_new)
-ws = dgcnn._KNN_WS[(B, N, C, x_pm.device)]
-fl, ca = ctypes.c_long(0), ctypes.c_long(0)
-_lib.call("gcn_knn_feature_stats", _lib.ptr(ws), B, N, C, ctypes.addressof(fl), ctypes.addressof(ca), _lib.stream_of(x_pm))
+_st = {}
+dgcnn.knn_feature_pm(x_pm, k, k, stats=_st)
+fl, ca = ctypes.c_long(_st["flagged"]), ctypes.c_long(_st["candidates"])
 print("C=%d N=%d B=%d k=%d %s: exact kernel %.3f ms, prefilter path %.3f ms (%.2fx), identical=%s, fallback queries %d, "
       "candidates/query %.1f" % (C, N, B, k, kind, ms_old, ms_new, ms_old / ms_new, same, fl.value, ca.value / (B * N)))
 if not same:

@@ -16,6 +16,7 @@ clouds = {
     "uniform": torch.randn(B, N, C, generator=g),
     "flat patches": torch.randn(B, 64, C, generator=g)[:, torch.arange(N) % 64] + 1e-4 * torch.randn(B, N, C, generator=g),
     "offset": torch.randn(B, N, C, generator=g) * 0.05 + 4.0,
+    "blobs": torch.randn(B, 64, C, generator=g)[:, torch.arange(N) % 64] + 0.03 * torch.randn(B, N, C, generator=g),
 }
 for name, x in clouds.items():
     x = x.to(dev)
@@ -28,8 +29,8 @@ for name, x in clouds.items():
         idx = dgcnn.knn_feature_pm(x, k, k)
     e1.record()
     torch.cuda.synchronize()
-    fl, ca = ctypes.c_long(0), ctypes.c_long(0)
-    ws = dgcnn._KNN_WS[(B, N, C, x.device)]
-    _lib.call("gcn_knn_feature_stats", _lib.ptr(ws), B, N, C, ctypes.addressof(fl), ctypes.addressof(ca), _lib.stream_of(x))
+    _st = {}
+    dgcnn.knn_feature_pm(x, k, k, stats=_st)
+    fl, ca = ctypes.c_long(_st["flagged"]), ctypes.c_long(_st["candidates"])
     same = torch.equal(idx, dgcnn._knn_model(x.transpose(1, 2).contiguous(), k, k, 0))
     print("%-14s %7.3f ms  flagged %6d of %d  identical to the exact kernel: %s" % (name, e0.elapsed_time(e1) / 5, fl.value, B * N, same))
