@@ -562,7 +562,7 @@ GCN_EXPORT int gcn_bn_relu_fwd(int M, int C, const float *x, const float *gamma,
   GCN_REQUIRE(x && gamma && beta && y && mean_rstd && sums_ws, "gcn_bn_relu_fwd: null pointer");
   GCN_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "gcn_bn_relu_fwd: pass both running buffers or neither");
   hipStream_t st = (hipStream_t)stream;
-  GCN_HIP(hipMemsetAsync(sums_ws, 0, sizeof(double) * 2 * C, st));
+  GCN_HIP(zero_dev(sums_ws, sizeof(double) * 2 * C, st));          // skipped inside the pre-zeroed arena
   const int rows = 256;
   bn_stats_kernel<<<cdiv(M, rows), 256, 0, st>>>(M, C, rows, x, sums_ws);
   const int blocks = (int)fmin(4096.0, (double)cdiv((long)M * C / 4, 256));
@@ -577,7 +577,7 @@ GCN_EXPORT int gcn_bn_relu_bwd(int M, int C, const float *dy, const float *x, co
   if (rc) return rc;
   GCN_REQUIRE(dy && x && gamma && beta && mean_rstd && dx && dgamma && dbeta && acc_ws, "gcn_bn_relu_bwd: null pointer");
   hipStream_t st = (hipStream_t)stream;
-  GCN_HIP(hipMemsetAsync(acc_ws, 0, sizeof(double) * 2 * C, st));
+  GCN_HIP(zero_dev(acc_ws, sizeof(double) * 2 * C, st));
   const int rows = 256;
   bn_bwd_reduce_kernel<<<cdiv(M, rows), 256, 0, st>>>(M, C, rows, dy, x, mean_rstd, gamma, beta, relu, acc_ws);
   const int blocks = (int)fmin(4096.0, (double)cdiv((long)M * C / 4, 256));

@@ -37,7 +37,7 @@ class GCANet(nn.Module):
             proposals_idx = proposals_idx[:int(proposals_offset[-1])]
         feats = out["output_feats"].float().reshape(B * N, -1)
         vf, vc, shape, nb, inst_map = clusters_voxelization(proposals_idx, proposals_offset, feats, coords_float, scale=64,
-                                                            spatial_shape=64, rand_quantize=True, rand=rand)
+                                                            spatial_shape=64, rand_quantize=True, rand=rand, inp_map_on_device=True)
         inst = SparseConvTensor(vf, vc, shape, nb)
         instance_batch_idxs, cls_scores, iou_scores, mask_scores = self.instance_head(inst, inst_map.to(points.device))
         return (out["type_per_point"], out["param_per_point"], out["semantic_scores"], out["pt_offsets"],

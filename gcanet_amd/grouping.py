@@ -186,10 +186,12 @@ def forward_grouping_device(semantic_scores, pt_offsets, batch_idxs, coords_floa
 
 
 def clusters_voxelization(clusters_idx, clusters_offset, feats, coords, scale, spatial_shape, rand_quantize=False,
-                          rand=None):
+                          rand=None, inp_map_on_device=False):
     """M4:1300-1355.  clusters_idx (S,2) int32 CPU, clusters_offset (P+1) int32 CPU, feats (M,C) cuda, coords (M,3)
     cuda.  Returns (voxel_feats (V,C) cuda, voxel_coords (V,4) int32 cuda, [spatial_shape]*3, batch_size, inp_map).
-    `rand` (two (3,) tensors) replaces the reference's torch.rand(3) draws to make tests reproducible."""
+    `rand` (two (3,) tensors) replaces the reference's torch.rand(3) draws to make tests reproducible.
+    inp_map_on_device: keep inp_map where it was computed (the reference returns it on the CPU, M4:1352, and its caller
+    moves it straight back, M4:771: a blocking round trip per step)."""
     dev = feats.device
     if clusters_idx.size(0) == 0:
         c = torch.tensor([[0, 0, 0, 0], [0, spatial_shape - 1, spatial_shape - 1, spatial_shape - 1]], dtype=torch.int,
@@ -197,8 +199,8 @@ def clusters_voxelization(clusters_idx, clusters_offset, feats, coords, scale, s
         return feats[0:2], c, [spatial_shape] * 3, 1, feats.new_zeros((1,), dtype=torch.long)
     batch_idx = clusters_idx[:, 0].to(dev).long()
     c_idxs = clusters_idx[:, 1].to(dev).long()
-    feats = feats[c_idxs].float().contiguous()
-    coords = coords[c_idxs].float().contiguous()
+    feats = feats.index_select(0, c_idxs).float().contiguous()      # backward = one index_add (advanced indexing: ~250 us)
+    coords = coords.index_select(0, c_idxs).float().contiguous()
     offs = clusters_offset.to(dev).int().contiguous()
     coords_min = sec_min(coords, offs)
     coords_max = sec_max(coords, offs)
@@ -213,15 +215,18 @@ def clusters_voxelization(clusters_idx, clusters_offset, feats, coords, scale, s
         coords_min = coords_min - torch.clamp(spatial_shape - rng - 0.001, min=0) * r1.to(dev)
         coords_min = coords_min - torch.clamp(spatial_shape - rng + 0.001, max=0) * r2.to(dev)
     coords = coords - coords_min[batch_idx]
-    assert coords.shape.numel() == int(((coords >= 0) * (coords < spatial_shape)).sum())
-    nb = int(clusters_idx[-1, 0]) + 1
+    if coords.is_cuda:                       # M4:1343's assert, checked on the device: no host synchronisation
+        torch._assert_async(((coords >= 0) & (coords < spatial_shape)).all())
+    else:
+        assert coords.shape.numel() == int(((coords >= 0) * (coords < spatial_shape)).sum())
+    nb = int(clusters_offset.shape[0]) - 1   # proposals are numbered 0..P-1 in order: == clusters_idx[-1, 0] + 1, no read-back
     if nb <= 65536 and spatial_shape <= 65536:
         # device voxelize_idx (csrc/voxelize_dev.hip): no .cpu() round trip of the coordinates; inp_map is returned
         # on the CPU as the reference does (M4:1352)
         coords = torch.cat([batch_idx.view(-1, 1), coords.long()], 1).contiguous()
         out_coords, inp_map, out_map = voxelization_idx(coords, nb)
         out_feats = voxelization(feats, out_map)
-        return out_feats, out_coords.int(), [spatial_shape] * 3, nb, inp_map.cpu()
+        return out_feats, out_coords.int(), [spatial_shape] * 3, nb, (inp_map if inp_map_on_device else inp_map.cpu())
     coords = torch.cat([clusters_idx[:, 0].view(-1, 1).long(), coords.long().cpu()], 1).contiguous()
     out_coords, inp_map, out_map = voxelization_idx(coords, nb)
     out_feats = voxelization(feats, out_map.to(dev))

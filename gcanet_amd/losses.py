@@ -25,7 +25,7 @@ def compute_embedding_loss(pred_feat, gt_label, t_pull=0.5, t_push=1.5):
     cnt = torch.zeros(B * L, device=dev, dtype=f.dtype).index_add_(0, seg, torch.ones_like(seg, dtype=f.dtype))
     present = cnt > 0
     centers = torch.zeros(B * L, K, device=dev, dtype=f.dtype).index_add_(0, seg, f) / cnt.clamp(min=1).unsqueeze(1)
-    dis = F.relu(torch.norm(f - centers[seg], 2, dim=1) - t_pull)
+    dis = F.relu(torch.norm(f - centers.index_select(0, seg), 2, dim=1) - t_pull)   # index_select: backward = one index_add
     seg_mean = torch.zeros(B * L, device=dev, dtype=f.dtype).index_add_(0, seg, dis) / cnt.clamp(min=1)
     npres = present.view(B, L).sum(1).to(f.dtype)                               # labels present per cloud (>= 1)
     pull = ((seg_mean * present).view(B, L).sum(1) / npres).sum() / B

@@ -18,6 +18,7 @@ import torch
 from torch import nn
 
 from . import _lib
+from .layers import zeroed_like
 
 
 def _call(name, like, *args):
@@ -133,7 +134,7 @@ class BatchNormReLUFunction(torch.autograd.Function):
         ga, be = gamma.float().contiguous(), beta.float().contiguous()
         y = torch.empty_like(x)
         mean_rstd = torch.empty(C, 2, dtype=torch.float32, device=x.device)
-        ws = torch.empty(2 * C, dtype=torch.float64, device=x.device)
+        ws = zeroed_like((2 * C,), torch.float64, x.device)          # call-local accumulators: from the step's pre-zeroed arena
         _call("gcn_bn_relu_fwd", x, M, C, _lib.ptr(x), _lib.ptr(ga), _lib.ptr(be), float(eps), int(relu), float(momentum),
               _lib.ptr(y), _lib.ptr(mean_rstd), _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(ws))
         ctx.save_for_backward(x, ga, be, mean_rstd)
@@ -147,7 +148,7 @@ class BatchNormReLUFunction(torch.autograd.Function):
         dy = dy.float().contiguous()
         dx = torch.empty_like(x)
         dgamma, dbeta = torch.empty(C, device=x.device), torch.empty(C, device=x.device)
-        ws = torch.empty(2 * C, dtype=torch.float64, device=x.device)
+        ws = zeroed_like((2 * C,), torch.float64, x.device)
         _call("gcn_bn_relu_bwd", x, M, C, _lib.ptr(dy), _lib.ptr(x), _lib.ptr(ga), _lib.ptr(be), _lib.ptr(mean_rstd), ctx.relu,
               _lib.ptr(dx), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ws))
         return dx, dgamma, dbeta, None, None, None, None, None
@@ -324,7 +325,7 @@ class InstanceHead(nn.Module):
     def forward(self, inst_feats: SparseConvTensor, inst_map):
         from .grouping import global_pool
         feats = self.tiny_unet_outputlayer(self.tiny_unet(inst_feats))
-        mask_scores = self.mask_linear(feats.features)[inst_map.long()]
+        mask_scores = self.mask_linear(feats.features).index_select(0, inst_map.long())   # backward = one index_add
         instance_batch_idxs = feats.indices[:, 0][inst_map.long()]
         pooled = global_pool(feats.features, feats.indices[:, 0])
         return instance_batch_idxs, self.cls_linear(pooled), self.iou_score_linear(pooled), mask_scores
