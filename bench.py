@@ -138,28 +138,38 @@ def kernel_model(tag):
     import re
     kv = {k: int(v) for k, v in re.findall(r"(\w+)=(\d+)", tag)}
     if tag.startswith("knn_model"):
-        # 2*B*N^2*C distance FLOPs (exact f32); f32 vector/MFMA peak is the honest ceiling
-        return dict(flops=2.0 * kv["B"] * kv["N"] ** 2 * kv["C"], bound="mfma", peak=PEAK_TFLOPS["f32_mfma"])
+        # 2*B*N^2*C distance FLOPs (exact f32); f32 vector/MFMA peak is the honest ceiling.  What the entry
+        # point EXECUTES since round 2 (feature space, C >= 32): a bf16 MFMA filter over all pairs (Cp + 16 deep: the
+        # threshold rides in an extra k-step) + the same over a 1-in-8 sample + ~200 exact f32 keys per query
+        B, N, C = kv["B"], kv["N"], kv["C"]
+        m = dict(flops=2.0 * B * N ** 2 * C, bound="mfma", peak=PEAK_TFLOPS["f32_mfma"])
+        if C >= 32:
+            Np = (N + 127) // 128 * 128
+            m["executed_flops"] = 2.0 * B * Np * Np * (C + 16) + 2.0 * B * Np * (N // 8) * C
+            m["executed_peak"] = PEAK_TFLOPS["bf16_mfma"]
+        return m
     if tag.startswith("edgeconv_fwd"):
-        # grouped (N*k, 2C) x (2C, Cout) contraction on bf16 MFMA
-        return dict(flops=2.0 * kv["B"] * kv["N"] * kv["k"] * 2 * kv["C"] * kv["Cout"], bound="mfma",
-                    peak=PEAK_TFLOPS["bf16_mfma"])
+        # grouped (N*k, 2C) x (2C, Cout) contraction on bf16 MFMA; executed: the centre half once per point, not per edge
+        m = dict(flops=2.0 * kv["B"] * kv["N"] * kv["k"] * 2 * kv["C"] * kv["Cout"], bound="mfma", peak=PEAK_TFLOPS["bf16_mfma"])
+        m["executed_flops"] = 2.0 * kv["B"] * kv["N"] * (kv["k"] + 1) * kv["C"] * kv["Cout"]
+        m["executed_peak"] = PEAK_TFLOPS["bf16_mfma"]
+        return m
     return None
 
 
 def pmc_traffic(tag):
     """HBM bytes per call of the entry point behind `tag` (all the kernels it launches, summed), from the committed
-    rocprofv3 PMC passes of this same command (profiles/r02_pmc_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE
+    rocprofv3 PMC passes of this same command (profiles/r03_pmc_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE
     runs, gfx950 read correction applied; tools/pmc_traffic.py).  Counters cannot be read from inside the process,
     hence the file; null if absent or if the profile was taken at another shape."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
     if not os.path.exists(path) or "B=8" not in tag or "N=8192" not in tag:
         return None
     ks = json.load(open(path))["kernels"]
     parts = {
         "knn_model[B=8,C=64": ["gcn::knnf_colsum_kernel", "gcn::knnf_prep_kernel", "gcn::knnf_stream_kernel<4, 0>",
                                "gcn::knnf_stream_kernel<4, 1>", "gcn::knnf_keys_kernel<64>", "gcn::knnf_rank_kernel<64>",
-                               "gcn::knnf_list_kernel", "gcn::knnf_fallback_kernel<64>", "gcn::knnf_transpose_kernel",
+                               "gcn::knnf_list_kernel", "gcn::knnf_fallback_kernel<64>", "gcn::knnf_fallback_merge_kernel", "gcn::knnf_transpose_kernel",
                                "gcn::knn_mfma16_kernel<64, 64, 1, true>"],
         "knn_model[B=8,C=6,": ["gcn::knnn_prep_kernel", "gcn::knnn_sample_kernel", "gcn::knnn_filter_kernel",
                                "gcn::knnn_rerank_kernel"],
@@ -235,7 +245,7 @@ def full_workload(args, dev, steps=5, warmup=2):
     from gcanet_amd.losses import compute_embedding_loss, instance_loss
     B, N, k = args.batch, args.points, args.k
     torch.manual_seed(0)
-    net = GCANet(nn_nb=k, dtype="bf16", grouping_cfg=dict(similarity_threshold_inst=0.0, min_npoint=30)).to(dev)
+    net = GCANet(nn_nb=k, dtype="bf16", grouping_cfg=GROUPING_CFG).to(dev)
     opt = torch.optim.Adam(net.parameters(), lr=1e-3, fused=True)
     casts = CastCache(net.point_net, pad_k={net.point_net.conv3.weight: (net.point_net.conv3.weight.shape[1] + 15) // 16 * 16})
     pts, nrm, lab = blob_clouds(range(B), N, dev)
@@ -401,24 +411,29 @@ def north_star_rooflines(dev, B=8, N=8192, k=64, C=128):
     return {"knn_gather": knn_gather, "grouped_mlp": grouped_mlp}
 
 
-def grouping_times(model, pts, nrm, reps=5):
+GROUPING_CFG = dict(similarity_threshold_inst=0.0, min_npoint=30)     # what lets random-init predictions form proposals
+
+
+def grouping_times(model, B, N, dev, reps=5):
     """forward_grouping (M4:737, the stage right after the timed step) on the model's own
-    predictions for this batch: the fused device path vs the literal per-(cloud, class) path.  Reported beside the
-    headline number, never part of it."""
+    predictions for a batch of BLOB clouds (bench.blob_clouds, the clouds of `full_workload`: with random-init weights
+    uniform clouds produce no proposal at all, and a comparison of two empty lists says nothing): the fused device path
+    vs the literal per-(cloud, class) path, which must return identical proposals.  Reported beside the headline number,
+    never part of it."""
     from gcanet_amd.grouping import forward_grouping, forward_grouping_device
+    pts, nrm, _ = blob_clouds(range(B), N, dev)
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
         out = model(pts, nrm)
-    B, N = pts.shape[:2]
     args = (out["semantic_scores"].float(), out["pt_offsets"].float(),
             torch.arange(B, device=pts.device).repeat_interleave(N), pts.reshape(-1, 3), out["type_per_point"],
             out["param_per_point"].float(), out["output_feats"].float())
     res = {}
     for name, fn, r in (("device_ms", forward_grouping_device, reps), ("literal_ms", forward_grouping, 2)):
-        pi, po = fn(*args)
+        pi, po = fn(*args, **GROUPING_CFG)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(r):
-            pi, po = fn(*args)
+            pi, po = fn(*args, **GROUPING_CFG)
         torch.cuda.synchronize()
         res[name] = round((time.perf_counter() - t0) / r * 1e3, 3)
         res.setdefault("proposals", int(po.numel()) - 1 if po.numel() else 0)
@@ -427,7 +442,8 @@ def grouping_times(model, pts, nrm, reps=5):
             dev_out = (pi, po)
         else:
             res["identical"] = bool(torch.equal(dev_out[0], pi) and torch.equal(dev_out[1], po))
-    res["note"] = "forward_grouping on this batch's predictions (random-init weights), outside the timed step"
+    res["note"] = ("forward_grouping on %d blob clouds with this model's predictions (random-init weights, thresholds %s), "
+                   "outside the timed step" % (B, GROUPING_CFG))
     return res
 
 
@@ -580,12 +596,18 @@ def main():
         roofline = {"kernel": tag, "bound": km["bound"], "achieved": round(ach, 2), "peak": km["peak"],
                     "unit": "TFLOP/s", "frac": round(ach / km["peak"], 4), "traffic": pmc_traffic(tag),
                     "avg_launch_ms": round(avg_ms, 4), "launches_per_step": n / timed_steps}
+        if "executed_flops" in km:       # the matrix-core work the entry point really issues, against ITS peak
+            ex = km["executed_flops"] / avg_ms / 1e9
+            roofline.update(executed_tflops=round(ex, 1), executed_peak=km["executed_peak"],
+                            executed_frac=round(ex / km["executed_peak"], 4))
         if tag.startswith("knn_model"):
             # since round 2 the N^2 part of this entry point is a FILTER (bf16 MFMA for feature space, packed f32 VALU
             # for xyz+normal) and only ~3k survivors per query get the exact f32 arithmetic: `achieved` stays the
             # algorithmic 2*B*N^2*C f32 FLOPs of SURVEY 8d over the entry point's whole duration (all its kernels)
-            roofline["note"] = ("algorithmic exact-f32 distance FLOPs / time of the whole entry point (prep + threshold + "
-                                "filter + exact re-rank kernels); the N^2 pass itself runs as a bf16-MFMA / packed-f32 filter")
+            roofline["note"] = ("`achieved`/`frac`: ALGORITHMIC exact-f32 distance FLOPs (SURVEY 8d) / time of the whole entry "
+                                "point (prep + threshold + filter + exact re-rank kernels) against the f32 peak -- an "
+                                "algorithmic-equivalent speed, not a utilisation (it can exceed 1); the N^2 pass runs as a "
+                                "bf16-MFMA filter: `executed_*` prices that against the bf16 peak")
     knn_ms = sum(tot for tag, (n, tot) in timing.items() if tag.startswith("knn_model")) / timed_steps
     res = {
         "metric": "point-clouds/sec fwd+bwd (N=%d,k=%d)" % (N, args.k), "value": round(clouds_per_s, 3),
@@ -607,7 +629,7 @@ def main():
     if world == 1 and not args.no_full:
         res["full_workload"] = full_workload(args, dev)
     if world == 1 and not args.no_cpu_baseline:
-        res["forward_grouping"] = grouping_times(model, pts, nrm)
+        res["forward_grouping"] = grouping_times(model, B, N, dev)
         res["cpu_baseline"] = cpu_baseline(N, args.k)
     print(json.dumps(res))
     if world > 1:

@@ -1215,7 +1215,8 @@ GCN_EXPORT int gcn_edgeconv_fwd(const void *x_pm, const void *w, const int64_t *
   GCN_REQUIRE(Cout == 64 || Cout == 128, "gcn_edgeconv_fwd(bf16): Cout must be 64 or 128, got %d", Cout);
   GCN_REQUIRE((Cout / G) % 32 == 0, "gcn_edgeconv_fwd(bf16): Cout/G must be a multiple of 32");
   const int Cp = padded_channels(C);
-  GCN_REQUIRE(Cp <= 128, "gcn_edgeconv_fwd(bf16): C=%d > 128 unsupported", C);
+  GCN_REQUIRE(Cp <= 128 || (Cp == 256 && Cout == 128 && (k + 31) / 32 * 32 <= 128),
+              "gcn_edgeconv_fwd(bf16): C=%d unsupported (C <= 128, or C <= 256 with Cout == 128 and k <= 128)", C);
   EcArgs a{};
   a.x = (const unsigned short *)x_pm; a.wp = (const unsigned short *)w; a.idx = idx;
   a.B = B; a.N = N; a.NX = NX; a.k = k; a.kp = (k + 31) / 32 * 32; a.Cout = Cout; a.G = G;

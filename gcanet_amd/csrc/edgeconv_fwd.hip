@@ -1,6 +1,7 @@
 // edgeconv_fwd.hip -- the grouped (N*k, 2C) x (2C, Cout) contraction of the DGCNN EdgeConv block
 // (get_graph_feature M4:93-124 + Conv2d 1x1 + the statistics/extreme half of GroupNorm + LeakyReLU + max over k,
-// models/dgcnn-hais-concat-direct-4.py:463-505) for gfx950, bf16 MFMA, k <= 128.
+// models/dgcnn-hais-concat-direct-4.py:463-505) for gfx950, bf16 MFMA, k <= 128, up to 256 input channels (BASELINE
+// configs[4] names C = 256: KS = 16 k-steps, a 64-KB tile per buffer, one workgroup per CU).
 //
 // Formulation.  The reference's row is e = [x_j - x_i ; x_i] with W = [W1 | W2]:  y[n,j] = W1.x_j + (W2 - W1).x_i.
 // The centre term q[n] = (W2 - W1).x_n is the same for the k rows of a point, so it is contracted ONCE per point
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(256) void edgeconv_center_kernel(const unsigned sho
 // ------------------------------------------------------------------ grouped contraction
 // KS = Cp/16 k-steps, CW = Cout/32 waves, NB = KP/32 accumulator blocks per point (1, 2, 3, 4).
 template <int KS, int CW, int NB, bool KEXACT, bool WITH_ARG, bool ROUTED>
-__global__ __launch_bounds__(64 * CW, 2) void edgeconv_fwd_q_kernel(EcqArgs a) {
+__global__ __launch_bounds__(64 * CW, KS > 8 ? 1 : 2) void edgeconv_fwd_q_kernel(EcqArgs a) {
   constexpr int CP = KS * 16;
   constexpr int NC = 2 * KS;               // 16-B chunks per x row
   constexpr int ROW_BYTES = CP * 2;
@@ -460,7 +461,7 @@ int launch_edgeconv_fwd_q(EcqArgs &a, int Cp, bool with_arg, hipStream_t st) {
 #define ECQ_CASE(KSV, CWV) \
   if (ks == KSV && a.Cout == CWV * 32) return launch_q<KSV, CWV>(a, with_arg, st);
   ECQ_CASE(1, 2) ECQ_CASE(2, 2) ECQ_CASE(4, 2) ECQ_CASE(8, 2)
-  ECQ_CASE(1, 4) ECQ_CASE(2, 4) ECQ_CASE(4, 4) ECQ_CASE(8, 4)
+  ECQ_CASE(1, 4) ECQ_CASE(2, 4) ECQ_CASE(4, 4) ECQ_CASE(8, 4) ECQ_CASE(16, 4)
 #undef ECQ_CASE
   set_error("gcn_edgeconv_fwd(bf16): unsupported configuration Cp=%d Cout=%d", Cp, a.Cout);
   return GCN_EINVAL;
@@ -473,7 +474,7 @@ using namespace gcn;
 GCN_EXPORT int gcn_edgeconv_center(const void *x_pm_bf16, const void *wp_bf16, long rows, int C, int Cout, float *q,
                                    void *stream) {
   GCN_REQUIRE(x_pm_bf16 && wp_bf16 && q, "gcn_edgeconv_center: null pointer");
-  GCN_REQUIRE(rows >= 0 && C >= 1 && C <= 128, "gcn_edgeconv_center: bad shape (C <= 128)");
+  GCN_REQUIRE(rows >= 0 && C >= 1 && C <= 256, "gcn_edgeconv_center: bad shape (C <= 256)");
   GCN_REQUIRE(Cout == 64 || Cout == 128, "gcn_edgeconv_center: Cout must be 64 or 128, got %d", Cout);
   if (rows == 0) return GCN_OK;
   int Cp = 16;
@@ -488,7 +489,7 @@ GCN_EXPORT int gcn_edgeconv_center(const void *x_pm_bf16, const void *wp_bf16, l
     return check_launch("edgeconv_center_kernel");                                                                 \
   }
   ECC_CASE(1, 2) ECC_CASE(2, 2) ECC_CASE(4, 2) ECC_CASE(8, 2)
-  ECC_CASE(1, 4) ECC_CASE(2, 4) ECC_CASE(4, 4) ECC_CASE(8, 4)
+  ECC_CASE(1, 4) ECC_CASE(2, 4) ECC_CASE(4, 4) ECC_CASE(8, 4) ECC_CASE(16, 4)
 #undef ECC_CASE
   set_error("gcn_edgeconv_center: unsupported configuration");
   return GCN_EINVAL;

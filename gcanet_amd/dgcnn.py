@@ -96,10 +96,11 @@ def _run(name, like, *args, tag=None):
 
 def _edgeconv_dtype(dtype, C, Cout, groups):
     """The kernel that serves this layer: the bf16 matrix-core kernel needs Cout in {64,128}, (Cout/groups) % 32 == 0 and
-    at most 128 (padded) input channels; any other width (M4:493-505 takes arbitrary channels) runs on the exact f32
-    kernel -- same op, same signature, no error."""
+    at most 128 (padded) input channels -- 256 with Cout == 128 (BASELINE configs[4]); any other width (M4:493-505 takes
+    arbitrary channels) runs on the exact f32 kernel -- same op, same signature, no error."""
+    Cp = _lib.lib().gcn_edgeconv_padded_channels(C)
     if dtype == "bf16" and not (Cout in (64, 128) and (Cout // groups) % 32 == 0 and Cout % groups == 0
-                                and _lib.lib().gcn_edgeconv_padded_channels(C) <= 128):
+                                and (Cp <= 128 or (Cp == 256 and Cout == 128))):
         return "f32"
     return dtype
 

@@ -176,6 +176,43 @@ def test_edgeconv_full_size_backward(dev, dtype):
             assert float((picked - ext).abs().max()) < 1e-5, "device arg is not a (near-)tie of the exact extreme"
 
 
+@pytest.mark.parametrize("n,k", [(2048, 20), (16384, 64)])
+def test_edgeconv_c256_on_matrix_cores(dev, n, k):
+    """BASELINE configs[4] names C = 256 (N = 16384, k = 64): a 256 -> 128 EdgeConv block runs on the bf16 matrix-core
+    kernel (KS = 16 k-steps; round 2 sent C > 128 to the exact f32 VALU kernel).  Forward on identical pre-rounded
+    operands vs the oracle at 1e-4; backward (closed form, generic-width path) vs the oracle's autograd at the small size."""
+    from gcanet_amd import _lib, dgcnn
+    C, Cout = 256, 128
+    g = torch.Generator().manual_seed(n + k)
+    x = _bf(torch.randn(1, C, n, generator=g))
+    w = torch.randn(Cout, 2 * C, generator=g) / (2 * C) ** 0.5
+    w1, wd = _bf(w[:, :C]), _bf(w[:, C:] - w[:, :C])
+    w = torch.cat([w1, wd + w1], 1)
+    gamma, beta = torch.randn(Cout, generator=g), torch.randn(Cout, generator=g) * 0.1
+    assert dgcnn._edgeconv_dtype("bf16", C, Cout, 2) == "bf16"
+    xd = x.to(dev)
+    idx = dgcnn._knn_model(xd[:, :64].contiguous(), k, k, 0)           # any valid neighbour lists
+    ref = R.edgeconv_block(x, idx.cpu(), w, gamma, beta, 2)
+    out = dgcnn.edgeconv_forward_raw(xd, idx, w.to(dev), gamma.to(dev), beta.to(dev), 2, "bf16")["out"].cpu()
+    _close(out, ref, what="bf16 C=256 N=%d" % n)
+    f32 = dgcnn.edgeconv_forward_raw(xd, idx, w.to(dev), gamma.to(dev), beta.to(dev), 2, "f32")["out"].cpu()
+    _close(f32, ref, what="f32 C=256 N=%d" % n)
+    if n > 4096:
+        return
+    leaves = [v.clone().requires_grad_() for v in (x, w, gamma, beta)]
+    gout = torch.randn(1, Cout, n, generator=g)
+    R.edgeconv_block(leaves[0], idx.cpu(), leaves[1], leaves[2], leaves[3], 2).mul(gout).sum().backward()
+    dl = [v.clone().to(dev).requires_grad_() for v in (x, w, gamma, beta)]
+    (dgcnn.edge_conv(dl[0], idx, dl[1], dl[2], dl[3], 2, "bf16") * gout.to(dev)).sum().backward()
+    for a, b, name in zip(dl, leaves, ("dx", "dw", "dgamma", "dbeta")):
+        refg, got = b.grad.numpy(), a.grad.cpu().numpy()
+        if name == "dx":        # near-tie max-k flips between the two summation orders move single contributions (see above)
+            tol = 1e-4 * np.abs(refg).max() + 1e-4 * np.abs(refg)
+            assert (np.abs(got - refg) > tol).mean() < 2e-4
+            continue
+        _close(got, refg, rtol=1e-4, atol=1e-4 * np.abs(refg).max(), what=name)
+
+
 def test_cfg1_edgeconv_forward(dev):
     """BASELINE configs[0] shape: 1 cloud N=2048, k=16, C=64 (EdgeConv 128->64 + GroupNorm(2) + LeakyReLU + max-k),
     kNN in feature space included: indices exact, features 1e-4."""
