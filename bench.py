@@ -529,7 +529,11 @@ def main():
     # step otherwise, about as long as the GPU needs to execute them.  Multi-rank runs launch every kernel from the host
     # (the heads' RCCL all-reduce is started from a backward hook and overlaps the encoder's backward); see DESIGN.md
     # section 6 for what was observed with a captured step followed by an eager all-reduce.
-    use_graph = world == 1 and not args.no_graph
+    # (tests/test_parallel_gpu.py captures the whole multi-rank step incl. its RCCL all-reduces on a 1-rank group and
+    # replays it correctly; GCANET_GRAPH_MULTIRANK=1 opts a multi-rank run into that mode.  It is not the default: with
+    # the packet-capture fast path off a replay costs the host about as much as the eager launches, see the top of
+    # this file, so there is nothing to gain and an unrehearsed N-rank capture to lose.)
+    use_graph = (world == 1 or os.environ.get("GCANET_GRAPH_MULTIRANK") == "1") and not args.no_graph
     B, N = args.batch, args.points
     pts, nrm = synth_clouds(range(rank * B, rank * B + B), N, dev)
     st = make_step(model, pts, nrm, world)
@@ -569,10 +573,25 @@ def main():
     torch.cuda.synchronize()
     timing = _lib.timing_results()
     _lib.enable_timing(False)
+    coll = None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
+        # the collective on its own: the flat fp32 gradient, all-reduced as the step does it (untimed region)
+        buf = torch.zeros_like(dp.flat)
+        for _ in range(2):
+            torch.distributed.all_reduce(buf)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            torch.distributed.all_reduce(buf)
+        e1.record()
+        torch.cuda.synchronize()
+        coll = {"rccl_ranks": torch.distributed.get_world_size(), "backend": torch.distributed.get_backend(),
+                "allreduce_bytes": int(buf.numel() * 4), "allreduce_ms": round(e0.elapsed_time(e1) / 5, 4),
+                "segments": "heads %d B (async, from inside backward) + encoder %d B" % (dp.split * 4, (buf.numel() - dp.split) * 4)}
     if rank != 0:
         if world > 1:
             torch.distributed.destroy_process_group()
@@ -624,6 +643,8 @@ def main():
         "knn_mpts_per_s": round(3 * B * N / knn_ms / 1e3, 2) if knn_ms > 0 else None,
         "roofline": roofline, "kernels": kernels, "loss": float(loss.detach()),
     }
+    if coll is not None:
+        res["collective"] = coll
     if world == 1:
         res["north_star"] = north_star_rooflines(dev)
     if world == 1 and not args.no_full:

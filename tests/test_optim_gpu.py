@@ -27,6 +27,6 @@ def test_flat_adam_matches_torch_adam(dev, wd):
         mine.step()
         theirs.step()
         for p, q in zip(mod, ref):
-            assert torch.allclose(p, q, rtol=2e-6, atol=2e-7), (step, (p - q).abs().max().item())
+            assert torch.allclose(p, q, rtol=1e-6, atol=1e-7), (step, (p - q).abs().max().item())   # bias corrections in double, as torch
     assert float(mine.state[0]) == 6.0
     assert all(p.data_ptr() >= mine.flat_p.data_ptr() for p in mod)      # parameters are views of the flat buffer
