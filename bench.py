@@ -288,6 +288,66 @@ def full_workload(args, dev, steps=5, warmup=2):
             "proposals": info.get("proposals"), "members": info.get("members"), "loss": info.get("loss")}
 
 
+def cfg5_workload(dev, B=4, N=16384, k=64, steps=3, warmup=2):
+    """Third workload: BASELINE configs[4] on ONE GPU's share (16 clouds over 4 GPUs = 4 clouds, N=16384, k=64, C=256,
+    attention in IEEE half): the hot path (M4:634-747) + a 256 -> 128 EdgeConv block on the encoder's 256-wide per-point
+    features (the C=256 matrix-core kernel) + one pre-norm Transformer layer over each cloud's 16384 tokens
+    (models/transformer.py:36-91, dim 256, 8 heads, fp16 flash attention forward and backward) + a two-layer QueryDecoder
+    (models/query_decoder.py:104-239: 100 queries cross-attending 16384 points per cloud), forward + backward + Adam.
+    The reference defines no model that joins these (its GCANet uses neither attention stack); the pieces and shapes are
+    the configuration's.  Reported beside the headline number, never part of it."""
+    from gcanet_amd import dgcnn
+    from gcanet_amd.layers import CastCache
+    from gcanet_amd.query_decoder import QueryDecoder
+    from gcanet_amd.transformer import Transformer
+    torch.manual_seed(0)
+    net = dgcnn.PrimitivesEmbeddingDGCNGn(nn_nb=k, dtype="bf16").to(dev)
+    net.keep_xf = True
+    wide = dgcnn._EdgeConvLayer(512, 128, torch.nn.GroupNorm(2, 128)).to(dev)
+    tr = Transformer(dim=256, depth=1, heads=8, dim_head=32, mlp_dim=512, dropout=0.0, precision="fp16").to(dev)
+    qd = QueryDecoder(num_layer=2, num_query=100, num_class=10, in_channel=256, d_model=256, nhead=8, hidden_dim=512,
+                      precision="fp16").to(dev)
+    params = [p for m_ in (net, wide, tr, qd) for p in m_.parameters()]
+    opt = torch.optim.Adam(params, lr=1e-3, fused=True)
+    casts = CastCache(net, pad_k={net.conv3.weight: (net.conv3.weight.shape[1] + 15) // 16 * 16})
+    pts, nrm = synth_clouds(range(B), N, dev)
+    offs = [i * N for i in range(B + 1)]
+    info = {}
+
+    def step():
+        from gcanet_amd.layers import ZeroArena
+        if ZeroArena.live is not None:
+            ZeroArena.live.begin_step()
+        opt.zero_grad(set_to_none=True)
+        casts.refresh()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = net(pts, nrm)
+            xf = net.last_xf                                                       # (B,N,256)
+            gn = wide._modules["1"]
+            xw, _ = dgcnn.edge_conv_pm(xf.float(), net.encoder.last_idx[2], wide._modules["0"].weight, gn, "bf16", want_cm=False)
+        tok = tr(xf.float())                                                       # (B,N,256), attention in fp16
+        dec = qd(tok.reshape(B * N, 256), offs)
+        loss = loss_of(out) + xw.pow(2).mean() + tok.pow(2).mean() + dec["labels"].pow(2).mean() \
+            + dec["scores"].pow(2).mean() + dec["parameters"].pow(2).mean() + sum(m_.pow(2).mean() for m_ in dec["masks"]) / B
+        loss.backward()
+        opt.step()
+        info["loss"] = loss.detach()
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"workload": "BASELINE configs[4], one GPU's share: %d clouds N=%d k=%d: hot path + EdgeConv 256->128 (bf16 MFMA) + "
+                        "Transformer layer (dim 256, 8 heads, fp16 flash attention) + QueryDecoder (2 layers, 100 queries), "
+                        "fwd+bwd+Adam, eager launches" % (B, N, k),
+            "ms_per_step": round(dt * 1e3, 3), "clouds_per_s": round(B / dt, 2), "steps": steps, "warmup": warmup,
+            "loss": float(info["loss"]), "finite": bool(torch.isfinite(info["loss"]))}
+
+
 def make_step(model, pts, nrm, world=1, lr=1e-3):
     """The training step bench.py times, as one closure (tests/test_step_parity_gpu.py runs exactly this):
     zero_grad -> arena.begin_step -> one multi-tensor bf16 weight cast -> forward under bf16 autocast -> synthetic
@@ -649,6 +709,7 @@ def main():
         res["north_star"] = north_star_rooflines(dev)
     if world == 1 and not args.no_full:
         res["full_workload"] = full_workload(args, dev)
+        res["cfg5_workload"] = cfg5_workload(dev)
     if world == 1 and not args.no_cpu_baseline:
         res["forward_grouping"] = grouping_times(model, B, N, dev)
         res["cpu_baseline"] = cpu_baseline(N, args.k)

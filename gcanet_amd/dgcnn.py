@@ -823,6 +823,8 @@ class PrimitivesEmbeddingDGCNGn(nn.Module):
         self.mlp_param_prob1, self.mlp_param_prob2 = nn.Conv1d(256, 256, 1), nn.Conv1d(256, 22, 1)
         self.bn_param_prob1 = nn.GroupNorm(4, 256)
         self.logsoftmax = nn.LogSoftmax(dim=1)
+        self.keep_xf = False           # True: keep the encoder's (B,N,256) per-point features (with their graph) in `last_xf`
+        self.last_xf = None
 
     @staticmethod
     def _unit(v):
@@ -839,6 +841,8 @@ class PrimitivesEmbeddingDGCNGn(nn.Module):
         pts = torch.cat([points, normals], dim=-1).contiguous() if self.mode == 5 else points.contiguous()   # (B,N,6)
         pts_cm = pts.transpose(1, 2).contiguous()
         xf, x4 = self.encoder.forward_pm(pts_cm, pts, idxs=idxs)
+        if self.keep_xf:
+            self.last_xf = xf
         w1 = self.conv1.weight.flatten(1)
         h = linear_pm(xf, w1[:, 1024:]) + F.linear(x4, w1[:, :1024], self.conv1.bias).unsqueeze(1)
         x = group_norm_relu(h, self.bn1)

@@ -212,3 +212,15 @@ def test_encoder_direct_bf16_slices_equal_cat(dev):
         ga = res[True][2][n_]
         d = (ga - gb).abs().max().item()
         assert d <= 1e-5 * max(gb.abs().max().item(), 1e-6) + 1e-8, (n_, d)
+
+
+def test_cfg5_combined_workload_runs(dev):
+    """BASELINE configs[4] in one piece (bench.cfg5_workload: hot path + 256-channel EdgeConv on the matrix cores + fp16
+    flash-attention Transformer layer + QueryDecoder, forward + backward + Adam) at a reduced size: finite loss, the
+    C=256 block on the bf16 path, every module gets gradients.  Parity of the pieces: test_fullsize_gpu.py
+    (test_edgeconv_c256_on_matrix_cores, hot path at N=16384), test_attention_*_gpu.py (reference goldens)."""
+    import bench
+    from gcanet_amd import dgcnn
+    assert dgcnn._edgeconv_dtype("bf16", 256, 128, 2) == "bf16"
+    r = bench.cfg5_workload(dev, B=2, N=2048, k=16, steps=1, warmup=1)
+    assert r["finite"] and r["ms_per_step"] > 0
