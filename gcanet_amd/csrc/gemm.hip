@@ -52,24 +52,29 @@ __device__ __forceinline__ unsigned short gemm_f2bf(float f) {
 // s_barrier: __syncthreads() would drain the ring.
 // BM = 256, BN = 256 (one workgroup per CU, 256 accumulator registers per lane, opt-in): a wave owns 128 x 128, so every
 // LDS fragment feeds FOUR MFMAs instead of two.
-template <int BN, int BM = 128>
-__global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void gemm_bf16_kernel(GemmArgs a) {
-  constexpr bool SQ = BN >= 128;                // 2 x 2 waves
-  constexpr int RB = SQ ? BM / 64 : 1;          // 32-row blocks per wave
-  constexpr int CB = SQ ? BN / 64 : BN / 32;    // 32-column blocks per wave
+// NWV = 8 (BM = BN = 256, round 3): eight waves in a 2 x 4 grid, a wave owns 128 rows x 64 columns = 128 accumulator
+// registers -- no AGPR traffic, TWO waves per SIMD (one wave's LDS / DMA waits hide under the other's MFMAs, which the
+// one-wave-per-SIMD 128 x 128 variant could not do) and 12 KB of LDS fragments per 16 MFMAs and wave.
+template <int BN, int BM = 128, int NWV = 4>
+__global__ __launch_bounds__(64 * NWV, (BM == 256 || NWV == 8) ? 1 : 2) void gemm_bf16_kernel(GemmArgs a) {
+  constexpr bool SQ = BN >= 128;                // 2 x 2 waves (NWV = 4)
+  constexpr int WR = NWV == 8 ? 2 : (SQ ? 2 : 4);   // wave grid: WR rows x WCN columns
+  constexpr int WCN = NWV / WR;
+  constexpr int RB = BM / WR / 32;              // 32-row blocks per wave
+  constexpr int CB = BN / WCN / 32;             // 32-column blocks per wave
   constexpr int WCOLS = CB * 32;                // columns per wave
   constexpr int NST = 4;
   constexpr int A_BYTES = BM * 64;              // BM rows x 32 k x 2 B
   constexpr int B_BYTES = BN * 64;
   constexpr int ST_BYTES = A_BYTES + B_BYTES;
-  constexpr int APW = BM / 64;                  // A pieces (16 rows x 64 B) per wave and stage
-  constexpr int WPW = BN >= 64 ? BN / 64 : 1;   // W pieces per wave and stage; BN = 32: waves 2,3 repeat 0,1
+  constexpr int APW = BM / 16 / NWV;            // A pieces (16 rows x 64 B) per wave and stage
+  constexpr int WPW = BN >= 16 * NWV ? BN / 16 / NWV : 1;   // W pieces per wave and stage; BN = 32: waves 2,3 repeat 0,1
   constexpr int DPS = APW + WPW;                // DMA instructions per wave and stage (the vmcnt unit)
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
   const int lane = lane_id(), wave = wave_id();
   const int lr = lane & 31, lh = lane >> 5;
-  const int wrow0 = SQ ? (wave >> 1) * (BM / 2) : wave * 32;  // this wave's first row / column inside the tile
-  const int wcol0 = SQ ? (wave & 1) * (BN / 2) : 0;
+  const int wrow0 = (wave / WCN) * (BM / WR);   // this wave's first row / column inside the tile
+  const int wcol0 = (wave % WCN) * (BN / WCN);
   // Workgroups are dealt to the 8 XCDs round robin by linear id.  The column blocks of one 128-row tile all read the
   // same A rows: give them to ONE XCD, back to back, so that the tile comes from HBM once and from that XCD's L2 for
   // the other column blocks.
@@ -96,7 +101,7 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void gemm_bf16_kernel(GemmA
   const unsigned short *arow[APW];
 #pragma unroll
   for (int i = 0; i < APW; ++i) {
-    const int row = (wave + i * 4) * 16 + prow;
+    const int row = (wave + i * NWV) * 16 + prow;
     long m = m0 + row;
     if (m >= a.M) m = a.M - 1;
     arow[i] = a.A + m * K + ((cs ^ ((row >> 2) & 3)) * 8);
@@ -104,7 +109,7 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void gemm_bf16_kernel(GemmA
   const unsigned short *wrow[WPW];
 #pragma unroll
   for (int i = 0; i < WPW; ++i) {
-    const int p = BN >= 64 ? wave + i * 4 : (wave & 1);
+    const int p = BN >= 16 * NWV ? wave + i * NWV : (wave & 1);
     const int row = p * 16 + prow;
     wrow[i] = a.W + (long)min(n0 + row, a.Np - 1) * K + ((cs ^ ((row >> 2) & 3)) * 8);
   }
@@ -117,12 +122,12 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void gemm_bf16_kernel(GemmA
     for (int i = 0; i < APW; ++i)
       if (ok)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(arow[i] + kbase),
-                                         (__attribute__((address_space(3))) void *)(dst + (wave + i * 4) * 1024), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void *)(dst + (wave + i * NWV) * 1024), 16, 0, 0);
 #pragma unroll
     for (int i = 0; i < WPW; ++i)
       if (ok)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wrow[i] + kbase),
-                                         (__attribute__((address_space(3))) void *)(dst + A_BYTES + (BN >= 64 ? wave + i * 4 : (wave & 1)) * 1024), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void *)(dst + A_BYTES + (BN >= 16 * NWV ? wave + i * NWV : (wave & 1)) * 1024), 16, 0, 0);
   };
   // fragment byte offsets inside an image: row lr (of a 32-row block), k-step s (0,1), half lh; 64-B rows
   unsigned int frag[2];
@@ -748,25 +753,34 @@ GCN_EXPORT int gcn_gemm_bf16(const void *A, const void *W, const float *bias, vo
   a.A = (const unsigned short *)A; a.W = (const unsigned short *)W; a.bias = bias; a.out = out; a.gsum = gsum;
   a.M = M; a.N = N; a.Np = Np; a.K = K; a.out_f32 = out_f32; a.rows_per_cloud = rows_per_cloud; a.G = G;
   a.part = (double *)stats_ws;
-#define GEMM_LAUNCH(BNV, BMV)                                                                                      \
+#define GEMM_LAUNCH(BNV, BMV, NWVV)                                                                                \
   {                                                                                                                 \
     constexpr int RING = 4 * (BMV * 64 + BNV * 64);                                                                 \
-    constexpr int WC = BNV >= 128 ? BNV / 2 : BNV;                                                                  \
-    constexpr int EPI = 4 * 32 * (WC * 4 + 16);                                                                     \
+    constexpr int WC = NWVV == 8 ? BNV / 4 : (BNV >= 128 ? BNV / 2 : BNV);                                          \
+    constexpr int EPI = NWVV * 32 * (WC * 4 + 16);                                                                  \
     constexpr int LDSB = RING > EPI ? RING : EPI;                                                                   \
     const int mblocks = (int)((M + BMV - 1) / BMV);                                                                 \
-    GCN_HIP(hipFuncSetAttribute((const void *)gemm_bf16_kernel<BNV, BMV>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB)); \
-    gemm_bf16_kernel<BNV, BMV><<<mblocks * ((N + BNV - 1) / BNV), 256, LDSB, st>>>(a);                           \
+    GCN_HIP(hipFuncSetAttribute((const void *)gemm_bf16_kernel<BNV, BMV, NWVV>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB)); \
+    gemm_bf16_kernel<BNV, BMV, NWVV><<<mblocks * ((N + BNV - 1) / BNV), 64 * NWVV, LDSB, st>>>(a);                 \
   }
-  // 256 x 256 tiles (128 x 128 per wave): opt-in (GCANET_GEMM_TILE=256).  Measured at M = 65536 it is no faster than
-  // the 128 x 128 tile at K = 1280 (147 us both, 585 TF: PMC says the matrix pipe is busy 30 % and waves sit in
-  // s_waitcnt 40 % of their cycles with LDS conflicts at zero -- the LDS-DMA ring, not the LDS read rate, is what
-  // starves it) and slower at K = 256, where eight k-steps cannot amortise a 256-register epilogue with one workgroup
-  // per CU (77 vs 49 us at N = 512).
+  // N >= 256: 256 x 256 tiles on EIGHT waves (128 x 64 per wave, two waves per SIMD).  M = 65536, us, forward without /
+  // with fused statistics (tools/gemm_bench.py; lib = hipBLASLt through torch, which needs a 16-us statistics pass on top):
+  //     N x K        8 waves        4 waves 128x128/wave   4 waves 64x64/wave (round 2)    lib
+  //   512 x 1280   122 / 125 (689 TF)   146 / 163              149 / 155                     70
+  //   512 x 256     43 / 55              75 / 92                49 / 63                      31
+  //   256 x 832     42 / 47              60 / 69                48 / 56                      30
+  //   256 x 512     31 / 39              50 / 59                36 / 43                      24
+  //   256 x 256     23 / 30              41 / 50                27 / 34                      20
+  //  1024 x 256     81 / 97             142 / 170               87 / 107                     56
+  // The one-wave-per-SIMD 128 x 128 variant (GCANET_GEMM_TILE=256) starves on its LDS-DMA ring (PMC: matrix pipe busy
+  // 30 %, waves in s_waitcnt 40 % of their cycles, no LDS conflicts); with two waves per SIMD one wave's waits hide
+  // under the other's MFMAs.  Still 0.6-0.85x of the library on the wide layers -- the policy in gcanet_amd/layers.py
+  // keeps those on hipBLASLt and uses this kernel where its fused statistics pay (N * K <= 256 * 256).
   const char *tile_env = getenv("GCANET_GEMM_TILE");
-  const bool big_ok = tile_env && atoi(tile_env) == 256;
-  if (N >= 256 && M >= 256 * 128 && big_ok) GEMM_LAUNCH(256, 256)
-  else if (N > 64) GEMM_LAUNCH(128, 128) else if (N > 32) GEMM_LAUNCH(64, 128) else GEMM_LAUNCH(32, 128)
+  const int tile_sel = tile_env ? atoi(tile_env) : 2568;     // 256: 4 waves x 128x128; 128: the round-2 tile everywhere
+  if (N >= 256 && M >= 256 * 128 && tile_sel == 256) GEMM_LAUNCH(256, 256, 4)
+  else if (N >= 256 && M >= 256 * 128 && tile_sel == 2568) GEMM_LAUNCH(256, 256, 8)
+  else if (N > 64) GEMM_LAUNCH(128, 128, 4) else if (N > 32) GEMM_LAUNCH(64, 128, 4) else GEMM_LAUNCH(32, 128, 4)
 #undef GEMM_LAUNCH
   int rc = check_launch("gemm_bf16_kernel");
   if (rc || !gsum) return rc;
