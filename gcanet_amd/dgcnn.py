@@ -158,7 +158,8 @@ def edgeconv_forward_raw(x, idx, weight, gamma, beta, groups, dtype="bf16", eps=
     ga, be = gamma.float().contiguous(), beta.float().contiguous()
     _run("gcn_edgeconv_finish", x, _lib.ptr(ymax), _lib.ptr(ymin), _lib.ptr(gsum), _lib.ptr(ga), _lib.ptr(be),
          B, N, k, Cout, groups, float(eps), float(slope), _lib.ptr(out), None, _lib.ptr(mean_rstd), None, 0)
-    return dict(out=out, ymax=ymax, ymin=ymin, amax=amax, amin=amin, gsum=gsum, mean_rstd=mean_rstd, x_pm=x_pm)
+    # gsum may live in the step's pre-zeroed arena (re-used next step): a tensor handed to the caller must not
+    return dict(out=out, ymax=ymax, ymin=ymin, amax=amax, amin=amin, gsum=gsum.clone(), mean_rstd=mean_rstd, x_pm=x_pm)
 
 
 class EdgeConvFunction(torch.autograd.Function):

@@ -624,7 +624,8 @@ int gcn_multi_cast_bf16(const void *segs_dev, int nseg, void *stream);
 /* Adam (torch.optim.Adam's rule: exp_avg lerp, exp_avg_sq, bias corrections, p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps),
  * optional L2 weight decay folded into the gradient) over flat f32 buffers of n elements, 16-byte aligned.  state: 4
  * floats on the device, zero before the first step: [0] the step count (incremented by the call: graph-capturable),
- * [1], [2] the bias corrections.  The reference's trainer: option_new.py:83-90. */
+ * [1], [2] the bias corrections 1 - beta^t, computed in double as torch.optim.Adam does, [3] the step count as a 32-bit
+ * integer (bit pattern).  The reference's trainer: option_new.py:83-90. */
 int gcn_adam_flat(float *p, const float *g, float *m, float *v, long n, float lr, float beta1, float beta2, float eps,
                   float weight_decay, float *state, void *stream);
 
@@ -633,7 +634,13 @@ int gcn_adam_flat(float *p, const float *g, float *m, float *v, long n, float lr
  * buffers out of ONE device allocation, zeroes the used part of it once per step and never hands the same bytes out
  * twice within a step may register the allocation here: a span that lies inside [base, base + bytes) is then trusted to
  * be zero and its fill is skipped (gcanet_amd/layers.py:ZeroArena).  bytes == 0 unregisters.  Process-wide setting, not
- * thread safe; every other pointer is zeroed by the call exactly as before. */
+ * thread safe; every other pointer is zeroed by the call exactly as before.
+ * THE CONTRACT IS THE CALLER'S: the library cannot tell a clean arena span from a dirty one.  An accumulator inside the
+ * registered range that was not zeroed since it was last handed out yields wrong sums WITHOUT an error.  Register an
+ * arena only if (1) one owner hands out its bytes, (2) the used prefix is zeroed once per step before the first call,
+ * (3) no span is used across steps and (4) results that outlive the step are never arena-backed (the Python layer
+ * clones the one tensor it used to return from the arena, the EdgeConv group sums).  Without a registered arena every
+ * "zeroed by the call" buffer is zeroed by the call. */
 int gcn_zero_arena_register(void *base, long bytes);
 
 #ifdef __cplusplus
