@@ -62,6 +62,9 @@ def _oracle_grads(sd, pts, nrm, k, idxs, sel, input_grads=False, dtype=torch.flo
     return g, float(loss.detach()), out
 
 
+_ORACLE_CACHE = {}
+
+
 def _rel_to_max(a, b):
     """max |a-b| / max |b|   (gradients are sums over up to N*k terms: compared relative to the tensor's largest entry)."""
     return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30))
@@ -86,8 +89,16 @@ def test_f32_step_gradients_match_oracle_autograd(dev, input_grads):
     loss.backward()
     idxs = [i.cpu() for i in m.encoder.last_idx]
     sel = m.offset_pred_block.last_topk_idx.cpu()
-    ref, ref_loss, _ = _oracle_grads(sd, pts, nrm, K, idxs, sel, input_grads, torch.float64)
-    ref32, _, _ = _oracle_grads(sd, pts, nrm, K, idxs, sel, input_grads, torch.float32)
+    # the oracle runs once for both variants (float64 + float32 autograd at N=8192 is ~35 s of CPU): the device's lists
+    # and key selection are the same in the two (same model, same cloud), which is checked before the cache is used
+    c = _ORACLE_CACHE
+    if not (c and all(torch.equal(a, b) for a, b in zip(c["idxs"] + [c["sel"]], idxs + [sel]))):
+        c.clear()
+        r64, l64, _ = _oracle_grads(sd, pts, nrm, K, idxs, sel, True, torch.float64)
+        r32, _, _ = _oracle_grads(sd, pts, nrm, K, idxs, sel, True, torch.float32)
+        c.update(idxs=idxs, sel=sel, r64=r64, r32=r32, loss=l64)
+    keep = lambda g: {n_: v for n_, v in g.items() if input_grads or not n_.startswith("<")}
+    ref, ref32, ref_loss = keep(c["r64"]), keep(c["r32"]), c["loss"]
     assert abs(float(loss) - ref_loss) <= 1e-5 * abs(ref_loss), (float(loss), ref_loss)
     got = {n_: p_.grad for n_, p_ in m.named_parameters()}
     if input_grads:
