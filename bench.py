@@ -20,11 +20,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# ROCm 7.2's HIP-graph "packet capture" fast path faults (memory access fault raised by the command processor, no wave
-# active) when a captured step is replayed again after the queue has gone idle -- reproduced 3 runs out of 4 at 2 clouds
-# per GPU, never with the fast path off (tools/debug/replay_sync_loop.py).  Must be set before the
-# HIP runtime loads, i.e. before `import torch`.
-os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+# (Round 3 note: ROCm 7.2 replays a captured graph through a "packet capture" fast path, 0.12 ms of host time per step
+# instead of 5.4.  That path faults on a replay after the queue has gone idle IF the graph holds a memset node -- found
+# with tools/debug/graph_trigger5.py; the library now zero-fills with a kernel (csrc/common.h: fill_dev) and the fast
+# path is safe again.  DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in the environment turns it off.)
 
 
 def parse_args(argv=None):
@@ -590,9 +589,9 @@ def main():
     # (the heads' RCCL all-reduce is started from a backward hook and overlaps the encoder's backward); see DESIGN.md
     # section 6 for what was observed with a captured step followed by an eager all-reduce.
     # (tests/test_parallel_gpu.py captures the whole multi-rank step incl. its RCCL all-reduces on a 1-rank group and
-    # replays it correctly; GCANET_GRAPH_MULTIRANK=1 opts a multi-rank run into that mode.  It is not the default: with
-    # the packet-capture fast path off a replay costs the host about as much as the eager launches, see the top of
-    # this file, so there is nothing to gain and an unrehearsed N-rank capture to lose.)
+    # replays it correctly; GCANET_GRAPH_MULTIRANK=1 opts a multi-rank run into that mode.  It is not the default: the
+    # eager multi-rank step is GPU-bound already (6.7 ms of GPU against 6.0 ms of host enqueue), so a replay would gain
+    # ~3 % and an N-rank capture cannot be rehearsed on the one-GPU test box.)
     use_graph = (world == 1 or os.environ.get("GCANET_GRAPH_MULTIRANK") == "1") and not args.no_graph
     B, N = args.batch, args.points
     pts, nrm = synth_clouds(range(rank * B, rank * B + B), N, dev)

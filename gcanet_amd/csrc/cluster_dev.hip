@@ -410,7 +410,7 @@ GCN_EXPORT int gcn_cluster_components(int n, const int32_t *nbr, const int32_t *
   GCN_REQUIRE(counts, "gcn_cluster_components: counts is null");
   GCN_REQUIRE(n >= 0 && n < (1 << 20) && S >= 1, "gcn_cluster_components: n=%d must be below 2^20 (queue rank is a 20-bit key field)", n);
   hipStream_t st = (hipStream_t)stream;
-  GCN_HIP(hipMemsetAsync(counts, 0, 2 * sizeof(int32_t), st));
+  GCN_HIP(fill_dev(counts, 0, 2 * sizeof(int32_t), st));
   if (n == 0) return GCN_OK;
   GCN_REQUIRE(start_len && seg_of && seg_offsets && seg_cls && point_index && ws && cluster_idxs && cluster_offsets,
               "gcn_cluster_components: null pointer");

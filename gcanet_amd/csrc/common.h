@@ -160,11 +160,45 @@ inline void exscan_rows(hipStream_t st, int rows, int m, int32_t *v, int32_t *bs
 // Pre-zeroed scratch arena (gcn_zero_arena_register): a span that lies inside it was zeroed by the owner of the arena
 // with ONE fill at the start of the step and has not been handed out since -- the fill is skipped.  Any other pointer
 // is zeroed here as before.
+// Device fills go through a KERNEL, never hipMemsetAsync: inside a captured HIP graph a memset NODE is what makes ROCm
+// 7.2's packet-capture replay path fault when the graph is replayed after the queue went idle (tools/debug/
+// graph_trigger5.py: a graph holding this library's kNN entry point faulted on its second replay 3 runs out of 4 -- the
+// stale, un-zeroed counter behind it sent knnf_list_kernel to a wild address -- and never with the fill as a kernel
+// node; graphs of plain kernels, 3000 nodes long, replay fine).  Word fills when pointer and size allow, bytes otherwise.
+static __global__ __launch_bounds__(256) void fill_words_kernel(unsigned int *__restrict__ p, unsigned int v, size_t nwords) {
+  const size_t stride = (size_t)gridDim.x * 256 * 4;
+  for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < nwords; i += stride) {
+    if (i + 4 <= nwords && (((uintptr_t)(p + i)) & 15) == 0) {
+      *reinterpret_cast<uint4 *>(p + i) = make_uint4(v, v, v, v);
+    } else {
+      for (size_t e = i; e < nwords && e < i + 4; ++e) p[e] = v;
+    }
+  }
+}
+static __global__ __launch_bounds__(256) void fill_bytes_kernel(unsigned char *__restrict__ p, unsigned char v, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = v;
+}
+inline hipError_t fill_dev(void *p, int value, size_t n, hipStream_t st) {
+  if (n == 0 || !p) return hipSuccess;
+  const unsigned int b = (unsigned int)value & 0xffu;
+  if ((((uintptr_t)p) & 3) == 0 && (n & 3) == 0) {
+    const size_t nwords = n / 4;
+    size_t blocks = (nwords + 1023) / 1024;
+    if (blocks > 4096) blocks = 4096;
+    fill_words_kernel<<<(unsigned int)blocks, 256, 0, st>>>((unsigned int *)p, b * 0x01010101u, nwords);
+  } else {
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    fill_bytes_kernel<<<(unsigned int)blocks, 256, 0, st>>>((unsigned char *)p, (unsigned char)b, n);
+  }
+  return hipGetLastError();
+}
+
 extern char *g_zero_lo, *g_zero_hi;
 inline hipError_t zero_dev(void *p, size_t n, hipStream_t st) {
   if (n == 0 || !p) return hipSuccess;
   if ((char *)p >= g_zero_lo && (char *)p + n <= g_zero_hi) return hipSuccess;
-  return hipMemsetAsync(p, 0, n, st);
+  return fill_dev(p, 0, n, st);
 }
 
 struct ZeroSpan { void *p; size_t n; };

@@ -236,7 +236,7 @@ GCN_EXPORT int gcn_multi_mean_square_fwd(const void *const *v, const long *numel
   MsqArgs a;
   const int nseg = msq_pack(a, v, nullptr, numel, is_bf16, nt);
   if (nseg == 0) {
-    GCN_HIP(hipMemsetAsync(loss, 0, sizeof(float), (hipStream_t)stream));
+    GCN_HIP(fill_dev(loss, 0, sizeof(float), (hipStream_t)stream));
     return GCN_OK;
   }
   multi_mean_square_fwd_kernel<<<nseg, 256, 0, (hipStream_t)stream>>>(a, part, done, loss);

@@ -860,9 +860,14 @@ GCN_EXPORT int gcn_knn_feature(const float *x_pm, int B, int N, int C, int k1, i
   int m = (int)(mu + sig * __builtin_sqrt(mu) + 2.0);
   if (m > 96) m = 96;
   a.m_rank = m;
-  GCN_HIP(hipMemsetAsync(base + w.msum, 0, w.ut - w.msum, st));
+  int dbg_stop = 99;                                           // debugging aid (tools/debug/graph_trigger5.py): stop after stage n
+  if (const char *e = getenv("GCANET_KNN_STOP_AFTER")) dbg_stop = atoi(e);
+  GCN_HIP(fill_dev(base + w.msum, 0, w.ut - w.msum, st));
+  if (dbg_stop < 1) return GCN_OK;
   knnf_colsum_kernel<<<dim3(64, B), 256, 0, st>>>(a);
+  if (dbg_stop < 2) return GCN_OK;
   knnf_prep_kernel<<<dim3(Np / 64, B), 256, 0, st>>>(a);
+  if (dbg_stop < 3) return GCN_OK;
   const dim3 grid(Np / 128, B);
 #define KNNF_STREAM(KSV)                                                                                           \
   {                                                                                                                 \
@@ -876,6 +881,7 @@ GCN_EXPORT int gcn_knn_feature(const float *x_pm, int B, int N, int C, int k1, i
 #undef KNNF_STREAM
   int rc = check_launch("knnf_stream_kernel");
   if (rc) return rc;
+  if (dbg_stop < 4) return GCN_OK;
   const dim3 rgrid(cdiv(N, 4), B);
 #define KNNF_RERANK2(CCV)                                                                                          \
   {                                                                                                                 \
@@ -889,21 +895,28 @@ GCN_EXPORT int gcn_knn_feature(const float *x_pm, int B, int N, int C, int k1, i
 #undef KNNF_RERANK2
   rc = check_launch("knnf_rank_kernel");
   if (rc) return rc;
+  if (dbg_stop < 5) return GCN_OK;
   // the exhaustive stage for the flagged queries.  k <= 64 on a cloud the f32 matrix-core kernel accepts: a short list
   // one workgroup per query, a long one on the matrix cores; otherwise the VALU selection kernel in its flagged mode
   // (one wave scans per flagged query; free when nothing is flagged)
   if (k2 > 64 || (N % 4) != 0)
     return launch_knn_flagged(x_pm, a.xx, a.flag, B, N, C, k2, a.step, a.kout, idx, st);
-  knnf_list_kernel<<<std::min(256, cdiv(B * N, 256)), 256, 0, st>>>(a);
+  int dbg_mask = 7;
+  if (const char *e = getenv("GCANET_KNN_STAGE5_MASK")) dbg_mask = atoi(e);
+  if (dbg_mask & 1) knnf_list_kernel<<<std::min(256, cdiv(B * N, 256)), 256, 0, st>>>(a);
+  if (dbg_mask & 2) {
   if (C == 32) knnf_fallback_kernel<32><<<1024, 256, 0, st>>>(a);
   else if (C == 64) knnf_fallback_kernel<64><<<1024, 256, 0, st>>>(a);
   else knnf_fallback_kernel<128><<<1024, 256, 0, st>>>(a);
-  knnf_fallback_merge_kernel<<<256, 256, 0, st>>>(a);
+  }
+  if (dbg_mask & 4) knnf_fallback_merge_kernel<<<256, 256, 0, st>>>(a);
   rc = check_launch("knnf_fallback_kernel");
   if (rc) return rc;
+  if (dbg_stop < 6) return GCN_OK;
   knnf_transpose_kernel<<<dim3(cdiv(N, 64), B), 256, 0, st>>>(a);
   rc = check_launch("knnf_transpose_kernel");
   if (rc) return rc;
+  if (dbg_stop < 7) return GCN_OK;
   return launch_knn_mfma16_flagged(a.xcm, a.xx, a.flag, a.nflag, a.long_list, B, N, C, k2, a.step, a.kout, idx, st);
 }
 

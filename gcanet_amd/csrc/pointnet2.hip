@@ -424,7 +424,7 @@ static int scatter_rows(int b, int c, int n, long E, const float *grad_out, cons
       scatter_rows_lds_kernel<1><<<dim3(c, b), 1024, row_bytes, st>>>(c, n, E, grad_out, idx, grad_points);
     }
   } else {
-    GCN_HIP(hipMemsetAsync(grad_points, 0, (size_t)b * c * n * sizeof(float), st));
+    GCN_HIP(fill_dev(grad_points, 0, (size_t)b * c * n * sizeof(float), st));
     if (E > 0) scatter_rows_atomic_kernel<<<dim3(cdiv(E, 256), c, b), 256, 0, st>>>(c, n, E, grad_out, idx, grad_points);
   }
   return check_launch(what);
@@ -536,7 +536,7 @@ GCN_EXPORT int gcn_three_interpolate_grad(int b, int c, int n, int m, const floa
   GCN_REQUIRE(b >= 0 && c >= 0 && m >= 1 && n >= 0, "gcn_three_interpolate_grad: bad shape");
   if (b == 0 || c == 0) return GCN_OK;
   hipStream_t st = (hipStream_t)stream;
-  GCN_HIP(hipMemsetAsync(grad_points, 0, (size_t)b * c * m * sizeof(float), st));
+  GCN_HIP(fill_dev(grad_points, 0, (size_t)b * c * m * sizeof(float), st));
   if (n == 0) return GCN_OK;
   three_interpolate_grad_kernel<<<dim3(cdiv(n, 256), c, b), 256, 0, st>>>(c, n, m, grad_out, idx, weight, grad_points);
   return check_launch("three_interpolate_grad_kernel");

@@ -790,9 +790,9 @@ static GridWs grid_ws_carve(void *ws, int n, int max_cells) {
 }
 // counting sort of the points by (segment, z, y, x) cell; everything on the device
 static int grid_build(const GridWs &w, int n, const float *xyz, const int32_t *seg_of, int nseg, float radius, hipStream_t st) {
-  GCN_HIP(hipMemsetAsync(w.g, 0x00, 64, st));
-  GCN_HIP(hipMemsetAsync(&w.g->bmin[0], 0xff, 12, st));
-  GCN_HIP(hipMemsetAsync(w.cell_start, 0, sizeof(int32_t) * (size_t)(w.max_cells + 1), st));
+  GCN_HIP(fill_dev(w.g, 0x00, 64, st));
+  GCN_HIP(fill_dev(&w.g->bmin[0], 0xff, 12, st));
+  GCN_HIP(fill_dev(w.cell_start, 0, sizeof(int32_t) * (size_t)(w.max_cells + 1), st));
   bq_bbox_kernel<<<32, 1024, 0, st>>>(n, xyz, w.g);
   bq_setup_kernel<<<1, 1, 0, st>>>(w.g, radius, nseg, w.max_cells);
   bq_cell_count_kernel<<<cdiv(n, 256), 256, 0, st>>>(n, xyz, seg_of, w.g, w.cell_of_pt, w.cell_start);
@@ -856,7 +856,7 @@ GCN_EXPORT int gcn_segment_diameter2(int n, int C, const float *feats, const int
   if (n == 0 || S == 0) return GCN_OK;
   GCN_REQUIRE(feats && seg_offsets && seg_cls && xx_ws && tile_ws && dmax2, "gcn_segment_diameter2: null pointer");
   hipStream_t st = (hipStream_t)stream;
-  GCN_HIP(hipMemsetAsync(dmax2, 0, sizeof(float) * (size_t)S, st));
+  GCN_HIP(fill_dev(dmax2, 0, sizeof(float) * (size_t)S, st));
   row_sqnorm_kernel<<<cdiv(n, 256), 256, 0, st>>>(n, C, feats, xx_ws);
   seg_tile_prefix_kernel<<<1, 1, 0, st>>>(S, seg_offsets, seg_cls, tile_ws);
   seg_diameter_kernel<<<n / 64 + S, 256, 0, st>>>(S, C, feats, xx_ws, seg_offsets, tile_ws, (unsigned int *)dmax2);
@@ -877,7 +877,7 @@ GCN_EXPORT int gcn_ballquery_sim(int n, float radius, const float *xyz, const in
   GCN_REQUIRE(Ci > 0 && Cp > 0 && Ci % 16 == 0 && Cp % 16 == 0 && Ci <= 256 && Cp <= 256, "gcn_ballquery_sim: feature rows must be zero-padded to a multiple of 16 columns, at most 256 (Ci=%d, Cp=%d)", Ci, Cp);
   GCN_REQUIRE(status, "gcn_ballquery_sim: status is null");
   hipStream_t st = (hipStream_t)stream;
-  GCN_HIP(hipMemsetAsync(status, 0, 4 * sizeof(int32_t), st));
+  GCN_HIP(fill_dev(status, 0, 4 * sizeof(int32_t), st));
   if (n == 0) return GCN_OK;
   GCN_REQUIRE(xyz && seg_of && seg_offsets && seg_cls && feat_inst && dmax2_inst && feat_para && dmax2_para && start_len &&
               grid_ws && (idx || capacity == 0), "gcn_ballquery_sim: null pointer");
@@ -886,7 +886,7 @@ GCN_EXPORT int gcn_ballquery_sim(int n, float radius, const float *xyz, const in
   int rc = grid_build(w, n, xyz, seg_of, S, radius, st);
   if (rc) return rc;
   SimArgs sa{feat_inst, feat_para, dmax2_inst, dmax2_para, seg_cls, thr_inst, thr_para, Ci, Cp};
-  GCN_HIP(hipMemsetAsync(w.region, 0, sizeof(int32_t) * BQ_REGIONS * 32, st));
+  GCN_HIP(fill_dev(w.region, 0, sizeof(int32_t) * BQ_REGIONS * 32, st));
   ballquery_sim_kernel<<<cdiv(n, 4), 256, 0, st>>>(n, radius * radius, 3000, xyz, seg_of, seg_offsets, sa, w.g, w.cell_start,
                                                    w.packed, idx, capacity, start_len, w.region, status);
   bq_status_kernel<<<1, 1, 0, st>>>(w.region, status);

@@ -318,7 +318,7 @@ GCN_EXPORT int gcn_sparse_subm_rules(int M, const int32_t *coords, int batch, in
   if (M == 0) return GCN_OK;
   GCN_REQUIRE(coords && grid && nbr, "gcn_sparse_subm_rules: null pointer");
   hipStream_t st = (hipStream_t)stream;
-  GCN_HIP(hipMemsetAsync(grid, 0xff, (size_t)gcn_sparse_grid_bytes(batch, D), st));
+  GCN_HIP(fill_dev(grid, 0xff, (size_t)gcn_sparse_grid_bytes(batch, D), st));
   sc_grid_fill_kernel<<<cdiv(M, 256), 256, 0, st>>>(M, coords, D, grid);
   sc_subm_rules_kernel<<<cdiv(27L * M, 256), 256, 0, st>>>(M, coords, D, grid, nbr);
   return check_launch("sc_subm_rules_kernel");
@@ -335,16 +335,16 @@ GCN_EXPORT int gcn_sparse_coarse_rules(int M, const int32_t *coords, int batch, 
   GCN_REQUIRE(M >= 0 && batch >= 1 && D >= 1, "gcn_sparse_coarse_rules: bad shape");
   GCN_REQUIRE(m2_dev, "gcn_sparse_coarse_rules: m2_dev is null");
   hipStream_t st = (hipStream_t)stream;
-  GCN_HIP(hipMemsetAsync(m2_dev, 0, sizeof(int32_t), st));
+  GCN_HIP(fill_dev(m2_dev, 0, sizeof(int32_t), st));
   if (M == 0) return GCN_OK;
   GCN_REQUIRE(coords && ws && coords2 && child && parent, "gcn_sparse_coarse_rules: null pointer");
   const int D2 = (D + 1) / 2;
   const long cells = (long)batch * D2 * D2 * D2 + 1;
   GCN_REQUIRE(cells < (1L << 31), "gcn_sparse_coarse_rules: grid too large");
   int32_t *flag = (int32_t *)ws, *bsum = flag + cells;
-  GCN_HIP(hipMemsetAsync(flag, 0, sizeof(int32_t) * (size_t)cells, st));
-  GCN_HIP(hipMemsetAsync(child, 0xff, sizeof(int32_t) * 8 * (size_t)M, st));      // at most M coarse voxels
-  GCN_HIP(hipMemsetAsync(parent, 0xff, sizeof(int32_t) * 8 * (size_t)M, st));
+  GCN_HIP(fill_dev(flag, 0, sizeof(int32_t) * (size_t)cells, st));
+  GCN_HIP(fill_dev(child, 0xff, sizeof(int32_t) * 8 * (size_t)M, st));      // at most M coarse voxels
+  GCN_HIP(fill_dev(parent, 0xff, sizeof(int32_t) * 8 * (size_t)M, st));
   sc_coarse_flag_kernel<<<cdiv(M, 256), 256, 0, st>>>(M, coords, D2, flag);
   exscan_rows(st, 1, (int)cells, flag, bsum);                 // flag[cells-1] = number of coarse voxels
   sc_coarse_rules_kernel<<<cdiv(M, 256), 256, 0, st>>>(M, coords, D2, flag, coords2, child, parent);
@@ -394,7 +394,7 @@ GCN_EXPORT int gcn_sparse_wgrad(int Mout, int K, int Cin, int Cout, const float 
               "gcn_sparse_wgrad: channels must be multiples of 64 (Cin=%d, Cout=%d)", Cin, Cout);
   GCN_REQUIRE(dW, "gcn_sparse_wgrad: dW is null");
   hipStream_t st = (hipStream_t)stream;
-  GCN_HIP(hipMemsetAsync(dW, 0, sizeof(float) * (size_t)K * Cin * Cout, st));
+  GCN_HIP(fill_dev(dW, 0, sizeof(float) * (size_t)K * Cin * Cout, st));
   if (Mout == 0) return GCN_OK;
   GCN_REQUIRE(in && ruleT && dout, "gcn_sparse_wgrad: null pointer");
   int rows = 1024;                                   // >= ~1000 workgroups; at most 4096 rows each

@@ -180,7 +180,7 @@ GCN_EXPORT int gcn_voxelize_idx(const int64_t *coords, int N, int ncol, int mode
   GCN_HIP(hipMemcpyAsync(&hh, h, sizeof(hh), hipMemcpyDeviceToHost, st));
   GCN_HIP(hipStreamSynchronize(st));
   const int M = hh.M, W = hh.maxActive + 1;
-  GCN_HIP(hipMemsetAsync(output_map, 0, sizeof(int32_t) * (size_t)M * W, st));
+  GCN_HIP(fill_dev(output_map, 0, sizeof(int32_t) * (size_t)M * W, st));
   vx_fill_kernel<<<nb, 256, 0, st>>>(coords, ncol, L.seg, L.ids_b, L.rank, L.run_pos, N, M, mode, W, output_coords, output_map);
   *M_host = M;
   *maxActive_host = hh.maxActive;

@@ -4,8 +4,6 @@ import sys
 import numpy as np
 import pytest
 
-# see bench.py: ROCm 7.2's graph packet-capture path faults on a replay after the queue went idle (before torch loads HIP)
-os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

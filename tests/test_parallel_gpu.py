@@ -17,7 +17,6 @@ def test_captured_step_with_rccl_allreduce(dev):
     a process group and a captured collective do not belong in the test runner's process)."""
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] = "0"
     env["MASTER_PORT"] = "29547"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "debug", "rccl_graph_step.py"), "2"], env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
