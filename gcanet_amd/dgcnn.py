@@ -837,7 +837,7 @@ class PrimitivesEmbeddingDGCNGn(nn.Module):
         Activations are point-major (B,N,C) end to end; the reference's (B,C,N) Conv1d tensors are the same
         values transposed.  conv1 on cat[x4 repeated, x_features] (M4:510-511,644) is evaluated as
         W[:, :1024].x4 (once per cloud) + W[:, 1024:].x_features -- identical, 5x fewer FLOPs."""
-        from .layers import conv1x1, conv1x1_gn_relu, group_norm_relu, linear_pm, param_normalise
+        from .layers import add_row_broadcast, conv1x1, conv1x1_gn_relu, group_norm_relu, linear_pm, param_normalise
         B, N, _ = points.shape
         pts = torch.cat([points, normals], dim=-1).contiguous() if self.mode == 5 else points.contiguous()   # (B,N,6)
         pts_cm = pts.transpose(1, 2).contiguous()
@@ -845,7 +845,7 @@ class PrimitivesEmbeddingDGCNGn(nn.Module):
         if self.keep_xf:
             self.last_xf = xf
         w1 = self.conv1.weight.flatten(1)
-        h = linear_pm(xf, w1[:, 1024:]) + F.linear(x4, w1[:, :1024], self.conv1.bias).unsqueeze(1)
+        h = add_row_broadcast(linear_pm(xf, w1[:, 1024:]), F.linear(x4, w1[:, :1024], self.conv1.bias))
         x = group_norm_relu(h, self.bn1)
         x_all = conv1x1_gn_relu(x, self.conv2, self.bn2)                                      # (B,N,256)
         x_type = conv1x1_gn_relu(x_all, self.mlp_prim_prob1, self.bn_prim_prob1)

@@ -290,8 +290,11 @@ def _wgrad_narrow(dy2, x2, with_bias):
     swap = False
     # where it wins (tools/wgrad_narrow_bench.py, M = 65536): 3x256 16 us vs 55 (library: split-K bmm + partial sum +
     # column sum), 30x30 21 vs 34-45, 3x128 f32 11 vs 52, 10x256 25 vs 35; it is a VALU kernel with 4 N accumulators per
-    # lane -- beyond 16 outputs only two waves fit a SIMD and 22x256 loses (48 vs 35): that one stays with the library
-    small = lambda n, k: n <= 4 or n * k <= 1024 or (n <= 16 and k <= 256)
+    # lane -- beyond 16 outputs only two waves fit a SIMD and 22x256 takes 48 us against the library's 35 (split-K bmm +
+    # partial-sum pass + column sum).  It is served here all the same since round 3: the library path's two reductions
+    # zero their semaphores with hipMemsetAsync, i.e. put memset NODES into the captured step (csrc/common.h: fill_dev
+    # says why this library issues none), and it is three launches against one.
+    small = lambda n, k: n <= 4 or n * k <= 1024 or (n <= 32 and k <= 256)
     if not (N <= 32 and small(N, K) and L.gcn_wgrad_narrow_supported(M, N, K)):
         if with_bias or not (K <= 32 and small(K, N) and L.gcn_wgrad_narrow_supported(M, K, N)):
             return None
@@ -392,6 +395,34 @@ class LinearPMFunction(torch.autograd.Function):
 
 def linear_pm(x, weight, bias=None):
     return LinearPMFunction.apply(x, weight, bias)
+
+
+_ONES = {}
+
+
+class AddRowBroadcastFunction(torch.autograd.Function):
+    """a (B,N,C) + b (B,C) broadcast over the N rows.  Backward: the gradient of b is the column sum of the incoming
+    gradient, taken as a (1 x N) . (N x C) product per cloud on the matrix cores -- torch's own reduction for this shape
+    runs in two stages whose semaphores are zeroed by hipMemsetAsync: a memset NODE in the captured step (see
+    csrc/common.h: fill_dev for why the step holds none)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.b_dtype = b.dtype
+        return a + b.to(a.dtype).unsqueeze(1)
+
+    @staticmethod
+    def backward(ctx, g):
+        B, N, _ = g.shape
+        key = (B, N, g.dtype, g.device)
+        if key not in _ONES:
+            _ONES[key] = torch.ones(B, 1, N, dtype=g.dtype, device=g.device)
+        gb = torch.bmm(_ONES[key], g.contiguous()).squeeze(1)
+        return g, gb.to(ctx.b_dtype)
+
+
+def add_row_broadcast(a, b):
+    return AddRowBroadcastFunction.apply(a, b)
 
 
 def conv1x1(x, conv):
