@@ -146,10 +146,12 @@ __global__ __launch_bounds__(64 * NWV, (BM == 256 || NWV == 8) ? 1 : 2) void gem
   for (int p = 0; p < NST - 1; ++p)
     if (p < ktiles) issue(p, p);
 
-  auto ktile = [&](int kt, auto stgc) {
-    constexpr int STG = decltype(stgc)::value;
-    // stage kt must have landed: the younger stages in flight are min(NST-2, ktiles-1-kt)
-    const int later = min(NST - 2, ktiles - 1 - kt);
+  // Software pipeline (round 3).  The fragments of k-step s+1 are read from LDS while the MFMAs of k-step s issue, and the
+  // workgroup barrier sits in the MIDDLE of a k-tile: [frags(kt, 0) in registers] -> read frags(kt, 1) | MFMAs(kt, 0)
+  // -> stage kt+1 landed? barrier -> refill the ring -> read frags(kt+1, 0) | MFMAs(kt, 1).  With the barrier at the top
+  // of the tile (rounds 2) all waves read their fragments at the same time and only then multiplied: PMC showed the
+  // matrix pipe 31 % busy at two waves per SIMD, waves waiting 40 % of their cycles -- LDS and MFMA phases in lock step.
+  auto wait_landed = [&](int later) {                          // my share of a stage has landed, `later` younger stages may fly
     static_assert(DPS == 3 || DPS == 4 || DPS == 8, "vmcnt literals below");
     if (later >= 2) {
       if (DPS == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -162,33 +164,41 @@ __global__ __launch_bounds__(64 * NWV, (BM == 256 || NWV == 8) ? 1 : 2) void gem
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    __builtin_amdgcn_s_barrier();                            // every wave's share of stage kt is in; stage kt-1 is free
-    if (kt + NST - 1 < ktiles) issue(kt + NST - 1, (STG + NST - 1) % NST);
-    const unsigned char *ta = lds + STG * ST_BYTES + wrow0 * 64;
-    const unsigned char *tw = lds + STG * ST_BYTES + A_BYTES + wcol0 * 64;
+  };
+  bf16x8 xf[2][RB], wf[2][CB];
+  auto load_frags = [&](int stg, int s, int set) {
+    const unsigned char *ta = lds + stg * ST_BYTES + wrow0 * 64;
+    const unsigned char *tw = lds + stg * ST_BYTES + A_BYTES + wcol0 * 64;
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) xf[set][rb] = *reinterpret_cast<const bf16x8 *>(ta + frag[s] + rb * 32 * 64);
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) wf[set][cb] = *reinterpret_cast<const bf16x8 *>(tw + frag[s] + cb * 32 * 64);
+  };
+  auto mfmas = [&](int set) {
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb)
+        acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[set][cb], xf[set][rb], acc[rb][cb], 0, 0, 0);   // D[n][m]
+  };
+  // prologue: stage 0 landed everywhere, its first k-step in registers
+  wait_landed(min(NST - 2, ktiles - 1));
+  __builtin_amdgcn_s_barrier();
+  load_frags(0, 0, 0);
+  auto ktile = [&](int kt, auto stgc) {
+    constexpr int STG = decltype(stgc)::value;
     const int ksteps = min(2, (K - kt * 32) >> 4);             // wave-uniform
-    // both k-steps' fragments are requested before the first MFMA: the second step's LDS reads complete under the
-    // first step's matrix work (one wave per SIMD at the 256 x 256 tile: nobody else would hide them)
-    bf16x8 xf[2][RB], wf[2][CB];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      if (s < ksteps) {
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb) xf[s][rb] = *reinterpret_cast<const bf16x8 *>(ta + frag[s] + rb * 32 * 64);
-#pragma unroll
-        for (int cb = 0; cb < CB; ++cb) wf[s][cb] = *reinterpret_cast<const bf16x8 *>(tw + frag[s] + cb * 32 * 64);
-      }
+    if (ksteps == 2) load_frags(STG, 1, 1);
+    mfmas(0);
+    if (kt + 1 < ktiles) {
+      // stage kt+1: tiles kt+2 .. kt+NST-2 were issued after it
+      wait_landed(min(NST - 3, ktiles - 2 - kt));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // my LDS reads of stage kt are done: the stage may be refilled
+      __builtin_amdgcn_s_barrier();                            // stage kt+1 is in for everybody; stages <= kt are free
+      if (kt + NST - 1 < ktiles) issue(kt + NST - 1, (STG + NST - 1) % NST);
+      load_frags((STG + 1) % NST, 0, 0);
     }
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      if (s < ksteps) {
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-          for (int cb = 0; cb < CB; ++cb)
-            acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][cb], xf[s][rb], acc[rb][cb], 0, 0, 0);   // D[n][m]
-      }
-    }
+    if (ksteps == 2) mfmas(1);
   };
   for (int kt = 0; kt < ktiles; kt += 4) {
     ktile(kt, std::integral_constant<int, 0>{});
