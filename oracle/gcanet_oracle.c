@@ -147,8 +147,13 @@ ORC_API void orc_knn_model(const float *x, int C, int N, int k2, int metric,
     }
     xx[j] = s;
   }
+  /* queries are independent: the loop over i runs on all host cores (OpenMP; each thread keeps its own list), which
+   * changes nothing in any result -- the parity tests call this at N = 8192..16384 */
+#pragma omp parallel
+  {
   float *bv = (float *)malloc(sizeof(float) * (size_t)k2);
   int64_t *bi = (int64_t *)malloc(sizeof(int64_t) * (size_t)k2);
+#pragma omp for schedule(dynamic, 16)
   for (int i = 0; i < N; ++i) {
     int cnt = 0;
     for (int j = 0; j < N; ++j) {
@@ -170,7 +175,9 @@ ORC_API void orc_knn_model(const float *x, int C, int N, int k2, int metric,
       if (val) val[(size_t)i * k2 + t] = bv[t];
     }
   }
-  free(xx); free(bv); free(bi);
+  free(bv); free(bi);
+  }
+  free(xx);
 }
 
 /* ------------------------------------------------------------------------- */

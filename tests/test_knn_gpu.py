@@ -365,6 +365,32 @@ def test_knn_feature_long_fallback_list_runs_on_the_matrix_cores(dev, monkeypatc
         assert st["flagged"] <= 2
 
 
+@pytest.mark.parametrize("B,C,N,k1,k2,metric", [
+    (1, 64, 1024, 1, 1, 0),          # smallest served cloud, k = 1 (the query itself)
+    (3, 32, 1025, 5, 5, 0),          # one row into the padding tile, three clouds (not a multiple of the 8 XCDs)
+    (1, 128, 16384, 128, 128, 0),    # largest served cloud, largest k
+    (1, 64, 16383, 16, 128, 0),      # ragged at the top end, dilated pick
+    (2, 6, 1025, 128, 128, 1), (1, 6, 16383, 80, 80, 1), (3, 3, 5000, 1, 1, 0), (2, 3, 9000, 100, 100, 0)])
+def test_knn_filters_size_and_k_limits(dev, B, C, N, k1, k2, metric):
+    """The edges of what the threshold / filter / re-rank paths accept (1024 <= N <= 16384, k <= 128, any batch):
+    bit-identical to the C oracle, feature space (csrc/knn_filter.hip) and xyz / xyz+normal (csrc/knn_normal.hip)."""
+    from gcanet_amd import _lib, dgcnn
+    g = torch.Generator().manual_seed(B * 1000 + N + k2)
+    x = torch.randn(B, C, N, generator=g)
+    if metric == 1:
+        x[:, :3] = torch.rand(B, 3, N, generator=g)
+        x[:, 3:] = torch.nn.functional.normalize(x[:, 3:], dim=1)
+    elif C == 3:
+        x = torch.rand(B, 3, N, generator=g)
+    if C >= 32:
+        assert _lib.lib().gcn_knn_feature_supported(B, N, C, k2) == 1
+    else:
+        assert _lib.lib().gcn_knn_normal_supported(B, N, k2) == 1
+    fn = dgcnn.knn_points_normals if metric == 1 else dgcnn.knn
+    idx = fn(x.to(dev), k1, k2).cpu().numpy()
+    np.testing.assert_array_equal(idx, oracle.knn_model(x.numpy(), k1, k2, metric))
+
+
 def test_knn_feature_unsupported_shapes_use_the_exact_kernel(dev):
     from gcanet_amd import _lib, dgcnn
     lib = _lib.lib()
