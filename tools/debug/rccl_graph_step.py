@@ -44,7 +44,8 @@ g_a, p_a = one(st["step"])
 g_c, p_c = one(st["step"])
 gs = float(g_a.abs().max())
 d, noise = float((g_a - g_b).abs().max()) / gs, float((g_a - g_c).abs().max()) / gs
-ok = d <= max(4 * noise, 1e-5) and bool(torch.isfinite(p_b).all()) and float((p_b - saved[0]).abs().max()) > 1e-4
+rel_l2 = float((g_a - g_b).norm() / g_a.norm())
+ok = d <= max(4 * noise, 5e-3) and rel_l2 <= 1e-3 and bool(torch.isfinite(p_b).all()) and float((p_b - saved[0]).abs().max()) > 1e-4   # (bar: see test_graph_replay_equals_eager_step)
 print("%s captured step with RCCL all-reduce: graph vs eager gradients %.2e of max|g| (eager vs eager %.2e); the early "
       "all-reduce was started inside backward in %d steps incl. the capture" % ("OK" if ok else "FAILED", d, noise, early_in_capture))
 dist.destroy_process_group()
