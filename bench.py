@@ -398,7 +398,12 @@ def capture_step(step, warmup):
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
+    # With a process group alive its watchdog thread polls the events of earlier collectives at any moment; under the
+    # default "global" capture mode such a query from another thread during the capture is an error that takes the
+    # process down (seen once in three runs of tests/test_parallel_gpu.py).  "thread_local" restricts the check to the
+    # capturing thread.
+    mode = "thread_local" if (torch.distributed.is_available() and torch.distributed.is_initialized()) else "global"
+    with torch.cuda.graph(graph, capture_error_mode=mode):
         loss = step()                                     # not executed: recorded; `loss` is the graph's output buffer
     return graph, loss
 

@@ -18,6 +18,7 @@ def test_captured_step_with_rccl_allreduce(dev):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env["MASTER_PORT"] = "29547"
+    env.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")   # a watchdog complaint must not abort the rehearsal process
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "debug", "rccl_graph_step.py"), "2"], env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     tail = "\n".join(r.stdout.splitlines()[-15:])
