@@ -849,6 +849,12 @@ GCN_EXPORT int gcn_ballquery_batch_p(int n, int meanActive, float radius, const 
   return GCN_OK;
 }
 
+// for csrc/segdiam.hip: the exhaustive kernel over the tiles tile_prefix assigns (segments it leaves out own none)
+void launch_seg_diameter_tiles(int n, int S, int C, const float *feats, const float *xx, const int32_t *seg_offsets,
+                               const int32_t *tile_prefix, float *dmax2, hipStream_t st) {
+  seg_diameter_kernel<<<n / 64 + S, 256, 0, st>>>(S, C, feats, xx, seg_offsets, tile_prefix, (unsigned int *)dmax2);
+}
+
 GCN_EXPORT int gcn_segment_diameter2(int n, int C, const float *feats, const int32_t *seg_offsets,
                                      const int32_t *seg_cls, int S, float *xx_ws, int32_t *tile_ws, float *dmax2,
                                      void *stream) {

@@ -132,13 +132,19 @@ def forward_grouping_device(semantic_scores, pt_offsets, batch_idxs, coords_floa
 
     lib = _lib.lib()
     st = _lib.stream_of(shifted)
-    xx = torch.empty(n, dtype=torch.float32, device=dev)
-    tiles = torch.empty(S + 1, dtype=torch.int32, device=dev)
     dm = torch.empty(2, S, dtype=torch.float32, device=dev)
     with _lib.on_device(shifted):
         for f, d in ((fi, dm[0]), (fp, dm[1])):
-            _lib.call("gcn_segment_diameter2", n, f.shape[1], _lib.ptr(f), _lib.ptr(seg_offsets), _lib.ptr(seg_cls), S,
-                      _lib.ptr(xx), _lib.ptr(tiles), _lib.ptr(d), st)
+            nb = lib.gcn_segment_diameter2_ws_bytes(n, f.shape[1], S)
+            if 0 <= nb <= (4 << 30):     # bf16 tile prefilter + exact recheck: the same bits as the exhaustive kernel
+                dws = torch.empty(nb, dtype=torch.uint8, device=dev)
+                _lib.call("gcn_segment_diameter2_filtered", n, f.shape[1], _lib.ptr(f), _lib.ptr(seg_offsets),
+                          _lib.ptr(seg_cls), S, _lib.ptr(dws), _lib.ptr(d), st)
+            else:                        # > 1 M rows: the tile-pair table would not pay; exhaustive kernel
+                xx = torch.empty(n, dtype=torch.float32, device=dev)
+                tiles = torch.empty(S + 1, dtype=torch.int32, device=dev)
+                _lib.call("gcn_segment_diameter2", n, f.shape[1], _lib.ptr(f), _lib.ptr(seg_offsets), _lib.ptr(seg_cls),
+                          S, _lib.ptr(xx), _lib.ptr(tiles), _lib.ptr(d), st)
         grid_ws = torch.empty(lib.gcn_ballquery_sim_ws_bytes(n), dtype=torch.uint8, device=dev)
         ws = torch.empty(lib.gcn_cluster_components_ws_bytes(n), dtype=torch.uint8, device=dev)
         start_len = torch.empty(n, 2, dtype=torch.int32, device=dev)

@@ -179,6 +179,12 @@ int gcn_ballquery_batch_p(int n, int meanActive, float radius, const float *xyz,
  * seg_cls (S) (< 0: segment skipped, dmax2 = 0), xx_ws (n) floats, tile_ws (S+1) ints. */
 int gcn_segment_diameter2(int n, int C, const float *feats, const int32_t *seg_offsets, const int32_t *seg_cls, int S,
                           float *xx_ws, int32_t *tile_ws, float *dmax2, void *stream);
+/* The same result, bit for bit, from a bf16 tile-maximum prefilter on the matrix cores plus the exhaustive kernel's f32
+ * arithmetic on the few 64x64 tiles that can hold the maximum (csrc/segdiam.hip); 16 <= C <= 256.  ws: at least
+ * gcn_segment_diameter2_ws_bytes(n, C, S) bytes, 256-B aligned (-1: shape not supported). */
+long gcn_segment_diameter2_ws_bytes(int n, int C, int S);
+int gcn_segment_diameter2_filtered(int n, int C, const float *feats, const int32_t *seg_offsets, const int32_t *seg_cls,
+                                   int S, void *ws, float *dmax2, void *stream);
 long gcn_ballquery_sim_ws_bytes(int n);
 /* ballquery_batch_p with `adj_inst[p][k] > thr_inst && adj_para[p][k] > thr_para` evaluated from the feature rows:
  * adj = exp(-(||f_p - f_k|| / dmax)^2 / 2), 0 for p == k, NaN (never accepted) when dmax == 0.  One asynchronous pass:

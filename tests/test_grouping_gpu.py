@@ -219,6 +219,58 @@ def test_segment_diameter_matches_cdist(dev):
         np.testing.assert_allclose(got[s], ref, rtol=2e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("case", ["ragged", "blobs_large", "tight_blobs", "identical_rows", "one_outlier", "wide_c"])
+def test_filtered_segment_diameter_equals_exhaustive(dev, case):
+    """csrc/segdiam.hip (bf16 bound passes + exact recheck of the surviving 32x32 blocks) returns the bits of the
+    exhaustive f32 kernel: ragged and inactive segments, large blob segments (where the filter removes > 99 % of the
+    tiles), blobs tighter than bf16 resolves (most blocks survive: still the same bits), a segment of identical rows
+    (diameter 0 up to rounding: nothing can be discarded), a single far outlier, and C = 128."""
+    from gcanet_amd import _lib
+    rng = np.random.default_rng(11)
+    C = 128 if case == "wide_c" else 32
+    if case == "ragged":
+        sizes = [1, 70, 0, 333, 64, 1000, 129, 2, 65]
+        cls = [0, 1, 2, -1, 4, 5, 6, 7, 8]
+        f = rng.standard_normal((sum(sizes), C)).astype(np.float32)
+    elif case == "identical_rows":                         # 5000 copies of one row: every block is listed -> fall-back
+        sizes, cls = [500, 300, 5000], [0, 1, 2]
+        f = np.concatenate([np.tile(rng.standard_normal((1, C)), (500, 1)), rng.standard_normal((300, C)),
+                            np.tile(rng.standard_normal((1, C)), (5000, 1))]).astype(np.float32)
+    else:
+        sizes = [6000, 9000, 3000] if case != "wide_c" else [2500, 1500]
+        cls = list(range(len(sizes)))
+        parts = []
+        for m in sizes:                                    # a few blobs per segment, as trained features are
+            cen = rng.standard_normal((5, C)) * 3.0
+            parts.append(cen[rng.integers(0, 5, m)] + (0.003 if case == "tight_blobs" else 0.3) * rng.standard_normal((m, C)))
+        f = np.concatenate(parts).astype(np.float32)
+        if case == "one_outlier":
+            f[7] += 40.0
+    n, S = sum(sizes), len(sizes)
+    f = torch.from_numpy(f).to(dev)
+    offs = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int32, device=dev)
+    cls = torch.tensor(cls, dtype=torch.int32, device=dev)
+    xx = torch.empty(n, device=dev)
+    tiles = torch.empty(S + 1, dtype=torch.int32, device=dev)
+    ref = torch.full((S,), -1.0, device=dev)
+    got = torch.full((S,), -2.0, device=dev)
+    st = _lib.stream_of(f)
+    _lib.call("gcn_segment_diameter2", n, C, _lib.ptr(f), _lib.ptr(offs), _lib.ptr(cls), S, _lib.ptr(xx), _lib.ptr(tiles),
+              _lib.ptr(ref), st)
+    nb = _lib.lib().gcn_segment_diameter2_ws_bytes(n, C, S)
+    assert nb > 0
+    ws = torch.full((nb,), 0xA5, dtype=torch.uint8, device=dev)          # the entry point may not rely on a clean buffer
+    for _ in range(2):                                                   # and must be re-runnable on its own leftovers
+        _lib.call("gcn_segment_diameter2_filtered", n, C, _lib.ptr(f), _lib.ptr(offs), _lib.ptr(cls), S, _lib.ptr(ws),
+                  _lib.ptr(got), st)
+        assert torch.equal(got.view(torch.int32), ref.view(torch.int32)), (got, ref)
+    if case in ("blobs_large", "one_outlier", "tight_blobs"):
+        # layout of the workspace is private; the number of listed 32x32 blocks is the word after the S bounds (256-B aligned)
+        ncand = int(ws[((4 * S + 255) // 256) * 256:][:4].view(torch.int32)[0])
+        blocks = 4 * sum(((m + 63) // 64) * ((m + 63) // 64 + 1) // 2 for m in sizes)
+        assert 0 < ncand < blocks // 20, (ncand, blocks)
+
+
 def test_forward_grouping_device_edge_cases(dev):
     """No subset reaches min_npoint -> empty result (M4:1150 `continue` for every subset); a list buffer that is too
     small -> the retry with the reported capacity gives the same result as a large one."""
