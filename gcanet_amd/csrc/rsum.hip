@@ -1,6 +1,6 @@
 // rsum.hip -- the transposed graph aggregation of the closed-form EdgeConv backward,
 //     r[b,m,:] = sum over the edges (n -> m), i.e. idx[b,n,j] == m, of x[b,n,:]      indeg[b,m] = their number,
-// as STAGE + SORT + GATHER for the shapes of the model (C in {64,128}, N <= 16384), gfx950.
+// as STAGE + SORT + GATHER for the shapes of the model (C in {64,128,256}, N <= 16384), gfx950.
 //
 // reverse_sum_lds_kernel (edgeconv.hip) lets every destination partition scan the cloud's whole edge list and add
 // the matching source rows into LDS with ds_add_u64 -- bound by the LDS atomic rate (3 lane-operations per clock and
@@ -64,8 +64,8 @@ __device__ __forceinline__ long long fixed64(float v) {
 }
 
 __global__ __launch_bounds__(256) void rsum_file_kernel(RsumArgs a) {
-  __shared__ int bcnt[64];
-  if (threadIdx.x < 64) bcnt[threadIdx.x] = 0;
+  __shared__ int bcnt[256];                                     // one counter per destination partition (P <= 256)
+  bcnt[threadIdx.x] = 0;
   __syncthreads();
   int tile, b;
   xcd_tile_cloud(tile, b);
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void rsum_file_kernel(RsumArgs a) {
   if ((int)threadIdx.x < a.P) a.counts[((long)b * a.P + threadIdx.x) * a.T + tile] = min(bcnt[threadIdx.x], a.cap);
 }
 
-template <int CW>   // channels per lane: C = 64 * CW
+template <int CW, int U = 16>   // channels per lane: C = 64 * CW; U source rows in flight (and U more issued)
 __global__ __launch_bounds__(1024) void rsum_gather_kernel(RsumArgs a) {
   constexpr int C = 64 * CW;
   constexpr int R = 16384 / C;
@@ -163,7 +163,6 @@ __global__ __launch_bounds__(1024) void rsum_gather_kernel(RsumArgs a) {
     __syncthreads();
     // 3. a wave takes whole destination rows: gather the source rows, 16 loads in flight and the next 16 issued before
     //    the current ones are added (the kernel is bound by the latency of these L2 reads, not by their bandwidth)
-    constexpr int U = 16;
     for (int row = wave; row < R; row += 16) {
       const int cnt = hist[row], off = offs[row];
       long long acc[CW];
@@ -245,7 +244,7 @@ static RsumWs rsum_layout(int B, int N, int C, int k) {
   auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
   RsumWs w{};
   const int R = 16384 / C;
-  w.rshift = C == 64 ? 8 : 7;
+  w.rshift = C == 64 ? 8 : (C == 128 ? 7 : 6);                  // log2 of the R = 16384 / C rows of a partition
   w.P = N / R;
   w.tile_rows = 128;
   w.T = (N + 127) / 128;
@@ -260,7 +259,7 @@ static RsumWs rsum_layout(int B, int N, int C, int k) {
 }
 
 bool rsum_staged_supported(int B, int N, int C, int k) {
-  return B >= 1 && B <= 60 && (C == 64 || C == 128) && N <= 16384 && N % (16384 / C) == 0 && N / (16384 / C) <= 64 && k >= 1 &&
+  return B >= 1 && B <= 60 && (C == 64 || C == 128 || C == 256) && N <= 16384 && N % (16384 / C) == 0 && N / (16384 / C) <= 256 && k >= 1 &&
          (long)N * k < (1L << 31);
 }
 
@@ -281,9 +280,12 @@ int run_reverse_sum_staged(const float *x, const int64_t *idx, int B, int N, int
   if (C == 64) {
     GCN_HIP(hipFuncSetAttribute((const void *)rsum_gather_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb));
     rsum_gather_kernel<1><<<w.P * B, 1024, ldsb, st>>>(a);
-  } else {
+  } else if (C == 128) {
     GCN_HIP(hipFuncSetAttribute((const void *)rsum_gather_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb));
     rsum_gather_kernel<2><<<w.P * B, 1024, ldsb, st>>>(a);
+  } else {                                                      // C = 256: 8 rows in flight (16 waves share the CU's registers)
+    GCN_HIP(hipFuncSetAttribute((const void *)rsum_gather_kernel<4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb));
+    rsum_gather_kernel<4, 8><<<w.P * B, 1024, ldsb, st>>>(a);
   }
   return check_launch("rsum_gather_kernel");
 }

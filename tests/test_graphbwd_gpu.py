@@ -15,7 +15,8 @@ def _graph(B, N, k, C, dev, seed):
     return x, idx
 
 
-@pytest.mark.parametrize("B,N,k,C", [(2, 256, 16, 64), (1, 1000, 30, 6), (3, 333, 7, 128), (2, 2048, 64, 64), (1, 96, 80, 13)])
+@pytest.mark.parametrize("B,N,k,C", [(2, 256, 16, 64), (1, 1000, 30, 6), (3, 333, 7, 128), (2, 2048, 64, 64), (1, 96, 80, 13),
+                                      (2, 2048, 24, 256)])
 def test_reverse_and_neighbor_sum(dev, B, N, k, C):
     from gcanet_amd import _lib
     x, idx = _graph(B, N, k, C, dev, B * 100 + N + k + C)
@@ -44,9 +45,11 @@ def test_reverse_and_neighbor_sum(dev, B, N, k, C):
 
 
 @pytest.mark.parametrize("B,N,k,C,kind", [(2, 1024, 16, 64, "one_hub"), (1, 2048, 64, 64, "hub_partition"), (2, 512, 20, 128, "one_hub"),
-                                          (1, 4096, 32, 128, "random"), (3, 8192, 8, 64, "random")])
+                                          (1, 4096, 32, 128, "random"), (3, 8192, 8, 64, "random"),
+                                          (1, 16384, 16, 256, "random"), (2, 4096, 32, 256, "one_hub"),
+                                          (1, 2048, 64, 256, "hub_partition"), (1, 16384, 20, 128, "random")])
 def test_reverse_sum_staged_path_degenerate_graphs(dev, B, N, k, C, kind):
-    """The stage + sort + gather form (csrc/rsum.hip; C in {64,128}) on graphs that overflow a staging segment (every edge
+    """The stage + sort + gather form (csrc/rsum.hip; C in {64,128,256}) on graphs that overflow a staging segment (every edge
     to one node) or the LDS sort list (every edge into one partition): the overflow list and the accumulate-in-LDS path
     must give the same sums, in-degrees included, bitwise reproducibly."""
     from gcanet_amd import _lib
