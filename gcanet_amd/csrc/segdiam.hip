@@ -19,8 +19,8 @@
 //   3. exact    the listed blocks in EXACTLY the arithmetic of seg_diameter_kernel (same operand order of the same
 //               MFMAs), so the result is bit-identical to the exhaustive kernel (tests/test_grouping_gpu.py).
 // Passes 1 and 2 recompute instead of storing per-tile bounds: the bf16 products cost less than the cross-lane
-// reductions a stored per-tile maximum needs.  A workgroup owns a 64-row tile (A fragments stay in registers) and a strip
-// of up to 16 column tiles; the (row tile, strip) work items of all segments are numbered in closed form (no scan).
+// reductions a stored per-tile maximum needs.  A workgroup owns a 256-row tile (A fragments stay in registers) and a
+// strip of up to 16 column tiles staged through LDS; rows of 16 <= C <= 128 channels.
 // Segments of <= SD_SMALL_T row tiles, and every segment when more than a sixth of the blocks was listed (features that
 // f32 itself barely separates, e.g. identical rows), go through the exhaustive kernel instead -- decided on the device.
 #include "common.h"
@@ -89,11 +89,11 @@ __global__ __launch_bounds__(256) void sd_prep_kernel(SdArgs a) {
   }
 }
 
-// work items of a segment of T row tiles: row tile ta walks T - ta column tiles in ceil((T - ta) / SD_STRIP) strips
-__device__ __forceinline__ int sd_work_items(int T) {
-  const int q = T / SD_STRIP, rem = T % SD_STRIP;
-  return SD_STRIP * q * (q + 1) / 2 + rem * (q + 1);
-}
+// work items of a segment of T column tiles: a workgroup owns a 256-row tile A (column tiles 4 A ..) and one strip of
+// SD_STRIP column tiles; the items are numbered as a rectangle (row tile, strip) and the strips left of the diagonal
+// (no column tile >= 4 A in them) return at once -- a closed form of the triangle saves nothing at <= 2000 items
+__device__ __forceinline__ int sd_strips(int T) { return (T + SD_STRIP - 1) / SD_STRIP; }
+__device__ __forceinline__ int sd_work_items(int T) { return ((T + 3) / 4) * sd_strips(T); }
 
 __global__ void sd_prefix_kernel(SdArgs a) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -119,11 +119,19 @@ __global__ void sd_fallback_kernel(SdArgs a) {
 }
 
 // ------------------------------------------------------------------ 1. / 2. bound and select passes
-// PP: two operand buffers loaded alternately one column tile ahead (KS <= 4; beyond that the registers are spent on the
-// operands themselves and the waves of the other workgroups on the SIMD cover the latency).
-template <int KS, bool SELECT, bool PP>
-__global__ __launch_bounds__(256) void sd_pass_kernel(SdArgs a) {
+// 512 threads: wave w owns rows 32 w .. 32 w + 31 of the 256-row tile (its h and l fragments stay in registers) and both
+// 32-column halves of every column tile.  The (h | l) rows of a column tile are staged ONCE per workgroup in LDS (the
+// 64 x 64-tile form of this kernel had each wave fetch its own operands: 2 GB of L2 reads per pass, 0.28 ms, L2-bound),
+// double buffered: the global loads of tile tb + 1 are issued before the MFMAs of tile tb and stored after them, one
+// barrier per tile.  Staged rows are 16 bytes longer than the data so that 16 consecutive lanes' ds_read_b128 cover all
+// banks.
+template <int KS, bool SELECT>
+__global__ __launch_bounds__(512) void sd_pass_kernel(SdArgs a) {
   constexpr int Cb = KS * 16;
+  constexpr int ROWB = 4 * Cb + 16;                        // staged bytes per column: h (2 Cb) | l (2 Cb) | pad
+  constexpr int CPC = Cb / 4;                              // 16-byte chunks per column
+  constexpr int NCH = (64 * CPC + 511) / 512;              // chunks per thread
+  extern __shared__ __attribute__((aligned(16))) unsigned char sd_lds[];    // 2 x 64 x ROWB
   const int lane = lane_id(), wave = wave_id();
   const int lr = lane & 31, lh = lane >> 5;
   const int total = a.work_prefix[a.S];
@@ -137,19 +145,13 @@ __global__ __launch_bounds__(256) void sd_pass_kernel(SdArgs a) {
     const int sg = slo;
     const int beg = a.seg_offsets[sg], end = a.seg_offsets[sg + 1];
     const int T = (end - beg + 63) / 64;
-    // items are numbered by r = T - ta = 1, 2, ..: the SD_STRIP rows r in (SD_STRIP g, SD_STRIP (g + 1)] have g + 1 strips
-    // each, H g (g + 1) items before them (H = SD_STRIP / 2); tools/debug/sd_decode_check.py replays this on the host
-    constexpr int H = SD_STRIP / 2;
+    const int nstrip = sd_strips(T);
     const int q = w - a.work_prefix[sg];
-    int g = (int)((sqrtf(1.f + 4.f * (float)q / (float)H) - 1.f) * 0.5f);
-    while (g > 0 && H * g * (g + 1) > q) --g;
-    while (H * (g + 1) * (g + 2) <= q) ++g;
-    const int idx = q - H * g * (g + 1);
-    const int r = SD_STRIP * g + 1 + idx / (g + 1), strip = idx % (g + 1);
-    const int ta = T - r, tb0 = ta + strip * SD_STRIP, tb1 = min(T, tb0 + SD_STRIP);
+    const int A = q / nstrip;
+    const int tb0 = max(4 * A, (q % nstrip) * SD_STRIP), tb1 = min(T, (q % nstrip + 1) * SD_STRIP);
+    if (tb0 >= tb1) continue;                                  // strip left of the diagonal (uniform over the workgroup)
 
-    const int i0 = beg + ta * 64 + 32 * (wave & 1);            // this wave's 32 rows (first operand: register index)
-    const int jh = 32 * (wave >> 1);                           // its half of every column tile (second operand: lane)
+    const int i0 = beg + A * 256 + 32 * wave;                  // this wave's 32 rows (first operand: register index)
     const unsigned short *arow = a.fb + (long)min(i0 + lr, end - 1) * (2 * Cb) + lh * 8;
     sd_bf16x8 ah[KS], al[KS];
 #pragma unroll
@@ -163,58 +165,66 @@ __global__ __launch_bounds__(256) void sd_pass_kernel(SdArgs a) {
     const float Lseg = SELECT ? __uint_as_float(a.L[sg]) : 0.f;
     float run = 0.f;
 
-    struct Operand { sd_bf16x8 h[KS], l[KS]; float xj; };
-    auto load = [&](int tb, Operand &b) {
-      const int jc = min(beg + min(tb, tb1 - 1) * 64 + jh + lr, end - 1);
-      const unsigned short *brow = a.fb + (long)jc * (2 * Cb) + lh * 8;
+    sd_bf16x8 stage[NCH];
+    float xjn[2];
+    auto fetch = [&](int tb) {                                 // global -> registers: tile tb's (h | l) rows and norms
 #pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        b.h[s] = *reinterpret_cast<const sd_bf16x8 *>(brow + s * 16);
-        b.l[s] = *reinterpret_cast<const sd_bf16x8 *>(brow + Cb + s * 16);
+      for (int u = 0; u < NCH; ++u) {
+        const int c = (int)threadIdx.x + 512 * u;
+        if (64 * CPC >= 512 || c < 64 * CPC) {
+          const int jc = min(beg + tb * 64 + c / CPC, end - 1);
+          stage[u] = *reinterpret_cast<const sd_bf16x8 *>(a.fb + (long)jc * (2 * Cb) + (c % CPC) * 8);
+        }
       }
-      b.xj = a.xx[jc];
+      xjn[0] = a.xx[min(beg + tb * 64 + lr, end - 1)];
+      xjn[1] = a.xx[min(beg + tb * 64 + 32 + lr, end - 1)];
     };
-    auto block = [&](int tb, const Operand &b) {
-      sd_f32x16 acc;
+    auto store = [&](int buf) {                                // registers -> LDS
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s], b.h[s], acc, 0, 0, 0);     // small terms first
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], b.l[s], acc, 0, 0, 0);
-      }
-#pragma unroll
-      for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], b.h[s], acc, 0, 0, 0);
-      // clamped duplicate rows are real rows; i == j gives lo <= ~0 (never a maximum) and at worst one more listed block
-      const float xj = scale * b.xj;
-      float m = SELECT ? -1.f : run;
-#pragma unroll
-      for (int i = 0; i < 16; i += 2)
-        m = fmaxf(m, fmaxf(fmaf(-2.f, acc[i], xi[i] + xj), fmaf(-2.f, acc[i + 1], xi[i + 1] + xj)));
-      if (SELECT) {
-        if (__ballot(m >= Lseg) != 0ull && lane == 0)
-          a.cand[atomicAdd(a.ncand, 1u)] = make_int4(i0, beg + tb * 64 + jh, sg, 0);
-      } else {
-        run = m;
+      for (int u = 0; u < NCH; ++u) {
+        const int c = (int)threadIdx.x + 512 * u;
+        if (64 * CPC >= 512 || c < 64 * CPC)
+          *reinterpret_cast<sd_bf16x8 *>(sd_lds + buf * (64 * ROWB) + (c / CPC) * ROWB + (c % CPC) * 16) = stage[u];
       }
     };
-    if (PP) {
-      // the loads of tile tb + 1 are in flight during the MFMAs and the bound arithmetic of tile tb (a single rotating
-      // buffer made the compiler wait for every load at once)
-      Operand b0, b1;
-      load(tb0, b0);
-      for (int tb = tb0; tb < tb1; tb += 2) {
-        load(tb + 1, b1);
-        block(tb, b0);
-        load(tb + 2, b0);
-        if (tb + 1 < tb1) block(tb + 1, b1);
+    fetch(tb0);
+    store(0);
+    __syncthreads();
+    int cur = 0;
+    for (int tb = tb0; tb < tb1; ++tb) {
+      const float xj0 = scale * xjn[0], xj1 = scale * xjn[1];
+      if (tb + 1 < tb1) fetch(tb + 1);
+      const unsigned char *bt = sd_lds + cur * (64 * ROWB) + lh * 16;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const unsigned char *bcol = bt + (half * 32 + lr) * ROWB;
+        sd_f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          const sd_bf16x8 bh = *reinterpret_cast<const sd_bf16x8 *>(bcol + s * 32);
+          const sd_bf16x8 bl = *reinterpret_cast<const sd_bf16x8 *>(bcol + 2 * Cb + s * 32);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s], bh, acc, 0, 0, 0);       // small terms first
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], bl, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], bh, acc, 0, 0, 0);
+        }
+        // clamped duplicate rows are real rows; i == j gives lo <= ~0 (never a maximum) and at worst one more listed block
+        const float xj = half ? xj1 : xj0;
+        float m = SELECT ? -1.f : run;
+#pragma unroll
+        for (int i = 0; i < 16; i += 2)
+          m = fmaxf(m, fmaxf(fmaf(-2.f, acc[i], xi[i] + xj), fmaf(-2.f, acc[i + 1], xi[i + 1] + xj)));
+        if (SELECT) {
+          if (__ballot(m >= Lseg) != 0ull && lane == 0)
+            a.cand[atomicAdd(a.ncand, 1u)] = make_int4(i0, beg + tb * 64 + half * 32, sg, 0);
+        } else {
+          run = m;
+        }
       }
-    } else {
-      Operand b;
-      for (int tb = tb0; tb < tb1; ++tb) {
-        load(tb, b);
-        block(tb, b);
-      }
+      if (tb + 1 < tb1) store(cur ^ 1);
+      __syncthreads();                                         // tile tb + 1 is staged; every wave is done with tile tb
+      cur ^= 1;
     }
     if (!SELECT) {
 #pragma unroll
@@ -292,13 +302,13 @@ __global__ __launch_bounds__(256) void sd_exact_kernel(SdArgs a) {
 
 static size_t sd_align(size_t v) { return (v + 255) & ~(size_t)255; }
 static int sd_cb(int C) { int cb = 16; while (cb < C) cb *= 2; return cb; }
+constexpr int SD_CMAX = 128;                // wider rows: registers and LDS of the pass kernel; the caller keeps the exhaustive kernel
 struct SdWs { size_t L, ncand, work_prefix, tiles_small, tiles_large, fb, xx, cand, total; long blocks_max, work_max; };
 static SdWs sd_layout(int n, int C, int S) {
   SdWs w{};
   const long Tmax = (long)n / 64 + S + 1;                     // 64-row tiles of all segments together
   w.blocks_max = 4 * (Tmax * (Tmax + 1) / 2);                 // 32 x 32 blocks of all tile pairs a <= b
-  const long q = Tmax / SD_STRIP + 1;
-  w.work_max = SD_STRIP * q * (q + 1) / 2 + (long)S * SD_STRIP;
+  w.work_max = (Tmax / 4 + S + 1) * (Tmax / SD_STRIP + 1);
   size_t o = 0;
   w.L = o; o += sd_align(sizeof(unsigned int) * (size_t)S);          // L and ncand are zeroed together
   w.ncand = o; o += 256;
@@ -321,7 +331,7 @@ void launch_seg_diameter_tiles(int n, int S, int C, const float *feats, const fl
                                const int32_t *tile_prefix, float *dmax2, hipStream_t st);
 
 GCN_EXPORT long gcn_segment_diameter2_ws_bytes(int n, int C, int S) {
-  if (n < 0 || C < 16 || C % 16 != 0 || C > 256 || S < 0) return -1;
+  if (n < 0 || C < 16 || C % 16 != 0 || C > SD_CMAX || S < 0) return -1;
   const SdWs w = sd_layout(n, C, S);
   if (w.blocks_max > 0x7fffffffL) return -1;
   return (long)w.total;
@@ -329,7 +339,7 @@ GCN_EXPORT long gcn_segment_diameter2_ws_bytes(int n, int C, int S) {
 
 GCN_EXPORT int gcn_segment_diameter2_filtered(int n, int C, const float *feats, const int32_t *seg_offsets,
                                               const int32_t *seg_cls, int S, void *ws, float *dmax2, void *stream) {
-  GCN_REQUIRE(n >= 0 && S >= 0 && C >= 16 && C % 16 == 0 && C <= 256, "gcn_segment_diameter2_filtered: C must be a multiple of 16 in [16, 256] (zero-pad the rows), got C=%d", C);
+  GCN_REQUIRE(n >= 0 && S >= 0 && C >= 16 && C % 16 == 0 && C <= SD_CMAX, "gcn_segment_diameter2_filtered: C must be a multiple of 16 in [16, 128] (zero-pad the rows; gcn_segment_diameter2 beyond), got C=%d", C);
   if (n == 0 || S == 0) return GCN_OK;
   GCN_REQUIRE(feats && seg_offsets && seg_cls && ws && dmax2, "gcn_segment_diameter2_filtered: null pointer");
   GCN_REQUIRE(((uintptr_t)ws & 255) == 0 && ((uintptr_t)feats & 15) == 0, "gcn_segment_diameter2_filtered: ws must be 256-B aligned, feats 16-B aligned");
@@ -348,16 +358,20 @@ GCN_EXPORT int gcn_segment_diameter2_filtered(int n, int C, const float *feats, 
   GCN_HIP(fill_dev(dmax2, 0, sizeof(float) * (size_t)S, st));
   sd_prep_kernel<<<cdiv((long)n * (a.Cb / 8), 256), 256, 0, st>>>(a);
   sd_prefix_kernel<<<1, 1, 0, st>>>(a);
-  const int grid = (int)(w.work_max < 8192 ? w.work_max : 8192);
-#define SD_PASSES(KS)                                                \
-  sd_pass_kernel<KS, false, (KS <= 4)><<<grid, 256, 0, st>>>(a);     \
-  sd_pass_kernel<KS, true, (KS <= 4)><<<grid, 256, 0, st>>>(a)
+  const int grid = (int)(w.work_max < 2048 ? w.work_max : 2048);
+#define SD_PASSES(KS)                                                                                               \
+  {                                                                                                                 \
+    constexpr int LDSB = 2 * 64 * (4 * KS * 16 + 16);                                                               \
+    GCN_HIP(hipFuncSetAttribute((const void *)sd_pass_kernel<KS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB)); \
+    GCN_HIP(hipFuncSetAttribute((const void *)sd_pass_kernel<KS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));  \
+    sd_pass_kernel<KS, false><<<grid, 512, LDSB, st>>>(a);                                                          \
+    sd_pass_kernel<KS, true><<<grid, 512, LDSB, st>>>(a);                                                           \
+  }
   switch (a.Cb) {
     case 16: SD_PASSES(1); break;
     case 32: SD_PASSES(2); break;
     case 64: SD_PASSES(4); break;
-    case 128: SD_PASSES(8); break;
-    default: SD_PASSES(16); break;
+    default: SD_PASSES(8); break;
   }
 #undef SD_PASSES
   sd_fallback_kernel<<<1, 1, 0, st>>>(a);
