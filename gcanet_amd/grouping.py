@@ -32,9 +32,16 @@ def compute_batch_adjacency_matrix(batch_point_clouds, radius=0, dist_state=True
     return adjacency - torch.diag_embed(torch.diagonal(adjacency, dim1=-2, dim2=-1))
 
 
+def _counts(idx, n):
+    """Occurrences of 0..n-1 in idx (other values must not occur).  torch.bincount reads the maximum back to size its
+    result -- a host synchronisation per call, three per literal training step -- the callers here know n."""
+    idx = idx.reshape(-1).long()
+    return torch.zeros(n, dtype=torch.int64, device=idx.device).scatter_add_(0, idx, torch.ones_like(idx))
+
+
 def get_batch_offsets(batch_idxs, bs):
     """M4:1372-1377 -> int32 (bs+1) on the device of batch_idxs."""
-    counts = torch.bincount(batch_idxs.reshape(-1).long(), minlength=bs)[:bs]
+    counts = _counts(batch_idxs, bs)
     return torch.cat([counts.new_zeros(1), torch.cumsum(counts, 0)]).int()
 
 
@@ -121,7 +128,7 @@ def forward_grouping_device(semantic_scores, pt_offsets, batch_idxs, coords_floa
     labels = semantic_scores.softmax(dim=-1).view(n, -1).argmax(dim=1)
     seg_key = torch.arange(B, device=dev).repeat_interleave(N) * P + labels
     seg_sorted, order = torch.sort(seg_key, stable=True)
-    counts = torch.bincount(seg_sorted, minlength=S)
+    counts = _counts(seg_sorted, S)
     seg_offsets = torch.cat([counts.new_zeros(1), counts.cumsum(0)]).int()
     seg_cls = torch.where(counts >= min_npoint, torch.arange(S, device=dev) % P, torch.full_like(counts, -1)).int()
     seg_of = seg_sorted.int()
@@ -239,8 +246,9 @@ def clusters_voxelization(clusters_idx, clusters_offset, feats, coords, scale, s
     return out_feats, out_coords.int().to(dev), [spatial_shape] * 3, nb, inp_map
 
 
-def global_pool(features, indices):
-    """M4:1358-1370 (expand=False): per-sample mean of sparse-tensor features; indices = first coord column."""
-    batch_counts = torch.bincount(indices.long())
+def global_pool(features, indices, batch_size=None):
+    """M4:1358-1370 (expand=False): per-sample mean of sparse-tensor features; indices = first coord column.
+    batch_size: number of samples when the caller knows it (no read-back of max(indices))."""
+    batch_counts = torch.bincount(indices.long()) if batch_size is None else _counts(indices, batch_size)
     batch_offset = torch.cat([batch_counts.new_zeros(1), torch.cumsum(batch_counts, 0)]).int()
     return global_avg_pool(features.float().contiguous(), batch_offset)

@@ -327,5 +327,5 @@ class InstanceHead(nn.Module):
         feats = self.tiny_unet_outputlayer(self.tiny_unet(inst_feats))
         mask_scores = self.mask_linear(feats.features).index_select(0, inst_map.long())   # backward = one index_add
         instance_batch_idxs = feats.indices[:, 0][inst_map.long()]
-        pooled = global_pool(feats.features, feats.indices[:, 0])
+        pooled = global_pool(feats.features, feats.indices[:, 0], feats.batch_size)
         return instance_batch_idxs, self.cls_linear(pooled), self.iou_score_linear(pooled), mask_scores
