@@ -188,6 +188,33 @@ def pmc_traffic(tag):
     return None
 
 
+def full_workload_roofline():
+    """`roofline` of the literal step's dominant own kernel, from the committed profiles of tools/full_profile.py
+    (profiles/r03_full_workload_kernel_stats.csv: rocprofv3 --kernel-trace --stats; r03_full_pmc_traffic.json: separate
+    --pmc FETCH_SIZE / WRITE_SIZE passes).  The kernels of that step are gathers and scans over irregular lists: the
+    bound named is HBM, `achieved` is the PMC traffic over the kernel's average duration.  None without the files."""
+    import csv
+    sp = os.path.join(ROOT, "profiles", "r03_full_workload_kernel_stats.csv")
+    tp = os.path.join(ROOT, "profiles", "r03_full_pmc_traffic.json")
+    if not (os.path.exists(sp) and os.path.exists(tp)):
+        return None
+    rows = [r for r in csv.DictReader(open(sp)) if "gcn::" in r["Name"][:20]]
+    if not rows:
+        return None
+    top = max(rows, key=lambda r: int(r["TotalDurationNs"]))
+    name = top["Name"].strip('"').replace("void ", "").split("(")[0]
+    rec = json.load(open(tp))["kernels"].get(name)
+    avg_ms = float(top["AverageNs"]) / 1e6
+    out = {"kernel": name, "bound": "hbm", "avg_launch_ms": round(avg_ms, 4), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+           "source": "profiles/r03_full_workload_kernel_stats.csv + r03_full_pmc_traffic.json (not measured live)"}
+    if rec:
+        ach = rec["hbm_bytes_corrected"] / (avg_ms * 1e-3) / 1e9
+        out.update(traffic=rec["hbm_bytes_corrected"], achieved=round(ach, 1), frac=round(ach / PEAK_HBM_GBS, 4))
+    else:
+        out.update(traffic=None, achieved=None, frac=None)
+    return out
+
+
 def cpu_baseline(N, k, seconds_budget=30.0):
     """The same hot-path step (fwd+bwd, fp32) through the CPU oracle on ONE cloud; all host cores.  One untimed
     warm-up, then best of up to 5 timed runs inside a ~30-s budget so that the default run stays short."""
@@ -258,16 +285,17 @@ def full_workload(args, dev, steps=5, warmup=2):
     sem = inst_cls[inst]                                                               # (B*N,)
     rand = (torch.full((3,), 0.5), torch.full((3,), 0.5))
     info = {}
+    from gcanet_amd.layers import ZeroArena
+    own_arena = ZeroArena(dev) if ZeroArena.live is None else None     # the headline step's arena when bench.py made one
 
     def step():
-        from gcanet_amd.layers import ZeroArena
         if ZeroArena.live is not None:
             ZeroArena.live.begin_step()
         opt.zero_grad(set_to_none=True)
         casts.refresh()
         with torch.autocast("cuda", dtype=torch.bfloat16):
             (type_pp, param_pp, sem_scores, off, ibi, cls_s, iou_s, mask_s, pidx, poff, feats) = net(pts, nrm, rand=rand)
-        loss = compute_embedding_loss(feats.float(), lab)[0].sum() \
+        loss = compute_embedding_loss(feats.float(), lab, num_labels=blobs)[0].sum() \
             + torch.nn.functional.nll_loss(type_pp.float().reshape(-1, type_pp.shape[-1]), sem) \
             + off.float().abs().mean() \
             + instance_loss(cls_s.float(), mask_s.float(), iou_s.float(), pidx, poff, inst, pointnum, inst_cls, ibi)
@@ -283,6 +311,8 @@ def full_workload(args, dev, steps=5, warmup=2):
         step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    if own_arena is not None:
+        own_arena.close()
     return {"workload": "literal forward_train (M4:634-777: hot path + device forward_grouping + clusters_voxelization + "
                         "sparse instance head) + embedding/instance/NLL/offset losses + backward + Adam; %d blob clouds "
                         "N=%d k=%d (%d blobs each)" % (B, N, k, blobs),
@@ -736,6 +766,8 @@ def main():
         res["north_star"] = guarded(lambda: north_star_rooflines(dev))
     if world == 1 and not args.no_full:
         res["full_workload"] = guarded(lambda: full_workload(args, dev))
+        if isinstance(res["full_workload"], dict) and "ms_per_step" in res["full_workload"]:
+            res["full_workload"]["roofline"] = full_workload_roofline()
         res["cfg5_workload"] = guarded(lambda: cfg5_workload(dev))
     if world == 1 and not args.no_cpu_baseline:
         res["forward_grouping"] = guarded(lambda: grouping_times(args.k, B, N, dev))

@@ -12,14 +12,16 @@ import torch.nn.functional as F
 from .softgroup.ops import get_mask_iou_on_cluster, get_mask_iou_on_pred, get_mask_label
 
 
-def compute_embedding_loss(pred_feat, gt_label, t_pull=0.5, t_push=1.5):
+def compute_embedding_loss(pred_feat, gt_label, t_pull=0.5, t_push=1.5, num_labels=None):
     """pred_feat (B,N,K) float, gt_label (B,N) int (>= -1).  Returns (loss, pull, push), each of shape (1,) as in the
     reference.  Per cloud: pull = mean over present labels of mean_i relu(|f_i - c_label| - t_pull); push = mean over
     ordered pairs of distinct present labels of relu(t_push - |c_a - c_b|), skipped when only one label is present."""
     B, N, K = pred_feat.shape
     dev = pred_feat.device
     lab = gt_label.long() + 1                                   # -1 becomes segment 0 (loss_utils.py:216-219)
-    L = int(lab.max()) + 1                                      # segments per cloud
+    # segments per cloud; num_labels (an upper bound of gt_label.max() + 1 the data loader knows) avoids reading the
+    # maximum back: a host synchronisation in the middle of every training step
+    L = int(lab.max()) + 1 if num_labels is None else int(num_labels) + 1
     seg = (torch.arange(B, device=dev).view(B, 1) * L + lab).reshape(-1)        # (B*N) segment id
     f = pred_feat.reshape(B * N, K)
     cnt = torch.zeros(B * L, device=dev, dtype=f.dtype).index_add_(0, seg, torch.ones_like(seg, dtype=f.dtype))

@@ -22,3 +22,8 @@ rm -rf /tmp/pfull
 rocprofv3 --kernel-trace --stats -f csv -d /tmp/pfull -- python3 $R/tools/full_profile.py 5 2 > $O/${T}_full.log 2>&1
 cp /tmp/pfull/*/*_kernel_stats.csv $O/${T}_full_workload_kernel_stats.csv
 echo "full workload stats done"
+rm -rf /tmp/pff /tmp/pfw
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d /tmp/pff -- python3 $R/tools/full_profile.py 2 1 > $O/${T}_full_pf.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d /tmp/pfw -- python3 $R/tools/full_profile.py 2 1 > $O/${T}_full_pw.log 2>&1
+python3 $R/tools/pmc_traffic.py /tmp/pff/*/*counter_collection.csv /tmp/pfw/*/*counter_collection.csv $O/${T}_full_pmc_traffic.json
+echo "full workload traffic done"
