@@ -837,7 +837,8 @@ class PrimitivesEmbeddingDGCNGn(nn.Module):
         Activations are point-major (B,N,C) end to end; the reference's (B,C,N) Conv1d tensors are the same
         values transposed.  conv1 on cat[x4 repeated, x_features] (M4:510-511,644) is evaluated as
         W[:, :1024].x4 (once per cloud) + W[:, 1024:].x_features -- identical, 5x fewer FLOPs."""
-        from .layers import add_row_broadcast, conv1x1, conv1x1_gn_relu, group_norm_relu, linear_pm, param_normalise
+        from .layers import (add_row_broadcast, cat_conv1x1_gn_relu, conv1x1, conv1x1_gn_relu, group_norm_relu, linear_pm,
+                             param_normalise)
         B, N, _ = points.shape
         pts = torch.cat([points, normals], dim=-1).contiguous() if self.mode == 5 else points.contiguous()   # (B,N,6)
         pts_cm = pts.transpose(1, 2).contiguous()
@@ -872,15 +873,16 @@ class PrimitivesEmbeddingDGCNGn(nn.Module):
             ef = torch.cat((angle, n_j - n_i, n_i.expand_as(n_j)), dim=3)                      # (B,N,k,7)
             normal_feature = grouped_block(ef, self.conv_normal[0].weight, self.bn_normal.weight, self.bn_normal.bias, 2,
                                            self.bn_normal.eps, 0.2, self.dtype, pm_out=True)   # (B,N,64)
-        x = torch.cat([x_all, x_type, x_para, normal_feature.to(x_all.dtype)], dim=2)          # (B,N,832)
-        x = conv1x1_gn_relu(x, self.mlp_seg_prob1, self.bn_seg_prob1)
+        # cat -> (B,N,832) -> conv: the concatenation belongs to the layer, whose backward hands every part a contiguous
+        # gradient (layers.py: CatLinearPMFunction)
+        x = cat_conv1x1_gn_relu([x_all, x_type, x_para, normal_feature], self.mlp_seg_prob1, self.bn_seg_prob1)
         output_feats = conv1x1(x, self.mlp_seg_prob2).float()                                  # (B,N,emb)
         # (B,N,262) -> zero columns up to a multiple of 16: the GEMM kernel's k-step (the cat copies anyway)
         kin = x_all.shape[2] + pts.shape[2]
-        parts = [x_all, pts.to(x_all.dtype)]
+        parts = [x_all, pts]
         if pts.is_cuda and kin % 16:
             parts.append(torch.zeros(B, N, (kin + 15) // 16 * 16 - kin, dtype=x_all.dtype, device=pts.device))
-        feat_plus = conv1x1_gn_relu(torch.cat(parts, dim=2), self.conv3, self.bn3)             # (B,N,128)
+        feat_plus = cat_conv1x1_gn_relu(parts, self.conv3, self.bn3)                           # (B,N,128); only x_all has a gradient
         semantic_scores = type_forgroup.reshape(-1, type_forgroup.shape[-1])
         feat_in = feat_plus if (feat_plus.is_cuda and torch.is_autocast_enabled()) else feat_plus.float()
         pt_offsets = self.offset_pred_block(pts[:, :, 0:3], feat_in, output_feats, pm_out=True, topk_idx=topk_idx)
