@@ -511,6 +511,21 @@ __global__ __launch_bounds__(256) void ballquery_sim_kernel(int n, float radius2
     pi[u] = c < Ci4 ? reinterpret_cast<const float4 *>(sa.fi)[(long)p * Ci4 + c] : float4{0.f, 0.f, 0.f, 0.f};
     pp[u] = c < Cp4 ? reinterpret_cast<const float4 *>(sa.fp)[(long)p * Cp4 + c] : float4{0.f, 0.f, 0.f, 0.f};
   }
+  // A threshold <= 0 needs no distance: d <= dmax inside a segment, so exp(-(d/dmax)^2 / 2) >= 0.6 > thr for every other
+  // point (0 on the diagonal, NaN -- never accepted -- when dmax == 0), and the rows of that feature set are not
+  // gathered at all (the reference's similarity_threshold_para is 0.0, M4:1140).  Guard: the diameter comes from the
+  // expanded form, whose noise floor is ~1e-6 |f|^2 -- only where it stands clear of that (dmax^2 >= 1e-4 |f_p|^2) is
+  // d^2 < 208 dmax^2 (no underflow of the exponential to 0) certain; other points take the exact evaluation.
+  auto row_sq = [&](const float4 (&r)[4]) -> float {
+    float q = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) q = fmaf(r[u].x, r[u].x, fmaf(r[u].y, r[u].y, fmaf(r[u].z, r[u].z, fmaf(r[u].w, r[u].w, q))));
+    q += __shfl_xor(q, 8); q += __shfl_xor(q, 4); q += __shfl_xor(q, 2); q += __shfl_xor(q, 1);
+    return q;
+  };
+  const float dmi2v = sa.dmi2[sg], dmp2v = sa.dmp2[sg];
+  const bool fast_i = sa.thr_i <= 0.f && dmi2v > 0.f && dmi2v < __builtin_inff() && dmi2v >= 1e-4f * row_sq(pi);
+  const bool fast_p = sa.thr_p <= 0.f && dmp2v > 0.f && dmp2v < __builtin_inff() && dmp2v >= 1e-4f * row_sq(pp);
   auto in_radius = [&](int kk) -> bool {
     return sqdist3s(ox, oy, oz, xyz[kk * 3], xyz[kk * 3 + 1], xyz[kk * 3 + 2]) < radius2;
   };
@@ -521,10 +536,21 @@ __global__ __launch_bounds__(256) void ballquery_sim_kernel(int n, float radius2
     for (int i0 = 0; i0 < m; i0 += 8) {
       const int ia = i0 + grp, ib = i0 + 4 + grp;
       const int ka = ia < m ? ids[ia] : p, kb = ib < m ? ids[ib] : p;
-      const float dia = row_dist2_16(pi, sa.fi, Ci4, ka, sub), dib = row_dist2_16(pi, sa.fi, Ci4, kb, sub);
-      const float dpa = row_dist2_16(pp, sa.fp, Cp4, ka, sub), dpb = row_dist2_16(pp, sa.fp, Cp4, kb, sub);
-      const bool oka = ia < m && sub == 0 && sim_from_dist2(dia, dmi, ka == p) > sa.thr_i && sim_from_dist2(dpa, dmp, ka == p) > sa.thr_p;
-      const bool okb = ib < m && sub == 0 && sim_from_dist2(dib, dmi, kb == p) > sa.thr_i && sim_from_dist2(dpb, dmp, kb == p) > sa.thr_p;
+      float sia, sib, spa, spb;                                          // the two similarities of the two candidates
+      if (fast_i) {                                                      // wave-uniform
+        sia = ka == p ? 0.f : 1.f; sib = kb == p ? 0.f : 1.f;            // any value in (thr, 1] decides the same
+      } else {
+        const float dia = row_dist2_16(pi, sa.fi, Ci4, ka, sub), dib = row_dist2_16(pi, sa.fi, Ci4, kb, sub);
+        sia = sim_from_dist2(dia, dmi, ka == p); sib = sim_from_dist2(dib, dmi, kb == p);
+      }
+      if (fast_p) {
+        spa = ka == p ? 0.f : 1.f; spb = kb == p ? 0.f : 1.f;
+      } else {
+        const float dpa = row_dist2_16(pp, sa.fp, Cp4, ka, sub), dpb = row_dist2_16(pp, sa.fp, Cp4, kb, sub);
+        spa = sim_from_dist2(dpa, dmp, ka == p); spb = sim_from_dist2(dpb, dmp, kb == p);
+      }
+      const bool oka = ia < m && sub == 0 && sia > sa.thr_i && spa > sa.thr_p;
+      const bool okb = ib < m && sub == 0 && sib > sa.thr_i && spb > sa.thr_p;
       const unsigned long long ma = __ballot(oka), mb = __ballot(okb);
       const unsigned long long lt = (1ull << lane) - 1ull;
       if (oka) ids[kept + __popcll(ma & lt)] = ka;                     // slots never run ahead of the reads

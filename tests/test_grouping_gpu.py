@@ -71,6 +71,32 @@ def test_forward_grouping_matches_oracle(dev):
     np.testing.assert_array_equal(pi.numpy(), rpi)
 
 
+@pytest.mark.parametrize("thr_i,thr_p,feat_kind", [(-0.2, 0.0, "blobs"), (0.0, -1.0, "blobs"), (0.0, 0.0, "nearly_identical"),
+                                                   (0.0, 0.0, "identical")])
+def test_forward_grouping_device_threshold_shortcuts(dev, thr_i, thr_p, feat_kind):
+    """csrc/softgroup.hip: ballquery_sim_kernel decides a similarity test with threshold <= 0 without gathering the
+    rows (d <= dmax inside a segment).  Same proposals as the CPU restatement for negative thresholds (the zero
+    diagonal passes), for features identical up to 1e-6 (the guard keeps the exact evaluation: the expanded-form
+    diameter is noise there) and for exactly identical features (dmax = 0: NaN similarities, nothing passes)."""
+    from gcanet_amd.grouping import forward_grouping_device
+    B, N, P = 2, 1500, 3
+    xyz, sem, off, bidx, par, feat = _blob_scene(5, B, N, P, 6)
+    rng = np.random.default_rng(9)
+    if feat_kind == "nearly_identical":
+        feat = (1.0 + 1e-6 * rng.standard_normal(feat.shape)).astype(np.float32)
+    elif feat_kind == "identical":
+        feat = np.ones_like(feat)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    pi, po = forward_grouping_device(t(sem), t(off), t(bidx), t(xyz.reshape(-1, 3)), torch.zeros(B, N, P), t(par), t(feat),
+                                     semantic_classes=P, radius=0.03, similarity_threshold_inst=thr_i,
+                                     similarity_threshold_para=thr_p, mean_active=300, min_npoint=20)
+    rpi, rpo = _oracle_forward_grouping(sem, off, bidx, xyz.reshape(-1, 3), B, N, par, feat, P, 0.03, thr_i, thr_p, 300, 20)
+    if feat_kind == "blobs":
+        assert rpo.size > 4, "test data produced no clusters"
+    np.testing.assert_array_equal(po.cpu().numpy(), rpo)
+    np.testing.assert_array_equal(pi.cpu().numpy(), rpi)
+
+
 def test_clusters_voxelization_and_global_pool(dev):
     from gcanet_amd.grouping import clusters_voxelization, global_pool
     rng = np.random.default_rng(1)
