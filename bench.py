@@ -293,12 +293,17 @@ def full_workload(args, dev, steps=5, warmup=2):
             ZeroArena.live.begin_step()
         opt.zero_grad(set_to_none=True)
         casts.refresh()
+        def point_losses(out):      # the losses on per-point predictions: enqueued before forward_grouping's host wait
+            with torch.autocast("cuda", enabled=False):
+                tp = out["type_per_point"]
+                return compute_embedding_loss(out["output_feats"].float(), lab, num_labels=blobs)[0].sum() \
+                    + torch.nn.functional.nll_loss(tp.float().reshape(-1, tp.shape[-1]), sem) \
+                    + out["pt_offsets"].float().abs().mean()
+
         with torch.autocast("cuda", dtype=torch.bfloat16):
-            (type_pp, param_pp, sem_scores, off, ibi, cls_s, iou_s, mask_s, pidx, poff, feats) = net(pts, nrm, rand=rand)
-        loss = compute_embedding_loss(feats.float(), lab, num_labels=blobs)[0].sum() \
-            + torch.nn.functional.nll_loss(type_pp.float().reshape(-1, type_pp.shape[-1]), sem) \
-            + off.float().abs().mean() \
-            + instance_loss(cls_s.float(), mask_s.float(), iou_s.float(), pidx, poff, inst, pointnum, inst_cls, ibi)
+            (type_pp, param_pp, sem_scores, off, ibi, cls_s, iou_s, mask_s, pidx, poff, feats, lpt) = \
+                net(pts, nrm, rand=rand, early=point_losses)
+        loss = lpt + instance_loss(cls_s.float(), mask_s.float(), iou_s.float(), pidx, poff, inst, pointnum, inst_cls, ibi)
         loss.backward()
         opt.step()
         info.update(proposals=int(poff.shape[0]) - 1, members=int(pidx.shape[0]), loss=float(loss.detach()))

@@ -20,11 +20,16 @@ class GCANet(nn.Module):
         self.semantic_classes, self.max_proposal_num = num_primitives, max_proposal_num
         self.grouping_cfg = dict(grouping_cfg or {})
 
-    def forward(self, points, normals, rand=None):
+    def forward(self, points, normals, rand=None, early=None):
         """points, normals (B,N,3).  Returns (type_per_point, param_per_point, semantic_scores, pt_offsets,
-        instance_batch_idxs, cls_scores, iou_scores, mask_scores, proposals_idx, proposals_offset, output_feats)."""
+        instance_batch_idxs, cls_scores, iou_scores, mask_scores, proposals_idx, proposals_offset, output_feats).
+        early: optional callable on the hot path's output dict, called before forward_grouping (whose proposal count is
+        a host synchronisation): work that depends on the per-point predictions only -- the per-point losses of a
+        training step -- is then enqueued while the device is still busy with the hot path instead of after the wait.
+        Its return value is appended to the outputs."""
         B, N, _ = points.shape
         out = self.point_net(points, normals)
+        extra = early(out) if early is not None else None
         batch_idxs = torch.arange(B, device=points.device).repeat_interleave(N)
         coords_float = points.reshape(-1, 3)
         with torch.no_grad():
@@ -40,6 +45,7 @@ class GCANet(nn.Module):
                                                             spatial_shape=64, rand_quantize=True, rand=rand, inp_map_on_device=True)
         inst = SparseConvTensor(vf, vc, shape, nb)
         instance_batch_idxs, cls_scores, iou_scores, mask_scores = self.instance_head(inst, inst_map.to(points.device))
-        return (out["type_per_point"], out["param_per_point"], out["semantic_scores"], out["pt_offsets"],
-                instance_batch_idxs, cls_scores, iou_scores, mask_scores, proposals_idx, proposals_offset,
-                out["output_feats"])
+        res = (out["type_per_point"], out["param_per_point"], out["semantic_scores"], out["pt_offsets"],
+               instance_batch_idxs, cls_scores, iou_scores, mask_scores, proposals_idx, proposals_offset,
+               out["output_feats"])
+        return res if early is None else res + (extra,)
