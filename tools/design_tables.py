@@ -6,7 +6,8 @@ in DESIGN.md is the current one and names the file it came from:
 Sources: r03_bench.json (the driver-style bench line), r03_kernel_stats.csv (rocprofv3 --kernel-trace --stats of the same
 command: 13 replayed + 3 eager steps, plus the untimed north-star legs), r03_pmc_traffic.json (separate --pmc FETCH_SIZE
 / WRITE_SIZE passes, gfx950 read correction applied), r03_full_workload_kernel_stats.csv, r03_cfg5_kernel_stats.csv,
-r03_bench_refshape.json, r03_bench_eager.json, r03_gemm_bench.log, r03_knn_fallback.log."""
+r03_bench_refshape.json, r03_bench_eager.json, r03_gemm_bench.log, r03_knn_fallback.log, r03_segdiam_bench.log,
+r03_full_pmc_traffic.json."""
 import csv
 import json
 import os
@@ -65,6 +66,10 @@ def t_headline():
     fw, c5, fg, cb = d["full_workload"], d["cfg5_workload"], d["forward_grouping"], d["cpu_baseline"]
     L.append("| literal full `forward_train` + losses + backward + Adam on blob clouds | %.2f ms/step, %.0f clouds/s, %d proposals, %d members | `r03_bench.json: full_workload` |"
              % (fw["ms_per_step"], fw["clouds_per_s"], fw["proposals"], fw["members"]))
+    fr = fw.get("roofline")
+    if fr and fr.get("achieved"):
+        L.append("| its dominant own kernel (`%s`) | %.3f ms per launch, %.0f MB of HBM traffic (PMC) = %.0f GB/s = %.1f %% of 8 TB/s: an L2-resident gather, not an HBM stream | `r03_full_workload_kernel_stats.csv`, `r03_full_pmc_traffic.json` |"
+                 % (fr["kernel"].replace("gcn::", ""), fr["avg_launch_ms"], fr["traffic"] / 1e6, fr["achieved"], 100 * fr["frac"]))
     L.append("| BASELINE configs[4], one GPU's share (4 clouds N=16384, C=256 EdgeConv, fp16 attention stacks) | %.2f ms/step, %.0f clouds/s | `r03_bench.json: cfg5_workload` |"
              % (c5["ms_per_step"], c5["clouds_per_s"]))
     L.append("| `forward_grouping`, device vs literal path | %.2f ms vs %.1f ms, %d proposals / %d members, identical: %s | `r03_bench.json: forward_grouping` |"
@@ -136,6 +141,7 @@ GEN = {
     "cfg5": lambda: t_other("r03_cfg5_kernel_stats.csv", 5, top=10),
     "gemm": lambda: t_log("r03_gemm_bench.log"),
     "knn_cases": lambda: t_log("r03_knn_fallback.log"),
+    "segdiam": lambda: t_log("r03_segdiam_bench.log"),
 }
 
 
