@@ -245,7 +245,8 @@ def test_segment_diameter_matches_cdist(dev):
         np.testing.assert_allclose(got[s], ref, rtol=2e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("case", ["ragged", "blobs_large", "tight_blobs", "identical_rows", "one_outlier", "wide_c"])
+@pytest.mark.parametrize("case", ["ragged", "blobs_large", "tight_blobs", "identical_rows", "one_outlier", "wide_c",
+                                  "big_offset", "random_sizes"])
 def test_filtered_segment_diameter_equals_exhaustive(dev, case):
     """csrc/segdiam.hip (bf16 bound passes + exact recheck of the surviving 32x32 blocks) returns the bits of the
     exhaustive f32 kernel: ragged and inactive segments, large blob segments (where the filter removes > 99 % of the
@@ -272,6 +273,12 @@ def test_filtered_segment_diameter_equals_exhaustive(dev, case):
         f = np.concatenate(parts).astype(np.float32)
         if case == "one_outlier":
             f[7] += 40.0
+    if case == "big_offset":        # |f| >> diameter: the error bound scales with the norms, most blocks survive -> still exact
+        f = f + 100.0
+    if case == "random_sizes":      # segment sizes around the small/large routing limit and around tile multiples
+        sizes = [int(v) for v in rng.integers(1, 5000, 12)] + [2048, 2049, 4096, 4097]
+        cls = [(-1 if i % 5 == 4 else i) for i in range(len(sizes))]
+        f = (rng.standard_normal((sum(sizes), C)) * rng.uniform(0.01, 30.0, (sum(sizes), 1))).astype(np.float32)
     n, S = sum(sizes), len(sizes)
     f = torch.from_numpy(f).to(dev)
     offs = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int32, device=dev)
