@@ -361,7 +361,7 @@ def cfg5_workload(dev, B=4, N=16384, k=64, steps=3, warmup=2):
             out = net(pts, nrm)
             xf = net.last_xf                                                       # (B,N,256)
             gn = wide._modules["1"]
-            xw, _ = dgcnn.edge_conv_pm(xf.float(), net.encoder.last_idx[2], wide._modules["0"].weight, gn, "bf16", want_cm=False)
+            xw, _ = dgcnn.edge_conv_pm(xf.float(), net.encoder.last_idx[2], wide._modules["0"].weight, gn, "f16", want_cm=False)
         tok = tr(xf.float())                                                       # (B,N,256), attention in fp16
         dec = qd(tok.reshape(B * N, 256), offs)
         loss = loss_of(out) + xw.pow(2).mean() + tok.pow(2).mean() + dec["labels"].pow(2).mean() \
@@ -378,7 +378,7 @@ def cfg5_workload(dev, B=4, N=16384, k=64, steps=3, warmup=2):
         step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    return {"workload": "BASELINE configs[4], one GPU's share: %d clouds N=%d k=%d: hot path + EdgeConv 256->128 (bf16 MFMA) + "
+    return {"workload": "BASELINE configs[4], one GPU's share: %d clouds N=%d k=%d: hot path + EdgeConv 256->128 (IEEE-half operands on the matrix cores) + "
                         "Transformer layer (dim 256, 8 heads, fp16 flash attention) + QueryDecoder (2 layers, 100 queries), "
                         "fwd+bwd+Adam, eager launches" % (B, N, k),
             "ms_per_step": round(dt * 1e3, 3), "clouds_per_s": round(B / dt, 2), "steps": steps, "warmup": warmup,

@@ -41,10 +41,19 @@ __device__ __forceinline__ unsigned short f32_to_bf16(float f) {
   return __builtin_bit_cast(unsigned short, h);
 }
 
+// bf16 (half == 0) or IEEE half (half == 1) image of an f32 value, as the 16-bit pattern the MFMA operand holds
+__device__ __forceinline__ unsigned short f32_to_16(float v, int half) {
+  if (half) {
+    const _Float16 h = (_Float16)v;                        // round to nearest even; |v| > 65504 becomes inf, as torch's .half()
+    return __builtin_bit_cast(unsigned short, h);
+  }
+  return f32_to_bf16(v);
+}
+
 // ------------------------------------------------------------------ operand packing
 // x (B,C,N) f32 channel-major -> x_bf (B,N,Cp) bf16 zero padded and/or x_f32 (B,N,C)
 __global__ __launch_bounds__(256) void pack_x_kernel(const float *__restrict__ x, int C, int N, int Cp,
-                                                     unsigned short *__restrict__ x_bf, float *__restrict__ x_f32) {
+                                                     unsigned short *__restrict__ x_bf, float *__restrict__ x_f32, int half) {
   __shared__ float tile[32][33];
   const int b = blockIdx.z;
   const int n0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
@@ -58,7 +67,7 @@ __global__ __launch_bounds__(256) void pack_x_kernel(const float *__restrict__ x
     const int n = n0 + i, c = c0 + tx;
     if (n < N) {
       const float v = tile[tx][i];
-      if (x_bf && c < Cp) x_bf[((long)b * N + n) * Cp + c] = f32_to_bf16(v);
+      if (x_bf && c < Cp) x_bf[((long)b * N + n) * Cp + c] = f32_to_16(v, half);
       if (x_f32 && c < C) x_f32[((long)b * N + n) * C + c] = v;
     }
   }
@@ -67,23 +76,23 @@ __global__ __launch_bounds__(256) void pack_x_kernel(const float *__restrict__ x
 
 // x (R, C) f32 row-major -> (R, Cp) bf16 zero padded (point-major operand of the fused kernel)
 __global__ __launch_bounds__(256) void cast_pad_bf16_kernel(const float *__restrict__ x, long R, int C, int Cp,
-                                                            unsigned short *__restrict__ y) {
+                                                            unsigned short *__restrict__ y, int half) {
   const long e = (long)blockIdx.x * 256 + threadIdx.x;
   if (e >= R * Cp) return;
   const long r = e / Cp;
   const int c = (int)(e % Cp);
-  y[e] = c < C ? f32_to_bf16(x[r * C + c]) : (unsigned short)0;
+  y[e] = c < C ? f32_to_16(x[r * C + c], half) : (unsigned short)0;
 }
 
 // w (Cout, 2C) f32 -> wp (Cout, 2Cp) bf16 = [W1 | 0 | W2 - W1 | 0]
-__global__ void pack_w_kernel(const float *__restrict__ w, int Cout, int C, int Cp, unsigned short *__restrict__ wp) {
+__global__ void pack_w_kernel(const float *__restrict__ w, int Cout, int C, int Cp, unsigned short *__restrict__ wp, int half) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= Cout * 2 * Cp) return;
   const int co = i / (2 * Cp), kk = i % (2 * Cp);
   float v = 0.f;
   if (kk < C) v = w[(long)co * 2 * C + kk];
   else if (kk >= Cp && kk < Cp + C) v = w[(long)co * 2 * C + C + (kk - Cp)] - w[(long)co * 2 * C + (kk - Cp)];
-  wp[i] = f32_to_bf16(v);
+  wp[i] = f32_to_16(v, half);
 }
 
 // ------------------------------------------------------------------ fused forward (bf16 MFMA)
@@ -1174,31 +1183,38 @@ static int padded_channels(int C) {
 
 GCN_EXPORT int gcn_edgeconv_padded_channels(int C) { return padded_channels(C); }
 
-GCN_EXPORT int gcn_edgeconv_pack_x(const float *x_cm, int B, int C, int N, void *x_pm_bf16, float *x_pm_f32, void *stream) {
-  GCN_REQUIRE(x_cm && (x_pm_bf16 || x_pm_f32), "gcn_edgeconv_pack_x: null pointer");
-  GCN_REQUIRE(B >= 0 && C >= 1 && N >= 1, "gcn_edgeconv_pack_x: bad shape");
+GCN_EXPORT int gcn_edgeconv_pack_x16(const float *x_cm, int B, int C, int N, void *x_pm_16, float *x_pm_f32, int half,
+                                     void *stream) {
+  GCN_REQUIRE(x_cm && (x_pm_16 || x_pm_f32), "gcn_edgeconv_pack_x: null pointer");
+  GCN_REQUIRE(B >= 0 && C >= 1 && N >= 1 && (half == 0 || half == 1), "gcn_edgeconv_pack_x: bad shape");
   if (B == 0) return GCN_OK;
   const int Cp = padded_channels(C);
-  pack_x_kernel<<<dim3(cdiv(N, 32), cdiv(Cp, 32), B), 256, 0, (hipStream_t)stream>>>(x_cm, C, N, Cp, (unsigned short *)x_pm_bf16, x_pm_f32);
+  pack_x_kernel<<<dim3(cdiv(N, 32), cdiv(Cp, 32), B), 256, 0, (hipStream_t)stream>>>(x_cm, C, N, Cp, (unsigned short *)x_pm_16, x_pm_f32, half);
   return check_launch("pack_x_kernel");
 }
+GCN_EXPORT int gcn_edgeconv_pack_x(const float *x_cm, int B, int C, int N, void *x_pm_bf16, float *x_pm_f32, void *stream) {
+  return gcn_edgeconv_pack_x16(x_cm, B, C, N, x_pm_bf16, x_pm_f32, 0, stream);
+}
 
-GCN_EXPORT int gcn_edgeconv_pack_w(const float *w, int Cout, int C, void *wp_bf16, void *stream) {
-  GCN_REQUIRE(w && wp_bf16, "gcn_edgeconv_pack_w: null pointer");
-  GCN_REQUIRE(Cout >= 1 && C >= 1, "gcn_edgeconv_pack_w: bad shape");
+GCN_EXPORT int gcn_edgeconv_pack_w16(const float *w, int Cout, int C, void *wp_16, int half, void *stream) {
+  GCN_REQUIRE(w && wp_16, "gcn_edgeconv_pack_w: null pointer");
+  GCN_REQUIRE(Cout >= 1 && C >= 1 && (half == 0 || half == 1), "gcn_edgeconv_pack_w: bad shape");
   const int Cp = padded_channels(C);
-  pack_w_kernel<<<cdiv((long)Cout * 2 * Cp, 256), 256, 0, (hipStream_t)stream>>>(w, Cout, C, Cp, (unsigned short *)wp_bf16);
+  pack_w_kernel<<<cdiv((long)Cout * 2 * Cp, 256), 256, 0, (hipStream_t)stream>>>(w, Cout, C, Cp, (unsigned short *)wp_16, half);
   return check_launch("pack_w_kernel");
+}
+GCN_EXPORT int gcn_edgeconv_pack_w(const float *w, int Cout, int C, void *wp_bf16, void *stream) {
+  return gcn_edgeconv_pack_w16(w, Cout, C, wp_bf16, 0, stream);
 }
 
 GCN_EXPORT int gcn_edgeconv_fwd(const void *x_pm, const void *w, const int64_t *idx, int dtype, int B, int N, int NX,
                                 int C, int k, int Cout, int G, const float *q, float *ymax, float *ymin, uint8_t *amax,
                                 uint8_t *amin, double *gsum, const float *gamma_route, void *stream) {
   GCN_REQUIRE(x_pm && w && idx && ymax && gsum, "gcn_edgeconv_fwd: null pointer");
-  GCN_REQUIRE(dtype == 1 || q == nullptr, "gcn_edgeconv_fwd: q belongs to the bf16 path (dtype 1) only");
+  GCN_REQUIRE(dtype >= 1 || q == nullptr, "gcn_edgeconv_fwd: q belongs to the matrix-core paths (dtype 1, 2) only");
   GCN_REQUIRE(gamma_route || ymin, "gcn_edgeconv_fwd: ymin may be NULL only in routed mode (gamma_route given)");
   GCN_REQUIRE(gamma_route || (amax == nullptr) == (amin == nullptr), "gcn_edgeconv_fwd: pass both amax and amin or neither");
-  GCN_REQUIRE(dtype == 0 || dtype == 1, "gcn_edgeconv_fwd: dtype must be 0 (f32) or 1 (bf16)");
+  GCN_REQUIRE(dtype == 0 || dtype == 1 || dtype == 2, "gcn_edgeconv_fwd: dtype must be 0 (f32), 1 (bf16) or 2 (IEEE half)");
   GCN_REQUIRE(B >= 0 && N >= 1 && NX >= N && C >= 1 && k >= 1 && k <= 255, "gcn_edgeconv_fwd: bad shape (need NX >= N, 1 <= k <= 255)");
   GCN_REQUIRE(G >= 1 && Cout % G == 0, "gcn_edgeconv_fwd: Cout=%d not divisible by G=%d", Cout, G);
   if (B == 0) return GCN_OK;
@@ -1227,8 +1243,9 @@ GCN_EXPORT int gcn_edgeconv_fwd(const void *x_pm, const void *w, const int64_t *
     e.x = a.x; e.wp = a.wp; e.idx = idx; e.q = q;
     e.B = B; e.N = N; e.NX = NX; e.k = k; e.Cout = Cout; e.G = G;
     e.ymax = ymax; e.ymin = ymin; e.amax = amax; e.amin = amin; e.gsum = gsum; e.gamma_route = gamma_route;
-    return launch_edgeconv_fwd_q(e, Cp, wa, st);
+    return dtype == 2 ? launch_edgeconv_fwd_q_f16(e, Cp, wa, st) : launch_edgeconv_fwd_q(e, Cp, wa, st);
   }
+  GCN_REQUIRE(dtype == 1, "gcn_edgeconv_fwd(f16): k <= 128 only");
   // 128 < k <= 255: two 128-row groups per point, full [x_j ; x_i] rows (q is not needed)
   const int ks = Cp / 8;
 #define EC_CASE(KS, CWV) \
@@ -1354,13 +1371,16 @@ GCN_EXPORT int gcn_keyedge_fwd(const float *att, const int64_t *kidx, const floa
   return check_launch("keyedge_fwd_kernel");
 }
 
-GCN_EXPORT int gcn_cast_pad_bf16(const float *x_pm, long rows, int C, void *x_pm_bf16, void *stream) {
-  GCN_REQUIRE(x_pm && x_pm_bf16, "gcn_cast_pad_bf16: null pointer");
-  GCN_REQUIRE(rows >= 0 && C >= 1, "gcn_cast_pad_bf16: bad shape");
+GCN_EXPORT int gcn_cast_pad16(const float *x_pm, long rows, int C, void *x_pm_16, int half, void *stream) {
+  GCN_REQUIRE(x_pm && x_pm_16, "gcn_cast_pad_bf16: null pointer");
+  GCN_REQUIRE(rows >= 0 && C >= 1 && (half == 0 || half == 1), "gcn_cast_pad_bf16: bad shape");
   if (rows == 0) return GCN_OK;
   const int Cp = padded_channels(C);
-  cast_pad_bf16_kernel<<<cdiv(rows * Cp, 256), 256, 0, (hipStream_t)stream>>>(x_pm, rows, C, Cp, (unsigned short *)x_pm_bf16);
+  cast_pad_bf16_kernel<<<cdiv(rows * Cp, 256), 256, 0, (hipStream_t)stream>>>(x_pm, rows, C, Cp, (unsigned short *)x_pm_16, half);
   return check_launch("cast_pad_bf16_kernel");
+}
+GCN_EXPORT int gcn_cast_pad_bf16(const float *x_pm, long rows, int C, void *x_pm_bf16, void *stream) {
+  return gcn_cast_pad16(x_pm, rows, C, x_pm_bf16, 0, stream);
 }
 
 GCN_EXPORT int gcn_keyedge_bwd(const float *att, const int64_t *kidx, const float *U, const float *V, const float *coef,

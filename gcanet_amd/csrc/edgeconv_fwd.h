@@ -20,5 +20,7 @@ struct EcqArgs {
 
 // k <= 128, Cp in {16,32,64,128}, Cout in {64,128}
 int launch_edgeconv_fwd_q(EcqArgs &a, int Cp, bool with_arg, hipStream_t st);
+// the same on IEEE-half operand images (edgeconv_fwd_f16.hip): Cp in {64,128,256}
+int launch_edgeconv_fwd_q_f16(EcqArgs &a, int Cp, bool with_arg, hipStream_t st);
 
 }  // namespace gcn

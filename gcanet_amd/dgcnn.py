@@ -99,19 +99,27 @@ def _edgeconv_dtype(dtype, C, Cout, groups):
     at most 128 (padded) input channels -- 256 with Cout == 128 (BASELINE configs[4]); any other width (M4:493-505 takes
     arbitrary channels) runs on the exact f32 kernel -- same op, same signature, no error."""
     Cp = _lib.lib().gcn_edgeconv_padded_channels(C)
-    if dtype == "bf16" and not (Cout in (64, 128) and (Cout // groups) % 32 == 0 and Cout % groups == 0
-                                and (Cp <= 128 or (Cp == 256 and Cout == 128))):
+    if dtype in ("bf16", "f16") and not (Cout in (64, 128) and (Cout // groups) % 32 == 0 and Cout % groups == 0
+                                         and (Cp <= 128 or (Cp == 256 and Cout == 128))):
         return "f32"
+    if dtype == "f16" and Cp < 64:          # the IEEE-half instantiations start at 33 input channels
+        return "bf16"
     return dtype
+
+
+_T16 = {"bf16": (torch.bfloat16, 0, 1), "f16": (torch.float16, 1, 2)}      # torch type, `half` flag, gcn_edgeconv_fwd dtype
 
 
 def _center_term(x_bf, wp, rows, C, Cout, k):
     """q (rows, Cout) f32 = x . (W2 - W1)^T, the per-point half of the EdgeConv contraction (csrc/edgeconv_fwd.hip);
     None for k > 128, where the kernel contracts full [x_j ; x_i] rows."""
     if k > 128:
+        if x_bf.dtype == torch.float16:
+            raise ValueError("EdgeConv on IEEE-half operands serves k <= 128 (got k=%d)" % k)
         return None
     q = torch.empty(rows, Cout, dtype=torch.float32, device=x_bf.device)
-    _run("gcn_edgeconv_center", x_bf, _lib.ptr(x_bf), _lib.ptr(wp), rows, C, Cout, _lib.ptr(q))
+    _run("gcn_edgeconv_center_f16" if x_bf.dtype == torch.float16 else "gcn_edgeconv_center", x_bf, _lib.ptr(x_bf),
+         _lib.ptr(wp), rows, C, Cout, _lib.ptr(q))
     return q
 
 
@@ -137,14 +145,15 @@ def edgeconv_forward_raw(x, idx, weight, gamma, beta, groups, dtype="bf16", eps=
     gsum = _zeroed_like((B, groups, 2), torch.float64, dev)
     x_pm = torch.empty(B, N, C, **f32)
     dtype = _edgeconv_dtype(dtype, C, Cout, groups)
-    if dtype == "bf16":
+    if dtype in _T16:
+        t16, half, code = _T16[dtype]
         Cp = _lib.lib().gcn_edgeconv_padded_channels(C)
-        x_bf = torch.empty(B, N, Cp, dtype=torch.bfloat16, device=dev)
-        wp = torch.empty(Cout, 2 * Cp, dtype=torch.bfloat16, device=dev)
-        _run("gcn_edgeconv_pack_x", x, _lib.ptr(x), B, C, N, _lib.ptr(x_bf), _lib.ptr(x_pm))
-        _run("gcn_edgeconv_pack_w", x, _lib.ptr(w), Cout, C, _lib.ptr(wp))
+        x_bf = torch.empty(B, N, Cp, dtype=t16, device=dev)
+        wp = torch.empty(Cout, 2 * Cp, dtype=t16, device=dev)
+        _run("gcn_edgeconv_pack_x16", x, _lib.ptr(x), B, C, N, _lib.ptr(x_bf), _lib.ptr(x_pm), half)
+        _run("gcn_edgeconv_pack_w16", x, _lib.ptr(w), Cout, C, _lib.ptr(wp), half)
         q = _center_term(x_bf, wp, B * N, C, Cout, k)
-        _run("gcn_edgeconv_fwd", x, _lib.ptr(x_bf), _lib.ptr(wp), _lib.ptr(idx), 1, B, N, N, C, k, Cout, groups,
+        _run("gcn_edgeconv_fwd", x, _lib.ptr(x_bf), _lib.ptr(wp), _lib.ptr(idx), code, B, N, N, C, k, Cout, groups,
              _lib.ptr(q), _lib.ptr(ymax), _lib.ptr(ymin), _lib.ptr(amax), _lib.ptr(amin), _lib.ptr(gsum), None,
              tag="edgeconv_fwd[B=%d,N=%d,k=%d,C=%d,Cout=%d]" % (B, N, k, C, Cout))
     elif dtype == "f32":
@@ -152,7 +161,7 @@ def edgeconv_forward_raw(x, idx, weight, gamma, beta, groups, dtype="bf16", eps=
         _run("gcn_edgeconv_fwd", x, _lib.ptr(x_pm), _lib.ptr(w), _lib.ptr(idx), 0, B, N, N, C, k, Cout, groups,
              None, _lib.ptr(ymax), _lib.ptr(ymin), _lib.ptr(amax), _lib.ptr(amin), _lib.ptr(gsum), None)
     else:
-        raise ValueError("dtype must be 'bf16' or 'f32'")
+        raise ValueError("dtype must be 'bf16', 'f16' or 'f32'")
     out = torch.empty(B, Cout, N, **f32)
     mean_rstd = torch.empty(B, groups, 2, **f32)
     ga, be = gamma.float().contiguous(), beta.float().contiguous()
@@ -314,7 +323,7 @@ class GroupedBlockFunction(torch.autograd.Function):
         amin = torch.empty(B, N, Cout, dtype=torch.uint8, device=dev)
         gsum = _zeroed_like((B, groups, 2), torch.float64, dev)
         # N "points" whose k neighbours are rows n*k..n*k+k-1 of the edge-row "cloud"
-        dtype = _edgeconv_dtype(dtype, F, Cout, groups)
+        dtype = _edgeconv_dtype("bf16" if dtype == "f16" else dtype, F, Cout, groups)    # generic block: bf16 or exact
         if dtype == "bf16":
             Fp = _lib.lib().gcn_edgeconv_padded_channels(F)
             x_bf = torch.empty(B, N * k, Fp, dtype=torch.bfloat16, device=dev)
@@ -928,14 +937,15 @@ class EdgeConvPMFunction(torch.autograd.Function):
         ymin = amin = None
         gsum = _zeroed_like((B, groups, 2), torch.float64, dev)
         dtype = _edgeconv_dtype(dtype, C, Cout, groups)
-        if dtype == "bf16":
+        if dtype in _T16:
+            t16, half, code = _T16[dtype]
             Cp = _lib.lib().gcn_edgeconv_padded_channels(C)
-            x_bf = torch.empty(B, N, Cp, dtype=torch.bfloat16, device=dev)
-            wp = torch.empty(Cout, 2 * Cp, dtype=torch.bfloat16, device=dev)
-            _run("gcn_cast_pad_bf16", x, _lib.ptr(x), B * N, C, _lib.ptr(x_bf))
-            _run("gcn_edgeconv_pack_w", x, _lib.ptr(w), Cout, C, _lib.ptr(wp))
+            x_bf = torch.empty(B, N, Cp, dtype=t16, device=dev)
+            wp = torch.empty(Cout, 2 * Cp, dtype=t16, device=dev)
+            _run("gcn_cast_pad16", x, _lib.ptr(x), B * N, C, _lib.ptr(x_bf), half)
+            _run("gcn_edgeconv_pack_w16", x, _lib.ptr(w), Cout, C, _lib.ptr(wp), half)
             q = _center_term(x_bf, wp, B * N, C, Cout, k)
-            _run("gcn_edgeconv_fwd", x, _lib.ptr(x_bf), _lib.ptr(wp), _lib.ptr(idx), 1, B, N, N, C, k, Cout, groups,
+            _run("gcn_edgeconv_fwd", x, _lib.ptr(x_bf), _lib.ptr(wp), _lib.ptr(idx), code, B, N, N, C, k, Cout, groups,
                  _lib.ptr(q), _lib.ptr(ymax), None, _lib.ptr(amax), None, _lib.ptr(gsum), _lib.ptr(ga),
                  tag="edgeconv_fwd[B=%d,N=%d,k=%d,C=%d,Cout=%d]" % (B, N, k, C, Cout))
         else:

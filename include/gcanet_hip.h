@@ -335,6 +335,8 @@ int gcn_hierarchical_aggregation_host(const int32_t *semantic_label_host, const 
  * Operands are point-major so that one neighbour is one contiguous row:
  *   dtype 1: x_pm (B,N,Cp) bf16 and w = W' (Cout,2Cp) bf16 from gcn_edgeconv_pack_x / _pack_w,
  *            Cp = gcn_edgeconv_padded_channels(C) (power of two >= 16); Cout in {64,128}, C <= 128, (Cout/G) % 32 == 0
+ *   dtype 2: the same kernels on IEEE-half operand images (gcn_edgeconv_pack_x16 / _pack_w16 / gcn_cast_pad16 with
+ *            half = 1, v_mfma_f32_32x32x16_f16): BASELINE configs[4] "fp16+MFMA"; 33 <= C <= 256, k <= 128
  *   dtype 0: x_pm (B,N,C) f32, w (Cout,2C) f32 (the reference's own Conv2d weight)
  *   idx    (B,N,k) int64 neighbour ids within the cloud (what knn()/topk returns), 1 <= k <= 255;
  *          ids index the NX rows per cloud of x_pm (NX == N for EdgeConv; a generic grouped block
@@ -352,6 +354,9 @@ int gcn_edgeconv_padded_channels(int C);
 int gcn_edgeconv_pack_x(const float *x_cm, int B, int C, int N, void *x_pm_bf16, float *x_pm_f32,
                         void *stream);
 int gcn_edgeconv_pack_w(const float *w, int Cout, int C, void *wp_bf16, void *stream);
+/* the same with the 16-bit type chosen by the caller: half = 0 bf16, half = 1 IEEE half (round to nearest even) */
+int gcn_edgeconv_pack_x16(const float *x_cm, int B, int C, int N, void *x_pm_16, float *x_pm_f32, int half, void *stream);
+int gcn_edgeconv_pack_w16(const float *w, int Cout, int C, void *wp_16, int half, void *stream);
 int gcn_edgeconv_fwd(const void *x_pm, const void *w, const int64_t *idx, int dtype, int B, int N,
                      int NX, int C, int k, int Cout, int G, const float *q, float *ymax, float *ymin,
                      uint8_t *amax, uint8_t *amin, double *gsum, const float *gamma_route, void *stream);
@@ -364,10 +369,12 @@ int gcn_edgeconv_fwd(const void *x_pm, const void *w, const int64_t *idx, int dt
  * corrected in closed form), so the matrix cores contract K = Cp instead of 2 Cp.  Needed for k <= 128 only. */
 int gcn_edgeconv_center(const void *x_pm_bf16, const void *wp_bf16, long rows, int C, int Cout, float *q,
                         void *stream);
+int gcn_edgeconv_center_f16(const void *x_pm_f16, const void *wp_f16, long rows, int C, int Cout, float *q, void *stream);   /* dtype 2 */
 
 /* Point-major operand preparation when activations are already (rows, C) f32: cast to bf16 and zero-pad
  * the channel axis to gcn_edgeconv_padded_channels(C) (no transpose, unlike gcn_edgeconv_pack_x). */
 int gcn_cast_pad_bf16(const float *x_pm, long rows, int C, void *x_pm_bf16, void *stream);
+int gcn_cast_pad16(const float *x_pm, long rows, int C, void *x_pm_16, int half, void *stream);
 
 /* GroupNorm(G, Cout, eps) + LeakyReLU(slope) on the routed extreme:
  *   out_cm (B,Cout,N) f32 (the reference's layout) and/or out_pm (B,N,Cout); either may be NULL

@@ -8,19 +8,26 @@ from oracle import ref_model as R
 pytestmark = pytest.mark.gpu
 
 
-def _bf16_round(t):
-    return t.to(torch.bfloat16).to(torch.float32)
+def _bf16_round(t, t16=torch.bfloat16):
+    return t.to(t16).to(torch.float32)
+
+
+def _served_as(dtype, C):
+    """The operand type dgcnn._edgeconv_dtype picks for the supported widths of CASES: the IEEE-half kernels
+    (csrc/edgeconv_fwd_f16.hip, BASELINE configs[4] "fp16+MFMA") start at 33 input channels, narrower layers keep bf16."""
+    return "bf16" if (dtype == "f16" and C <= 32) else dtype
 
 
 def _reference(x, idx, w, gamma, beta, G, bf16):
-    """fp32 oracle.  For the bf16 MFMA path the oracle sees the SAME bf16-rounded operands the
-    kernel contracts ([x_j ; x_i] against [W1 | W2-W1]); products of bf16 values are exact in f32,
+    """fp32 oracle.  For the 16-bit MFMA paths (bf16 = True or a torch 16-bit type) the oracle sees the SAME rounded
+    operands the kernel contracts ([x_j ; x_i] against [W1 | W2-W1]); products of 16-bit values are exact in f32,
     so the only difference left is f32 summation order."""
     if not bf16:
         return R.edgeconv_block(x, idx, w, gamma, beta, G)
+    t16 = torch.bfloat16 if bf16 is True else bf16
     C = x.shape[1]
-    xr = _bf16_round(x)
-    w1, w2 = _bf16_round(w[:, :C]), _bf16_round(w[:, C:] - w[:, :C])
+    xr = _bf16_round(x, t16)
+    w1, w2 = _bf16_round(w[:, :C], t16), _bf16_round(w[:, C:] - w[:, :C], t16)
     # W1.(x_j - x_i) + W2.x_i == W1.x_j + (W2-W1).x_i  -> feed the oracle an equivalent weight
     w_eq = torch.cat([w1, w2 + w1], 1)
     return R.edgeconv_block(xr, idx, w_eq, gamma, beta, G)
@@ -29,11 +36,13 @@ def _reference(x, idx, w, gamma, beta, G, bf16):
 CASES = [  # B, C, N, k, Cout, G
     (2, 16, 96, 8, 64, 2), (2, 64, 300, 20, 64, 2), (1, 64, 257, 64, 128, 2), (2, 6, 200, 16, 64, 2),
     (1, 128, 130, 64, 128, 2), (1, 3, 100, 30, 64, 2), (1, 32, 90, 80, 128, 4), (1, 128, 64, 33, 64, 2),
+    (1, 256, 96, 32, 128, 2),
 ]
+_T16 = {"bf16": torch.bfloat16, "f16": torch.float16}
 
 
 @pytest.mark.parametrize("B,C,N,k,Cout,G", CASES)
-@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+@pytest.mark.parametrize("dtype", ["bf16", "f32", "f16"])
 def test_edgeconv_forward(dev, B, C, N, k, Cout, G, dtype):
     from gcanet_amd import dgcnn
     g = torch.Generator().manual_seed(B * 1000 + C + N + k)
@@ -43,16 +52,17 @@ def test_edgeconv_forward(dev, B, C, N, k, Cout, G, dtype):
     gamma = torch.randn(Cout, generator=g)       # mixed signs: exercises max- and min-routing
     beta = torch.randn(Cout, generator=g) * 0.1
     r = dgcnn.edgeconv_forward_raw(x.to(dev), idx.to(dev), w.to(dev), gamma.to(dev), beta.to(dev), G, dtype, need_arg=True)
-    ref = _reference(x, idx, w, gamma, beta, G, dtype == "bf16")
-    # tolerance: fp32 features within 1e-4 (north star); bf16 path compared on identical rounded operands
+    t16 = _T16.get(_served_as(dtype, C))
+    ref = _reference(x, idx, w, gamma, beta, G, t16 if t16 is not None else False)
+    # tolerance: fp32 features within 1e-4 (north star); 16-bit paths compared on identical rounded operands
     np.testing.assert_allclose(r["out"].cpu().numpy(), ref.numpy(), rtol=1e-4, atol=1e-4)
     # raw extremes + arg slots vs a direct evaluation
-    xr, wr = (x, w) if dtype == "f32" else (_bf16_round(x), None)
+    xr, wr = (x, w) if dtype == "f32" else (_bf16_round(x, t16), None)
     ef = R.get_graph_feature(xr, idx=idx)                      # (B,2C,N,k)
     if dtype == "f32":
         y = torch.einsum("oc,bcnk->bnko", w, ef)
     else:
-        w1, w2 = _bf16_round(w[:, :C]), _bf16_round(w[:, C:] - w[:, :C])
+        w1, w2 = _bf16_round(w[:, :C], t16), _bf16_round(w[:, C:] - w[:, :C], t16)
         y = torch.einsum("oc,bcnk->bnko", torch.cat([w1, w2 + w1], 1), ef)
     np.testing.assert_allclose(r["ymax"].cpu().numpy(), y.max(2)[0].numpy(), rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(r["ymin"].cpu().numpy(), y.min(2)[0].numpy(), rtol=1e-4, atol=1e-4)

@@ -195,6 +195,11 @@ def test_edgeconv_c256_on_matrix_cores(dev, n, k):
     ref = R.edgeconv_block(x, idx.cpu(), w, gamma, beta, 2)
     out = dgcnn.edgeconv_forward_raw(xd, idx, w.to(dev), gamma.to(dev), beta.to(dev), 2, "bf16")["out"].cpu()
     _close(out, ref, what="bf16 C=256 N=%d" % n)
+    # IEEE-half operands (csrc/edgeconv_fwd_f16.hip, configs[4] "fp16+MFMA"): bf16-representable values of this size are
+    # f16-representable too, so the same oracle output applies
+    assert dgcnn._edgeconv_dtype("f16", C, Cout, 2) == "f16"
+    out16 = dgcnn.edgeconv_forward_raw(xd, idx, w.to(dev), gamma.to(dev), beta.to(dev), 2, "f16")["out"].cpu()
+    _close(out16, ref, what="f16 C=256 N=%d" % n)
     f32 = dgcnn.edgeconv_forward_raw(xd, idx, w.to(dev), gamma.to(dev), beta.to(dev), 2, "f32")["out"].cpu()
     _close(f32, ref, what="f32 C=256 N=%d" % n)
     if n > 4096:
