@@ -657,8 +657,14 @@ def main():
 
     run_step = step
     if use_graph:
-        graph, loss = capture_step(step, args.warmup)
+        # the W untimed warm-up steps: all but the last (the last two from W = 6 on) are launched eagerly before the
+        # capture, the rest are REPLAYS of the captured graph -- the first replay after a capture runs ~5 % slow (cold
+        # instruction caches / clocks after the synchronising capture: tools/debug/replay_jitter.py) and is warm-up, not work
+        replay_warm = 0 if args.warmup < 2 else (1 if args.warmup < 6 else 2)
+        graph, loss = capture_step(step, args.warmup - replay_warm)
         run_step = graph.replay
+        for _ in range(replay_warm):
+            graph.replay()
     else:
         for _ in range(args.warmup):
             step()
