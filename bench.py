@@ -212,6 +212,9 @@ def full_workload_roofline():
         out.update(traffic=rec["hbm_bytes_corrected"], achieved=round(ach, 1), frac=round(ach / PEAK_HBM_GBS, 4))
     else:
         out.update(traffic=None, achieved=None, frac=None)
+    if "knnf_keys" in name:
+        out["note"] = ("exact f32 keys of ~200 surviving candidates per query: an L2-RESIDENT row gather (3.4 GB of 256-byte rows "
+                       "per launch ~ 15 TB/s ~ 44 % of the aggregate L2 rate); HBM sees the 8 x 2 MB clouds once plus the key lists")
     return out
 
 
