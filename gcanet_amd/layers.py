@@ -232,7 +232,8 @@ def _own_gemm(M, N, K, fused_gn):
         return False
     if mode == "own":
         return True
-    return N <= 128 or (fused_gn and N * K <= 256 * 256)
+    lim = int(os.environ.get("GCANET_GEMM_FUSED_K", "256"))
+    return N <= 128 or (fused_gn and N <= 256 and K <= lim)
 
 
 def gemm_own(x2, wq, bias, N, out_f32=False, gn=None, rows_per_cloud=0):
