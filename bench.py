@@ -513,6 +513,13 @@ def north_star_rooflines(dev, B=8, N=8192, k=64, C=128):
                    "peak": PEAK_TFLOPS["bf16_mfma"], "unit": "TFLOP/s", "frac": round(tf / PEAK_TFLOPS["bf16_mfma"], 4),
                    "executed_tflops": round(executed / (ms_c + ms_f) / 1e9, 1),
                    "executed_frac": round(executed / (ms_c + ms_f) / 1e9 / PEAK_TFLOPS["bf16_mfma"], 4)}
+    # matrix-pipe busy fraction of the same kernel from the committed PMC passes (SQ_VALU_MFMA_BUSY_CYCLES over the active
+    # cycles of the 1024 SIMDs; tools/pmc_mfma.py): clock independent, where `executed_frac` prices against 2.4 GHz
+    mp = os.path.join(ROOT, "profiles", "r03_pmc_mfma.json")
+    if os.path.exists(mp) and (B, N, k, C) == (8, 8192, 64, 128):
+        rec = json.load(open(mp))["kernels"].get("gcn::edgeconv_fwd_q_kernel<8, 4, 2, true, true, true, false>")
+        if rec:
+            grouped_mlp["mfma_busy_pmc"] = rec["mfma_busy"]
     return {"knn_gather": knn_gather, "grouped_mlp": grouped_mlp}
 
 

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Everything profiles/ holds for one round, in one GPU-box call:  bash tools/collect_all.sh   (from the repo root)
 # bench line + rocprofv3 stats + PMC traffic (collect_profiles.sh), cfg5 stats, eager / reference-shape bench lines,
-# kNN robustness cases, segment-diameter bench.  Copy gpurun_out/<tag>_* into profiles/ afterwards.
+# kNN robustness cases, segment-diameter bench (PMC: HBM traffic and matrix-pipe busy cycles, separate passes).  Copy gpurun_out/<tag>_* into profiles/ afterwards.
 export GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 T=r03_v4
 bash tools/collect_profiles.sh $T > gpurun_out/${T}_collect.log 2>&1 && \

@@ -18,6 +18,11 @@ echo "fetch done"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d /tmp/pw -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-full > $O/${T}_pw.log 2>&1
 echo "write done"
 python3 $R/tools/pmc_traffic.py /tmp/pf/*/*counter_collection.csv /tmp/pw/*/*counter_collection.csv $O/${T}_pmc_traffic.json
+rm -rf /tmp/pm /tmp/pg
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES -f csv -d /tmp/pm -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-full > $O/${T}_pm.log 2>&1
+rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE -f csv -d /tmp/pg -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-full > $O/${T}_pg.log 2>&1
+python3 $R/tools/pmc_mfma.py /tmp/pm/*/*counter_collection.csv /tmp/pg/*/*counter_collection.csv $O/${T}_pmc_mfma.json
+echo "mfma utilisation done"
 rm -rf /tmp/pfull
 rocprofv3 --kernel-trace --stats -f csv -d /tmp/pfull -- python3 $R/tools/full_profile.py 5 2 > $O/${T}_full.log 2>&1
 cp /tmp/pfull/*/*_kernel_stats.csv $O/${T}_full_workload_kernel_stats.csv

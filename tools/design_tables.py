@@ -61,8 +61,15 @@ def t_headline():
     kg, gm = ns["knn_gather"], ns["grouped_mlp"]
     L.append("| north star: kNN + gather vs HBM (%s) | %.3f + %.3f ms, %.0f GB/s = **%.1f %%** of 8 TB/s (gather alone %.1f %%) | `r03_bench.json: north_star.knn_gather` |"
              % (kg["shape"], kg["knn_ms"], kg["group_ms"], kg["achieved"], 100 * kg["frac"], 100 * kg["group_only_frac"]))
-    L.append("| north star: grouped MLP vs bf16 MFMA (%s) | %.3f + %.3f ms, %.0f TF algorithmic = **%.1f %%** of 2.5 PF; executed %.0f TF = %.1f %% | `r03_bench.json: north_star.grouped_mlp` |"
-             % (gm["shape"], gm["center_ms"], gm["grouped_ms"], gm["achieved"], 100 * gm["frac"], gm["executed_tflops"], 100 * gm["executed_frac"]))
+    pm = json.load(open(os.path.join(P, "r03_pmc_mfma.json")))["kernels"] if os.path.exists(os.path.join(P, "r03_pmc_mfma.json")) else {}
+    busy = pm.get("gcn::edgeconv_fwd_q_kernel<8, 4, 2, true, true, true, false>", {}).get("mfma_busy")
+    L.append("| north star: grouped MLP vs bf16 MFMA (%s) | %.3f + %.3f ms, %.0f TF algorithmic = **%.1f %%** of 2.5 PF; executed %.0f TF = %.1f %% of the 2.4-GHz peak%s | `r03_bench.json: north_star.grouped_mlp`, `r03_pmc_mfma.json` |"
+             % (gm["shape"], gm["center_ms"], gm["grouped_ms"], gm["achieved"], 100 * gm["frac"], gm["executed_tflops"], 100 * gm["executed_frac"],
+                ("; matrix pipes busy %.1f %% of the active cycles (PMC `SQ_VALU_MFMA_BUSY_CYCLES`)" % (100 * busy)) if busy else ""))
+    if pm:
+        L.append("| matrix-pipe busy fraction of other kernels (PMC) | %s | `r03_pmc_mfma.json` |"
+                 % ", ".join("`%s` %.1f %%" % (k.replace("gcn::", "").replace(", true, true, true, false", ",…"), 100 * v["mfma_busy"])
+                             for k, v in sorted(pm.items(), key=lambda kv: -kv[1]["mfma_busy"])[:8]))
     fw, c5, fg, cb = d["full_workload"], d["cfg5_workload"], d["forward_grouping"], d["cpu_baseline"]
     L.append("| literal full `forward_train` + losses + backward + Adam on blob clouds | %.2f ms/step, %.0f clouds/s, %d proposals, %d members | `r03_bench.json: full_workload` |"
              % (fw["ms_per_step"], fw["clouds_per_s"], fw["proposals"], fw["members"]))
