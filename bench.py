@@ -655,7 +655,8 @@ def main():
     # replays it correctly; GCANET_GRAPH_MULTIRANK=1 opts a multi-rank run into that mode.  It is not the default: the
     # eager multi-rank step is GPU-bound already (6.7 ms of GPU against 6.0 ms of host enqueue), so a replay would gain
     # ~3 % and an N-rank capture cannot be rehearsed on the one-GPU test box.)
-    use_graph = (world == 1 or os.environ.get("GCANET_GRAPH_MULTIRANK") == "1") and not args.no_graph
+    # a capture needs at least one eager step before it (lazy initialisation, allocator warm-up): --warmup 0 runs eager
+    use_graph = (world == 1 or os.environ.get("GCANET_GRAPH_MULTIRANK") == "1") and not args.no_graph and args.warmup >= 1
     B, N = args.batch, args.points
     pts, nrm = synth_clouds(range(rank * B, rank * B + B), N, dev)
     st = make_step(model, pts, nrm, world)
