@@ -47,6 +47,7 @@ struct SdArgs {
   unsigned int *L;            // (S) float bits of max lo
   int4 *cand;                 // listed blocks: (first row, first column, segment, -)
   unsigned int *ncand;        // [0] listed blocks, [1] the limit beyond which the large segments fall back
+  unsigned int cand_cap;      // entries `cand` holds (every block of every large segment: sd_layout)
   unsigned int *dmax2;        // (S) float bits
   float eps;
   int n, C, Cb, S;
@@ -216,8 +217,10 @@ __global__ __launch_bounds__(512) void sd_pass_kernel(SdArgs a) {
         for (int i = 0; i < 16; i += 2)
           m = fmaxf(m, fmaxf(fmaf(-2.f, acc[i], xi[i] + xj), fmaf(-2.f, acc[i + 1], xi[i + 1] + xj)));
         if (SELECT) {
-          if (__ballot(m >= Lseg) != 0ull && lane == 0)
-            a.cand[atomicAdd(a.ncand, 1u)] = make_int4(i0, beg + tb * 64 + half * 32, sg, 0);
+          if (__ballot(m >= Lseg) != 0ull && lane == 0) {
+            const unsigned int slot = atomicAdd(a.ncand, 1u);
+            if (slot < a.cand_cap) a.cand[slot] = make_int4(i0, beg + tb * 64 + half * 32, sg, 0);   // (a full list means fall-back)
+          }
         } else {
           run = m;
         }
@@ -307,7 +310,10 @@ struct SdWs { size_t L, ncand, work_prefix, tiles_small, tiles_large, fb, xx, ca
 static SdWs sd_layout(int n, int C, int S) {
   SdWs w{};
   const long Tmax = (long)n / 64 + S + 1;                     // 64-row tiles of all segments together
-  w.blocks_max = 4 * (Tmax * (Tmax + 1) / 2);                 // 32 x 32 blocks of all tile pairs a <= b
+  // 32 x 32 blocks the select pass can list: a segment of T column tiles walks 16 (T - 4 A) blocks per 256-row tile A
+  // (all 8 waves, clamped rows past the end included), 2 T^2 + 8 T + 8 <= 2 (T + 2)^2 in total, and
+  // sum_s (T_s + 2)^2 <= (sum_s T_s + 2 S)^2 with sum_s T_s <= n / 64 + S
+  w.blocks_max = 2 * (Tmax + 2 * S + 1) * (Tmax + 2 * S + 1);
   w.work_max = (Tmax / 4 + S + 1) * (Tmax / SD_STRIP + 1);
   size_t o = 0;
   w.L = o; o += sd_align(sizeof(unsigned int) * (size_t)S);          // L and ncand are zeroed together
@@ -354,6 +360,7 @@ GCN_EXPORT int gcn_segment_diameter2_filtered(int n, int C, const float *feats, 
   a.cand = (int4 *)(base + w.cand); a.ncand = (unsigned int *)(base + w.ncand); a.dmax2 = (unsigned int *)dmax2;
   a.n = n; a.C = C; a.Cb = sd_cb(C); a.S = S;
   a.eps = 5e-5f + 5e-7f * (float)a.Cb;
+  a.cand_cap = (unsigned int)w.blocks_max;
   GCN_HIP(fill_dev(base + w.L, 0, w.work_prefix - w.L, st));
   GCN_HIP(fill_dev(dmax2, 0, sizeof(float) * (size_t)S, st));
   sd_prep_kernel<<<cdiv((long)n * (a.Cb / 8), 256), 256, 0, st>>>(a);

@@ -246,7 +246,7 @@ def test_segment_diameter_matches_cdist(dev):
 
 
 @pytest.mark.parametrize("case", ["ragged", "blobs_large", "tight_blobs", "identical_rows", "one_outlier", "wide_c",
-                                  "big_offset", "random_sizes"])
+                                  "big_offset", "random_sizes", "identical_single"])
 def test_filtered_segment_diameter_equals_exhaustive(dev, case):
     """csrc/segdiam.hip (bf16 bound passes + exact recheck of the surviving 32x32 blocks) returns the bits of the
     exhaustive f32 kernel: ragged and inactive segments, large blob segments (where the filter removes > 99 % of the
@@ -259,6 +259,9 @@ def test_filtered_segment_diameter_equals_exhaustive(dev, case):
         sizes = [1, 70, 0, 333, 64, 1000, 129, 2, 65]
         cls = [0, 1, 2, -1, 4, 5, 6, 7, 8]
         f = rng.standard_normal((sum(sizes), C)).astype(np.float32)
+    elif case == "identical_single":                       # ONE segment, n % 64 != 0, every block listed: the list's capacity
+        sizes, cls = [2113], [0]                           # bound (2 (T + 2)^2 blocks for T column tiles) is reached
+        f = np.tile(rng.standard_normal((1, C)), (2113, 1)).astype(np.float32)
     elif case == "identical_rows":                         # 5000 copies of one row: every block is listed -> fall-back
         sizes, cls = [500, 300, 5000], [0, 1, 2]
         f = np.concatenate([np.tile(rng.standard_normal((1, C)), (500, 1)), rng.standard_normal((300, C)),
