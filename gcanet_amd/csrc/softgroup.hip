@@ -442,6 +442,7 @@ struct SimArgs {
   const int32_t *seg_cls;         // (S) class of the segment, < 0 = inactive
   float thr_i, thr_p;
   int Ci, Cp;
+  int exact_only;                 // 1: evaluate every similarity from the rows (GCANET_BQ_EXACT=1: tools/debug/bq_fuzz.py)
 };
 
 // adjacency value of M4:210-233 from a squared feature distance: exp(-(d/dmax)^2 / 2), zero on the diagonal, NaN when
@@ -524,8 +525,8 @@ __global__ __launch_bounds__(256) void ballquery_sim_kernel(int n, float radius2
     return q;
   };
   const float dmi2v = sa.dmi2[sg], dmp2v = sa.dmp2[sg];
-  const bool fast_i = sa.thr_i <= 0.f && dmi2v > 0.f && dmi2v < __builtin_inff() && dmi2v >= 1e-4f * row_sq(pi);
-  const bool fast_p = sa.thr_p <= 0.f && dmp2v > 0.f && dmp2v < __builtin_inff() && dmp2v >= 1e-4f * row_sq(pp);
+  const bool fast_i = !sa.exact_only && sa.thr_i <= 0.f && dmi2v > 0.f && dmi2v < __builtin_inff() && dmi2v >= 1e-4f * row_sq(pi);
+  const bool fast_p = !sa.exact_only && sa.thr_p <= 0.f && dmp2v > 0.f && dmp2v < __builtin_inff() && dmp2v >= 1e-4f * row_sq(pp);
   auto in_radius = [&](int kk) -> bool {
     return sqdist3s(ox, oy, oz, xyz[kk * 3], xyz[kk * 3 + 1], xyz[kk * 3 + 2]) < radius2;
   };
@@ -917,7 +918,8 @@ GCN_EXPORT int gcn_ballquery_sim(int n, float radius, const float *xyz, const in
   const GridWs w = grid_ws_carve(grid_ws, n, 128 * n + 4096);     // segments x cells of edge ~radius: HBM is plentiful
   int rc = grid_build(w, n, xyz, seg_of, S, radius, st);
   if (rc) return rc;
-  SimArgs sa{feat_inst, feat_para, dmax2_inst, dmax2_para, seg_cls, thr_inst, thr_para, Ci, Cp};
+  const char *bq_exact = getenv("GCANET_BQ_EXACT");
+  SimArgs sa{feat_inst, feat_para, dmax2_inst, dmax2_para, seg_cls, thr_inst, thr_para, Ci, Cp, (bq_exact && bq_exact[0] == '1') ? 1 : 0};
   GCN_HIP(fill_dev(w.region, 0, sizeof(int32_t) * BQ_REGIONS * 32, st));
   ballquery_sim_kernel<<<cdiv(n, 4), 256, 0, st>>>(n, radius * radius, 3000, xyz, seg_of, seg_offsets, sa, w.g, w.cell_start,
                                                    w.packed, idx, capacity, start_len, w.region, status);
