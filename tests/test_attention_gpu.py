@@ -86,3 +86,36 @@ def test_mha_refuses_attention_dropout_in_training(dev):
         layer(torch.randn(2, 10, 32, device=dev))
     layer.eval()
     assert torch.isfinite(layer(torch.randn(2, 10, 32, device=dev))).all()
+
+
+@pytest.mark.parametrize("kw", [dict(iter_pred=False, attn_mask=False), dict(iter_pred=True, attn_mask=True, pe=True)])
+@pytest.mark.parametrize("precision", ["f32", "fp16"])
+def test_query_decoder_equal_length_batch_equals_per_cloud_loop(dev, kw, precision):
+    """Clouds of equal length take ONE attention launch over B*heads (gcanet_amd/query_decoder.py: CrossAttentionLayer);
+    the reference's per-cloud loop (query_decoder.py:32-43) is kept for ragged batches.  Same outputs and gradients:
+    offsets handed over as a device tensor keep the loop."""
+    from gcanet_amd.query_decoder import QueryDecoder
+    torch.manual_seed(3)
+    B, n, C = 3, 640, 16
+    Q = QueryDecoder(num_layer=2, num_query=20, num_class=5, in_channel=C, d_model=64, nhead=2, hidden_dim=64,
+                     precision=precision, **kw).to(dev)
+    x = torch.randn(B * n, C, device=dev)
+    offs = [i * n for i in range(B + 1)]
+    outs = []
+    for o in (offs, torch.tensor(offs, device=dev)):
+        Q.zero_grad()
+        xi = x.clone().requires_grad_()
+        r = Q(xi, o)
+        loss = r["labels"].float().sum() + r["parameters"].float().pow(2).sum() + sum(m.float().mean() for m in r["masks"])
+        loss.backward()
+        outs.append((r, xi.grad.clone(), {k: p.grad.clone() for k, p in Q.named_parameters() if p.grad is not None}))
+    (ra, ga, pa), (rb, gb, pb) = outs
+    tol = dict(rtol=1e-5, atol=1e-6) if precision == "f32" else dict(rtol=2e-3, atol=2e-4)
+    for k_ in ("labels", "scores", "parameters"):
+        np.testing.assert_allclose(ra[k_].detach().cpu().numpy(), rb[k_].detach().cpu().numpy(), **tol)
+    for ma, mb in zip(ra["masks"], rb["masks"]):
+        np.testing.assert_allclose(ma.detach().cpu().numpy(), mb.detach().cpu().numpy(), **tol)
+    np.testing.assert_allclose(ga.cpu().numpy(), gb.cpu().numpy(), rtol=tol["rtol"] * 10, atol=tol["atol"] * 10 * float(gb.abs().max()))
+    for k_ in pa:
+        np.testing.assert_allclose(pa[k_].cpu().numpy(), pb[k_].cpu().numpy(), rtol=tol["rtol"] * 10,
+                                   atol=tol["atol"] * 10 * float(pb[k_].abs().max()) + 1e-7, err_msg=k_)
