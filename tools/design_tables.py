@@ -149,6 +149,7 @@ GEN = {
     "gemm": lambda: t_log("r03_gemm_bench.log"),
     "knn_cases": lambda: t_log("r03_knn_fallback.log"),
     "segdiam": lambda: t_log("r03_segdiam_bench.log"),
+    "grouping": lambda: t_log("r03_grouping_bench.log"),
 }
 
 
