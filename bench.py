@@ -173,7 +173,7 @@ def pmc_traffic(tag):
         "knn_model[B=8,C=6,": ["gcn::knnn_prep_kernel", "gcn::knnn_sample_kernel", "gcn::knnn_filter_kernel",
                                "gcn::knnn_rerank_kernel"],
         "edgeconv_fwd[B=8,N=8192,k=64,C=64,Cout=128": ["gcn::edgeconv_center_kernel<4, 4>",
-                                                       "gcn::edgeconv_fwd_q_kernel<4, 4, 2, true, true, true>"],
+                                                       "gcn::edgeconv_fwd_q_kernel<4, 4, 2, true, true, true"],
     }
     for pre, names in parts.items():
         if tag.startswith(pre):
@@ -365,8 +365,13 @@ def cfg5_workload(dev, B=4, N=16384, k=64, steps=3, warmup=2):
             xf = net.last_xf                                                       # (B,N,256)
             gn = wide._modules["1"]
             xw, _ = dgcnn.edge_conv_pm(xf.float(), net.encoder.last_idx[2], wide._modules["0"].weight, gn, "f16", want_cm=False)
-        tok = tr(xf.float())                                                       # (B,N,256), attention in fp16
-        dec = qd(tok.reshape(B * N, 256), offs)
+        # the attention stacks as configs[4] names them: IEEE half -- the Linear layers under fp16 autocast (the library's
+        # f32 GEMMs were a third of this step), LayerNorm / softmax statistics / losses in f32, attention cores fp16 flash
+        with torch.autocast("cuda", dtype=torch.float16):
+            tok = tr(xf.float())                                                   # (B,N,256)
+            dec = qd(tok.reshape(B * N, 256), offs)
+        tok = tok.float()
+        dec = {k_: ([m_.float() for m_ in v] if isinstance(v, list) else v.float()) for k_, v in dec.items()}
         loss = loss_of(out) + xw.pow(2).mean() + tok.pow(2).mean() + dec["labels"].pow(2).mean() \
             + dec["scores"].pow(2).mean() + dec["parameters"].pow(2).mean() + sum(m_.pow(2).mean() for m_ in dec["masks"]) / B
         loss.backward()
@@ -382,7 +387,7 @@ def cfg5_workload(dev, B=4, N=16384, k=64, steps=3, warmup=2):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     return {"workload": "BASELINE configs[4], one GPU's share: %d clouds N=%d k=%d: hot path + EdgeConv 256->128 (IEEE-half operands on the matrix cores) + "
-                        "Transformer layer (dim 256, 8 heads, fp16 flash attention) + QueryDecoder (2 layers, 100 queries), "
+                        "Transformer layer (dim 256, 8 heads) + QueryDecoder (2 layers, 100 queries) under fp16 autocast with fp16 flash attention, "
                         "fwd+bwd+Adam, eager launches" % (B, N, k),
             "ms_per_step": round(dt * 1e3, 3), "clouds_per_s": round(B / dt, 2), "steps": steps, "warmup": warmup,
             "loss": float(info["loss"]), "finite": bool(torch.isfinite(info["loss"]))}

@@ -111,15 +111,15 @@ def t_traffic():
             ("knnf_keys_kernel<64>", "exact keys of ~197 candidates per query", None),
             ("knnf_rank_kernel<64>", "ranking + proof", None),
             ("knnn_filter_kernel<1>", "xyz+normal filter, all pairs", 8 * 8192 * 32 + 8 * 8192 * 8192 / 8),
-            ("edgeconv_fwd_q_kernel<4, 4, 2, true, true, true>", "EdgeConv 64->128 forward", 8 * 8192 * (64 * 2 + 64 * 8 + 128 * 5)),
+            ("edgeconv_fwd_q_kernel<4, 4, 2, true, true, true", "EdgeConv 64->128 forward", 8 * 8192 * (64 * 2 + 64 * 8 + 128 * 5)),
             ("group_points_lds_kernel<4, 1024>", "grouping_operation C=128 (north star)", 2.198e9),
             ("route_bwd_kernel", "EdgeConv backward routing", None),
-            ("rsum_gather_kernel<1>", "transposed aggregation", None)]
+            ("rsum_gather_kernel<1", "transposed aggregation", None)]
     L = ["| kernel | what | HBM bytes per launch (PMC, corrected) | algorithmic bytes |", "|---|---|---|---|"]
     for key, what, alg in want:
         for full, rec in d.items():
             if key in full:
-                L.append("| `%s` | %s | %.1f MB | %s |" % (key, what, rec["hbm_bytes_corrected"] / 1e6, ("%.1f MB" % (alg / 1e6)) if alg else "-"))
+                L.append("| `%s` | %s | %.1f MB | %s |" % (full.replace("gcn::", ""), what, rec["hbm_bytes_corrected"] / 1e6, ("%.1f MB" % (alg / 1e6)) if alg else "-"))
                 break
     return "\n".join(L)
 
@@ -145,7 +145,7 @@ GEN = {
     "step_kernels": t_step_kernels,
     "traffic": t_traffic,
     "full_workload": lambda: t_other("r03_full_workload_kernel_stats.csv", 7),
-    "cfg5": lambda: t_other("r03_cfg5_kernel_stats.csv", 5, top=10),
+    "cfg5": lambda: t_other("r03_cfg5_kernel_stats.csv", 7, top=10),
     "gemm": lambda: t_log("r03_gemm_bench.log"),
     "knn_cases": lambda: t_log("r03_knn_fallback.log"),
     "segdiam": lambda: t_log("r03_segdiam_bench.log"),
