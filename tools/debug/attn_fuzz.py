@@ -1,0 +1,46 @@
+"""Random shapes through the matrix-core attention kernels (csrc/attention_mfma.hip, bf16 and fp16) against the exact f32
+kernel (csrc/attention.hip): outputs and the three input gradients within the 16-bit budget; ragged lengths, 2-D and
+per-head masks (never a fully masked row), head dimensions 32 and 64."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from gcanet_amd.attention import sdpa  # noqa: E402
+
+dev = torch.device("cuda:0")
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+cases = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+bad = 0
+for it in range(cases):
+    BH = int(rng.integers(1, 9))
+    Lq = int(rng.choice([rng.integers(1, 40), rng.integers(40, 300), 100, 128, 129, rng.integers(300, 900)]))
+    Lk = int(rng.choice([rng.integers(1, 40), rng.integers(40, 300), 64, 65, 256, rng.integers(300, 1500)]))
+    D = int(rng.choice([32, 64]))
+    prec = str(rng.choice(["bf16", "fp16"]))
+    mk = str(rng.choice(["none", "2d", "3d"]))
+    q, k, v = (torch.randn(BH, L, D, generator=g).to(dev) for L in (Lq, Lk, Lk))
+    mask = None
+    if mk != "none":
+        shape = (Lq, Lk) if mk == "2d" else (BH, Lq, Lk)
+        mask = torch.rand(shape, generator=g) < 0.3
+        mask[..., 0] = False                                   # no fully masked row
+        mask = mask.to(dev)
+    gout = torch.randn(BH, Lq, D, generator=g).to(dev)
+    res = []
+    for p in ("f32", prec):
+        a, b, c = (t.clone().requires_grad_() for t in (q, k, v))
+        o = sdpa(a, b, c, mask, None, p)
+        (o * gout).sum().backward()
+        res.append((o.detach(), a.grad, b.grad, c.grad))
+    tol = 4e-2 if prec == "bf16" else 8e-3
+    for name, x, y in zip(("out", "dq", "dk", "dv"), res[0], res[1]):
+        err = float((x - y).abs().max() / (x.abs().max() + 1e-6))
+        if not (err <= tol) or not bool(torch.isfinite(y).all()):
+            bad += 1
+            print("MISMATCH case %d: BH=%d Lq=%d Lk=%d D=%d %s mask=%s: %s rel err %.3g" % (it, BH, Lq, Lk, D, prec, mk, name, err), flush=True)
+            break
+print("cases %d, mismatches %d" % (cases, bad))
