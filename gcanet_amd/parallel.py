@@ -65,6 +65,7 @@ class FlatGradDP:
             p.grad = v
         self._early_work = None
         self._early_done = False
+        self._zero = set()                          # parameters whose flat-gradient segment is known to hold zeros
         self.early_started_in_backward = 0          # statistics for tests / logs
         if latep:
             for p in latep:
@@ -84,11 +85,16 @@ class FlatGradDP:
     def _pack(self, lo, hi):
         dst, src = [], []
         for p, v in zip(self.params[lo:hi], self.views[lo:hi]):
-            if p.grad is None:
-                v.zero_()                       # parameter unused this step
+            if p.grad is None:                  # parameter unused this step: its segment of the flat gradient is zero
+                if id(p) not in self._zero:     # ... and stays zero (all-reduce sums zeros, Adam only reads): one fill, not
+                    v.zero_()                   # one per step
+                    self._zero.add(id(p))
             elif p.grad.data_ptr() != v.data_ptr():
+                self._zero.discard(id(p))
                 dst.append(v)
                 src.append(p.grad.detach().to(torch.float32))
+            else:                               # accumulated in place into the view (no zero_grad in between)
+                self._zero.discard(id(p))
             p.grad = v
         if dst:
             torch._foreach_copy_(dst, src)
