@@ -150,7 +150,10 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_mfma_kernel(const unsigned sh
                                                                const unsigned short *__restrict__ vt,
                                                                const unsigned char *__restrict__ mask, long mask_bh_stride,
                                                                int Lq, int Lk, int Lqp, int Lkp,
-                                                               float *__restrict__ out, float *__restrict__ lse) {
+                                                               float *__restrict__ out, float *__restrict__ lse,
+                                                               float *__restrict__ part) {
+  // gridDim.z > 1 (few query rows, many keys -- the query decoder's cross attention): workgroup z streams its share of
+  // the key tiles and leaves (unnormalised O, running maximum, running sum) in `part`; attn_fwd_combine_kernel joins them.
   constexpr int KS = D / 16;            // k-steps of S^T = K.Q^T
   constexpr int DB = D / 32;            // 32-row blocks of O^T
   constexpr int KT_BYTES = 64 * D * 2;  // K tile; the V^T tile is the same size
@@ -177,17 +180,18 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_mfma_kernel(const unsigned sh
     for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
   float m_run = -__builtin_inff(), l_run = 0.f;
 
-  const int ntiles = Lkp / 64;
+  const int tiles_all = Lkp / 64, tps = (tiles_all + (int)gridDim.z - 1) / (int)gridDim.z;
+  const int tbeg = (int)blockIdx.z * tps, ntiles = min(tiles_all, tbeg + tps);     // this workgroup's key tiles [tbeg, ntiles)
   auto issue = [&](int t, int buf) {
     unsigned char *base = smem + buf * 2 * KT_BYTES;
     dma_rm_tile<D>(kimg + (long)t * 64 * D, base, wave, lane, nwaves);
     dma_t_tile<D>(vimg + (long)t * 64, Lkp, base + KT_BYTES, wave, lane, nwaves);
   };
-  issue(0, 0);
+  if (tbeg < ntiles) issue(tbeg, tbeg & 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  for (int t = 0; t < ntiles; ++t) {
+  for (int t = tbeg; t < ntiles; ++t) {
     const int buf = t & 1;
     if (t + 1 < ntiles) issue(t + 1, buf ^ 1);
     const unsigned char *kt = smem + buf * 2 * KT_BYTES;
@@ -259,6 +263,23 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_mfma_kernel(const unsigned sh
   }
 
   const float l_tot = l_run + __shfl_xor(l_run, 32);
+  if (gridDim.z > 1) {
+    if (qrow < Lq) {
+      const long row = ((long)blockIdx.z * gridDim.y + bh) * Lq + qrow;
+      float *prow = part + row * (D + 4);                      // D values, maximum, sum, 2 pad floats: 16-byte rows
+#pragma unroll
+      for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          prow[32 * d + 8 * g + 4 * lh + 0] = o[d][4 * g];
+          prow[32 * d + 8 * g + 4 * lh + 1] = o[d][4 * g + 1];
+          prow[32 * d + 8 * g + 4 * lh + 2] = o[d][4 * g + 2];
+          prow[32 * d + 8 * g + 4 * lh + 3] = o[d][4 * g + 3];
+        }
+      if (lh == 0) { prow[D] = m_run; prow[D + 1] = l_tot; }
+    }
+    return;
+  }
   if (qrow < Lq) {
     const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
     float *orow = out + ((long)bh * Lq + qrow) * D;
@@ -271,6 +292,54 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_mfma_kernel(const unsigned sh
       }
     if (lse && lh == 0) lse[(long)bh * Lq + qrow] = (m_run + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;
   }
+}
+
+// joins the key-split partials: m = max_z m_z, l = sum_z l_z 2^(m_z - m), O = sum_z O_z 2^(m_z - m) / l; one thread per
+// (row, 4 channels); a split whose keys were all masked carries m_z = -inf and weight 0
+template <int D>
+__global__ __launch_bounds__(256) void attn_fwd_combine_kernel(const float *__restrict__ part, int splits, long rows,
+                                                               float *__restrict__ out, float *__restrict__ lse) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  const long row = e / (D / 4);
+  const int c4 = (int)(e % (D / 4));
+  if (row >= rows) return;
+  float m = -__builtin_inff();
+  for (int z = 0; z < splits; ++z) m = fmaxf(m, part[((long)z * rows + row) * (D + 4) + D]);
+  const float mu = m == -__builtin_inff() ? 0.f : m;
+  float l = 0.f;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int z = 0; z < splits; ++z) {
+    const float *p = part + ((long)z * rows + row) * (D + 4);
+    const float w = __builtin_amdgcn_exp2f(p[D] - mu);         // -inf -> 0
+    l = fmaf(p[D + 1], w, l);
+    const float4 v = *reinterpret_cast<const float4 *>(p + 4 * c4);
+    acc.x = fmaf(v.x, w, acc.x); acc.y = fmaf(v.y, w, acc.y); acc.z = fmaf(v.z, w, acc.z); acc.w = fmaf(v.w, w, acc.w);
+  }
+  const float inv = l > 0.f ? 1.f / l : 0.f;
+  *reinterpret_cast<float4 *>(out + row * D + 4 * c4) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+  if (lse && c4 == 0) lse[row] = (m + __builtin_amdgcn_logf(l)) * 0.6931471805599453f;
+}
+
+// sum of the key-split partial dQ tiles
+__global__ __launch_bounds__(256) void attn_sum_splits_kernel(const float4 *__restrict__ part, int splits, long n4, float4 *__restrict__ out) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n4) return;
+  float4 a = part[e];
+  for (int z = 1; z < splits; ++z) {
+    const float4 v = part[(long)z * n4 + e];
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  }
+  out[e] = a;
+}
+
+// Key splits of the forward and dQ kernels: only when the query side cannot fill the chip (fewer than 128 workgroups)
+// and there are enough key tiles to share out; at most 16.
+static inline int attn_key_splits(long row_wgs, int key_tiles) {
+  if (row_wgs >= 128 || key_tiles < 32) return 1;
+  long s = (256 + row_wgs - 1) / row_wgs;
+  if (s > key_tiles / 8) s = key_tiles / 8;
+  if (s > 16) s = 16;
+  return s < 2 ? 1 : (int)s;
 }
 
 // ---- backward -------------------------------------------------------------------------------------
@@ -324,6 +393,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const unsigned shor
                                                              const unsigned char *__restrict__ mask, long mask_bh_stride,
                                                              int Lq, int Lk, int Lqp, int Lkp, float scale,
                                                              float *__restrict__ dq) {
+  // gridDim.z > 1: workgroup z takes its share of the key tiles and writes a partial dQ (dq then points at
+  // [z][bh][Lq][D] partial tiles, summed by attn_sum_splits_kernel)
   constexpr int KS = D / 16, DB = D / 32, TB = 64 * D * 2;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];  // 2 x (K | V | K^T)
   const int lane = lane_id(), wave = wave_id();
@@ -347,17 +418,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const unsigned shor
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
 
-  const int ntiles = Lkp / 64;
+  const int tiles_all = Lkp / 64, tps = (tiles_all + (int)gridDim.z - 1) / (int)gridDim.z;
+  const int tbeg = (int)blockIdx.z * tps, ntiles = min(tiles_all, tbeg + tps);
   auto issue = [&](int t, int buf) {
     unsigned char *base = smem + buf * 3 * TB;
     dma_rm_tile<D>(kimg + (long)t * 64 * D, base, wave, lane);
     dma_rm_tile<D>(vimg + (long)t * 64 * D, base + TB, wave, lane);
     dma_t_tile<D>(ktimg + (long)t * 64, Lkp, base + 2 * TB, wave, lane);
   };
-  issue(0, 0);
+  if (tbeg < ntiles) issue(tbeg, tbeg & 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  for (int t = 0; t < ntiles; ++t) {
+  for (int t = tbeg; t < ntiles; ++t) {
     const int buf = t & 1;
     if (t + 1 < ntiles) issue(t + 1, buf ^ 1);
     const unsigned char *kt = smem + buf * 3 * TB, *vtile = kt + TB, *ktt = kt + 2 * TB;
@@ -397,7 +469,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const unsigned shor
     __syncthreads();
   }
   if (qrow < Lq) {
-    float *orow = dq + ((long)bh * Lq + qrow) * D;
+    float *orow = dq + (((long)blockIdx.z * gridDim.y + bh) * Lq + qrow) * D;
 #pragma unroll
     for (int d = 0; d < DB; ++d)
 #pragma unroll
@@ -528,6 +600,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const unsigned sho
 }
 
 static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+// operand images of gcn_attention_ws_bytes (the key-split partials start behind them, 256-byte aligned)
+static inline long attn_ws_base(int BH, int Lq, int Lk, int D) {
+  const long Lqp = round_up(Lq, 128), Lkp = round_up(Lk, 128);
+  return ((2L * BH * D * (4 * Lqp + 4 * Lkp) + 8L * BH * Lqp + 1024) + 255) & ~255L;
+}
 
 template <int D, bool F16>
 static int run_bwd(const float *q, const float *k, const float *v, const float *out, const float *dout, const float *lse,
@@ -538,6 +615,10 @@ static int run_bwd(const float *q, const float *k, const float *v, const float *
   unsigned short *qs = (unsigned short *)wsb, *qst = qs + nq, *dor = qst + nq, *dot = dor + nq;
   unsigned short *kr = dot + nq, *ktr = kr + nk, *vr = ktr + nk;
   float *delta = (float *)(vr + nk), *lse2 = delta + (size_t)BH * Lqp;
+  const int splits = attn_key_splits((long)BH * (Lqp / 128), Lkp / 64);
+  float *dq_out = dq;
+  if (splits > 1) dq_out = reinterpret_cast<float *>(wsb + attn_ws_base(BH, Lq, Lk, D));    // partial dQ tiles [split][BH][Lq][D]
+  const dim3 gq(Lqp / 128, BH, splits);
   attn_pack_kernel<D, F16><<<dim3(Lqp / 64, BH), 256, 0, st>>>(q, Lq, Lqp, scale * 1.4426950408889634f, qs, qst);
   attn_pack_kernel<D, F16><<<dim3(Lqp / 64, BH), 256, 0, st>>>(dout, Lq, Lqp, 1.f, dor, dot);
   attn_pack_kernel<D, F16><<<dim3(Lkp / 64, BH), 256, 0, st>>>(k, Lk, Lkp, 1.f, kr, ktr);
@@ -547,12 +628,17 @@ static int run_bwd(const float *q, const float *k, const float *v, const float *
   const int lds_q = 2 * 3 * 64 * D * 2, lds_kv = 2 * (4 * 64 * D * 2 + 1024);
   if (mask) {
     GCN_HIP(hipFuncSetAttribute((const void *)attn_bwd_dkv_kernel<D, true, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv));
-    attn_bwd_dq_kernel<D, true, F16><<<dim3(Lqp / 128, BH), 256, lds_q, st>>>(qs, kr, vr, ktr, dor, lse2, delta, mask, ms, Lq, Lk, Lqp, Lkp, scale, dq);
+    attn_bwd_dq_kernel<D, true, F16><<<gq, 256, lds_q, st>>>(qs, kr, vr, ktr, dor, lse2, delta, mask, ms, Lq, Lk, Lqp, Lkp, scale, dq_out);
     attn_bwd_dkv_kernel<D, true, F16><<<dim3(Lkp / 128, BH), 256, lds_kv, st>>>(qs, qst, kr, vr, dor, dot, lse2, delta, mask, ms, Lq, Lk, Lqp, Lkp, dk, dv);
   } else {
     GCN_HIP(hipFuncSetAttribute((const void *)attn_bwd_dkv_kernel<D, false, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv));
-    attn_bwd_dq_kernel<D, false, F16><<<dim3(Lqp / 128, BH), 256, lds_q, st>>>(qs, kr, vr, ktr, dor, lse2, delta, nullptr, 0, Lq, Lk, Lqp, Lkp, scale, dq);
+    attn_bwd_dq_kernel<D, false, F16><<<gq, 256, lds_q, st>>>(qs, kr, vr, ktr, dor, lse2, delta, nullptr, 0, Lq, Lk, Lqp, Lkp, scale, dq_out);
     attn_bwd_dkv_kernel<D, false, F16><<<dim3(Lkp / 128, BH), 256, lds_kv, st>>>(qs, qst, kr, vr, dor, dot, lse2, delta, nullptr, 0, Lq, Lk, Lqp, Lkp, dk, dv);
+  }
+  if (splits > 1) {
+    const long n4 = (long)BH * Lq * D / 4;
+    attn_sum_splits_kernel<<<(int)((n4 + 255) / 256), 256, 0, st>>>(reinterpret_cast<const float4 *>(dq_out), splits, n4,
+                                                                     reinterpret_cast<float4 *>(dq));
   }
   return check_launch("attn_bwd kernels");
 }
@@ -570,11 +656,17 @@ static int run_fwd(const float *q, const float *k, const float *v, const uint8_t
   const long ms = mask_per_bh ? (long)Lq * Lk : 0;
   // eight waves (256 query rows) per streamed tile when the padded length allows it: half the LDS-DMA work per row
   const int threads = (Lqp % 256 == 0) ? 512 : 256;
-  const dim3 grid(Lqp / (threads / 2), BH);
+  const int splits = attn_key_splits((long)BH * (Lqp / (threads / 2)), Lkp / 64);
+  float *part = splits > 1 ? reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(ws) + attn_ws_base(BH, Lq, Lk, D)) : nullptr;
+  const dim3 grid(Lqp / (threads / 2), BH, splits);
   if (mask)
-    attn_fwd_mfma_kernel<D, true, F16><<<grid, threads, lds, st>>>(qb, kb, vt, mask, ms, Lq, Lk, Lqp, Lkp, out, lse);
+    attn_fwd_mfma_kernel<D, true, F16><<<grid, threads, lds, st>>>(qb, kb, vt, mask, ms, Lq, Lk, Lqp, Lkp, out, lse, part);
   else
-    attn_fwd_mfma_kernel<D, false, F16><<<grid, threads, lds, st>>>(qb, kb, vt, nullptr, 0, Lq, Lk, Lqp, Lkp, out, lse);
+    attn_fwd_mfma_kernel<D, false, F16><<<grid, threads, lds, st>>>(qb, kb, vt, nullptr, 0, Lq, Lk, Lqp, Lkp, out, lse, part);
+  if (splits > 1) {
+    const long rows = (long)BH * Lq;
+    attn_fwd_combine_kernel<D><<<(int)((rows * (D / 4) + 255) / 256), 256, 0, st>>>(part, splits, rows, out, lse);
+  }
   return check_launch("attn_fwd_mfma_kernel");
 }
 
@@ -585,8 +677,10 @@ using namespace gcn;
 GCN_EXPORT long gcn_attention_ws_bytes(int BH, int Lq, int Lk, int D) {
   if (BH < 0 || Lq < 1 || Lk < 1 || D < 1) return -1;
   const long Lqp = round_up(Lq, 128), Lkp = round_up(Lk, 128);
-  // forward: Qs, K, V^T images; backward: Qs, Qs^T, dO, dO^T, K, K^T, V (all bf16), delta and lse2 (f32)
-  return 2L * BH * D * (4 * Lqp + 4 * Lkp) + 8L * BH * Lqp + 1024;
+  // forward: Qs, K, V^T images; backward: Qs, Qs^T, dO, dO^T, K, K^T, V (all bf16), delta and lse2 (f32); then up to 16
+  // key-split partials of (D + 4) floats per query row (forward) / D floats (dQ) when few query rows meet many keys
+  (void)Lqp; (void)Lkp;
+  return attn_ws_base(BH, Lq, Lk, D) + 16L * BH * Lq * (D + 4) * 4;
 }
 
 static int attention_fwd_16(bool f16, const float *q, const float *k, const float *v, const uint8_t *mask, int mask_per_bh,
