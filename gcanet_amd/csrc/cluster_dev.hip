@@ -51,6 +51,20 @@ __device__ __forceinline__ int uf_find(int32_t *parent, int x) {
   }
 }
 
+// every point directly under the root of its initial tree: the union pass then looks roots up in one or two steps
+// instead of walking the chains "point -> its smallest neighbour -> ..." of the initial forest edge by edge
+__global__ void cc_compress_kernel(int n, int32_t *parent) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int r = i;
+  for (;;) {                                   // parents only decrease and nobody hooks yet: a plain walk
+    const int p = ld_i(parent + r);
+    if (p == r) break;
+    r = p;
+  }
+  st_i(parent + i, r);
+}
+
 // wave per point, lanes across its neighbour list; the lists are symmetric, so the edges to smaller indices suffice
 __global__ __launch_bounds__(256) void cc_union_kernel(int n, const int32_t *__restrict__ nbr, const int32_t *__restrict__ start_len,
                                                        int32_t *parent) {
@@ -422,6 +436,7 @@ GCN_EXPORT int gcn_cluster_components(int n, const int32_t *nbr, const int32_t *
   int32_t *vals = work + 3L * n, *scan = vals + 4L * (n + 1);   // 2 x 4(n+1)
   int32_t *bsum = scan + 4L * (n + 1);
   cc_init_kernel<<<cdiv(n, 256), 256, 0, st>>>(n, nbr, start_len, parent, csize, key, visited, counters);
+  cc_compress_kernel<<<cdiv(n, 256), 256, 0, st>>>(n, parent);
   cc_union_kernel<<<cdiv(n, 4), 256, 0, st>>>(n, nbr, start_len, parent);
   cc_flatten_kernel<<<cdiv(n, 256), 256, 0, st>>>(n, parent, comp, csize);
   cluster_classify_kernel<<<cdiv(n + 1, 256), 256, 0, st>>>(n, comp, csize, seg_of, seg_cls, size_threshold, vals);
