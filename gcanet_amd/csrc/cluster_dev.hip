@@ -153,7 +153,11 @@ __global__ void cluster_offsets_kernel(int n, const int32_t *__restrict__ comp, 
   }
 }
 
-__global__ __launch_bounds__(1024) void cluster_bfs_kernel(const int32_t *__restrict__ nbr, const int32_t *__restrict__ start_len,
+// COMPACT: `nbr` is CLOBBERED -- the pass that counts a frontier node's winners compacts them to the front of the node's
+// own list (a node is in the frontier once and only its own wave reads its list), so the append pass copies winners, one
+// per point of the component, instead of scanning every list a third time (gcn_cluster_components_clobber).
+template <bool COMPACT>
+__global__ __launch_bounds__(1024) void cluster_bfs_kernel(int32_t *nbr, const int32_t *__restrict__ start_len,
                                                            const int32_t *__restrict__ work, int32_t *counters,
                                                            unsigned int *key, int32_t *visited, int32_t *base, int32_t *out) {
   __shared__ int s_item, s_total, s_wtot[16];
@@ -185,8 +189,11 @@ __global__ __launch_bounds__(1024) void cluster_bfs_kernel(const int32_t *__rest
         int w = 0;
         for (int b0 = 0; b0 < len; b0 += 64) {
           const int pos = b0 + lane;
-          const bool win = pos < len && ld_u(key + nbr[s + pos]) == (((unsigned int)t << 12) | (unsigned int)pos);
-          w += __popcll(__ballot(win));
+          const int v = pos < len ? nbr[s + pos] : 0;
+          const bool win = pos < len && ld_u(key + v) == (((unsigned int)t << 12) | (unsigned int)pos);
+          const unsigned long long mask = __ballot(win);
+          if (COMPACT && win) nbr[s + w + __popcll(mask & lt)] = v;  // w + rank <= pos: behind this wave's own reads
+          w += __popcll(mask);
         }
         if (lane == 0) st_i(base + o + t, w);
       }
@@ -211,15 +218,25 @@ __global__ __launch_bounds__(1024) void cluster_bfs_kernel(const int32_t *__rest
       for (int t = lo + wave; t < hi; t += 16) {
         const int u = ld_i(out + o + t);
         const int s = start_len[2 * u], len = start_len[2 * u + 1];
-        int off = hi + ld_i(base + o + t);
-        for (int b0 = 0; b0 < len; b0 += 64) {
-          const int pos = b0 + lane;
-          const int v = pos < len ? nbr[s + pos] : 0;
-          const bool win = pos < len && ld_u(key + v) == (((unsigned int)t << 12) | (unsigned int)pos);
-          const unsigned long long mask = __ballot(win);
-          const int q = off + __popcll(mask & lt);
-          if (win && q < m) { st_i(out + o + q, v); st_i(visited + v, 1); }
-          off += __popcll(mask);
+        const int off0 = ld_i(base + o + t);
+        if (COMPACT) {                                             // they sit compacted at the front of the node's list
+          const int cnt = (t + 1 < hi ? ld_i(base + o + t + 1) : total) - off0;
+          for (int i = lane; i < cnt; i += 64) {
+            const int v = nbr[s + i];
+            const int q = hi + off0 + i;
+            if (q < m) { st_i(out + o + q, v); st_i(visited + v, 1); }
+          }
+        } else {
+          int off = hi + off0;
+          for (int b0 = 0; b0 < len; b0 += 64) {
+            const int pos = b0 + lane;
+            const int v = pos < len ? nbr[s + pos] : 0;
+            const bool win = pos < len && ld_u(key + v) == (((unsigned int)t << 12) | (unsigned int)pos);
+            const unsigned long long mask = __ballot(win);
+            const int q = off + __popcll(mask & lt);
+            if (win && q < m) { st_i(out + o + q, v); st_i(visited + v, 1); }
+            off += __popcll(mask);
+          }
         }
       }
       lo = hi;
@@ -417,10 +434,10 @@ GCN_EXPORT long gcn_cluster_components_ws_bytes(int n) {
   return 4L * (20L * n + 64 + 4L * scan_blocks(n + 1));
 }
 
-GCN_EXPORT int gcn_cluster_components(int n, const int32_t *nbr, const int32_t *start_len, const int32_t *seg_of,
-                                      const int32_t *seg_offsets, const int32_t *seg_cls, int S,
-                                      const int32_t *point_index, float size_threshold, void *ws, int32_t *cluster_idxs,
-                                      int32_t *cluster_offsets, int32_t *counts, void *stream) {
+static int cluster_components(int n, int32_t *nbr, bool clobber, const int32_t *start_len, const int32_t *seg_of,
+                              const int32_t *seg_offsets, const int32_t *seg_cls, int S, const int32_t *point_index,
+                              float size_threshold, void *ws, int32_t *cluster_idxs, int32_t *cluster_offsets,
+                              int32_t *counts, void *stream) {
   GCN_REQUIRE(counts, "gcn_cluster_components: counts is null");
   GCN_REQUIRE(n >= 0 && n < (1 << 20) && S >= 1, "gcn_cluster_components: n=%d must be below 2^20 (queue rank is a 20-bit key field)", n);
   hipStream_t st = (hipStream_t)stream;
@@ -444,10 +461,27 @@ GCN_EXPORT int gcn_cluster_components(int n, const int32_t *nbr, const int32_t *
   exscan_rows(st, 4, n + 1, scan, bsum);
   cluster_offsets_kernel<<<cdiv(n, 256), 256, 0, st>>>(n, comp, csize, seg_of, seg_offsets, vals, scan, cluster_offsets, out,
                                                        visited, work, counters);
-  cluster_bfs_kernel<<<512, 1024, 0, st>>>(nbr, start_len, work, counters, key, visited, base, out);
+  if (clobber) cluster_bfs_kernel<true><<<512, 1024, 0, st>>>(nbr, start_len, work, counters, key, visited, base, out);
+  else cluster_bfs_kernel<false><<<512, 1024, 0, st>>>(nbr, start_len, work, counters, key, visited, base, out);
   cluster_emit_kernel<<<cdiv(n, 256), 256, 0, st>>>(n, counters, cluster_offsets, out, point_index, cluster_idxs);
   GCN_HIP(hipMemcpyAsync(counts, counters + 2, 2 * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
   return check_launch("cluster kernels");
+}
+
+GCN_EXPORT int gcn_cluster_components(int n, const int32_t *nbr, const int32_t *start_len, const int32_t *seg_of,
+                                      const int32_t *seg_offsets, const int32_t *seg_cls, int S,
+                                      const int32_t *point_index, float size_threshold, void *ws, int32_t *cluster_idxs,
+                                      int32_t *cluster_offsets, int32_t *counts, void *stream) {
+  return cluster_components(n, const_cast<int32_t *>(nbr), false, start_len, seg_of, seg_offsets, seg_cls, S, point_index,
+                            size_threshold, ws, cluster_idxs, cluster_offsets, counts, stream);
+}
+
+GCN_EXPORT int gcn_cluster_components_clobber(int n, int32_t *nbr, const int32_t *start_len, const int32_t *seg_of,
+                                              const int32_t *seg_offsets, const int32_t *seg_cls, int S,
+                                              const int32_t *point_index, float size_threshold, void *ws,
+                                              int32_t *cluster_idxs, int32_t *cluster_offsets, int32_t *counts, void *stream) {
+  return cluster_components(n, nbr, true, start_len, seg_of, seg_offsets, seg_cls, S, point_index, size_threshold, ws,
+                            cluster_idxs, cluster_offsets, counts, stream);
 }
 
 GCN_EXPORT long gcn_set_aggregation_ws_bytes(int n, int S) {

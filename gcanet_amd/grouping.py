@@ -166,7 +166,7 @@ def forward_grouping_device(semantic_scores, pt_offsets, batch_idxs, coords_floa
                       _lib.ptr(fp), fp.shape[1], _lib.ptr(dm[1]), float(similarity_threshold_para), _lib.ptr(nbr),
                       capacity, _lib.ptr(start_len), _lib.ptr(status), _lib.ptr(grid_ws), st)
             if not set_aggr:
-                _lib.call("gcn_cluster_components", n, _lib.ptr(nbr), _lib.ptr(start_len), _lib.ptr(seg_of),
+                _lib.call("gcn_cluster_components_clobber", n, _lib.ptr(nbr), _lib.ptr(start_len), _lib.ptr(seg_of),
                           _lib.ptr(seg_offsets), _lib.ptr(seg_cls), S, _lib.ptr(point_index), -1.0, _lib.ptr(ws),
                           _lib.ptr(cluster_idxs), _lib.ptr(cluster_offsets), _lib.ptr(status[4:]), st)
             else:
@@ -175,7 +175,7 @@ def forward_grouping_device(semantic_scores, pt_offsets, batch_idxs, coords_floa
                 all_idxs = torch.empty(n, 2, dtype=torch.int32, device=dev)
                 all_offs = torch.empty(n + 1, dtype=torch.int32, device=dev)
                 all_counts = torch.empty(2, dtype=torch.int32, device=dev)
-                _lib.call("gcn_cluster_components", n, _lib.ptr(nbr), _lib.ptr(start_len), _lib.ptr(seg_of),
+                _lib.call("gcn_cluster_components_clobber", n, _lib.ptr(nbr), _lib.ptr(start_len), _lib.ptr(seg_of),
                           _lib.ptr(seg_offsets), _lib.ptr(seg_cls), S, _lib.ptr(ident), -2.0, _lib.ptr(ws),
                           _lib.ptr(all_idxs), _lib.ptr(all_offs), _lib.ptr(all_counts), st)
                 cluster_idxs = torch.empty(2 * n, 2, dtype=torch.int32, device=dev)      # absorbed points appear twice

@@ -211,6 +211,12 @@ int gcn_cluster_components(int n, const int32_t *nbr, const int32_t *start_len, 
                            const int32_t *seg_offsets, const int32_t *seg_cls, int S, const int32_t *point_index,
                            float size_threshold, void *ws, int32_t *cluster_idxs, int32_t *cluster_offsets,
                            int32_t *counts, void *stream);
+/* The same result for a caller that does not need the neighbour lists afterwards: `nbr` is used as scratch (each node's
+ * discovered neighbours are compacted to the front of its list), which saves one of the three list scans per BFS level. */
+int gcn_cluster_components_clobber(int n, int32_t *nbr, const int32_t *start_len, const int32_t *seg_of,
+                                   const int32_t *seg_offsets, const int32_t *seg_cls, int S, const int32_t *point_index,
+                                   float size_threshold, void *ws, int32_t *cluster_idxs, int32_t *cluster_offsets,
+                                   int32_t *counts, void *stream);
 /* Set aggregation of hierarchical_aggregation (hierarchical_aggregation.cu:22-196, using_set_aggr = True: evaluation) on
  * the device.  Input: gcn_cluster_components(size_threshold = -2) -- ALL components per segment (fragments in discovery
  * order, then primaries; pass point_index = 0..n-1 there so that rows carry sorted positions), counts_in (2) device.
